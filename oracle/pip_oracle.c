@@ -1,0 +1,1610 @@
+/* oracle/pip_oracle.c -- TEST INFRASTRUCTURE (see pip_oracle.h).
+ *
+ * A CPU restatement of PipLib's parametric dual-simplex / Gomory-cut solver.
+ * It follows the reference function by function (each block names the
+ * reference file:line it restates) but is written against a flat row store of
+ * our own so that it doubles as an executable specification for the HIP
+ * engine in piplib_amd/csrc.  Integer arithmetic deliberately wraps modulo
+ * 2^ORACLE_BITS exactly like the reference's `long long` build does on x86-64.
+ */
+#define _GNU_SOURCE
+#include "pip_oracle.h"
+
+#include <ctype.h>
+#include <setjmp.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <time.h>
+
+#include "batchfmt.h"
+
+#define ENT_BITS ORACLE_BITS
+#define MAXCOL 512   /* type.h:44 */
+#define MAXPARM 50   /* type.h:45 */
+#define SOL_SIZE 4096 /* type.h:33 */
+#define MAXDET 4     /* tab.h:67 */
+
+/* ------------------------------------------------------------------ integers
+ * piplib.h:128-169 (macro layer of the SP/DP builds) and integrer.c:41-89. */
+static inline ent e_add(ent a, ent b) { return (ent)((uent)a + (uent)b); }
+static inline ent e_sub(ent a, ent b) { return (ent)((uent)a - (uent)b); }
+static inline ent e_mul(ent a, ent b) { return (ent)((uent)a * (uent)b); }
+static inline ent e_neg(ent a) { return (ent)((uent)0 - (uent)a); }
+static inline ent e_abs(ent a) { return a < 0 ? e_neg(a) : a; }
+static inline ent e_rem(ent a, ent b) { return b == -1 ? 0 : a % b; }       /* C '%', trap-free */
+static inline ent e_quo(ent a, ent b) { return b == -1 ? e_neg(a) : a / b; } /* C '/', trap-free */
+/* integrer.c:43-50: Euclid on signed values, absolute value of the result */
+static ent e_gcd(ent a, ent b) {
+  while (b) {
+    ent t = e_rem(a, b);
+    a = b;
+    b = t;
+  }
+  return e_abs(a);
+}
+/* integrer.c:69-74 */
+static inline ent e_mod(ent a, ent b) {
+  ent m = e_rem(a, b);
+  if (m < 0) m = e_add(m, e_abs(b));
+  return m;
+}
+/* piplib.h:147-149 */
+static inline ent e_floordiv(ent a, ent b) { return e_quo(e_sub(a, e_mod(a, b)), b); }
+/* integrer.c:51-59 (bit length of |x|, 1 for 0) */
+static int e_log2(ent x) {
+  uent u = (uent)e_abs(x);
+  int n = 0;
+  if (x != 0 && e_abs(x) < 0) return ENT_BITS; /* most negative value */
+  while (u) {
+    u >>= 1;
+    n++;
+  }
+  return n ? n : 1;
+}
+static int e_get_si(ent x) { return (int)x; }
+static void e_print(FILE *f, ent x) {
+#if ORACLE_BITS == 128
+  char buf[48];
+  int n = 0, neg = x < 0;
+  uent u = neg ? (uent)0 - (uent)x : (uent)x;
+  if (!u) buf[n++] = '0';
+  while (u) {
+    buf[n++] = (char)('0' + (int)(u % 10));
+    u /= 10;
+  }
+  if (neg) fputc('-', f);
+  while (n) fputc(buf[--n], f);
+#else
+  fprintf(f, "%lld", (long long)x);
+#endif
+}
+
+/* ------------------------------------------------------------------ row store
+ * tab.h:36-85, tab.c:158-220.  A tableau is `nrows` logical rows; a row is
+ * either a unit row (flag & OF_UNIT, identity on column `unit`) or a real row
+ * with `width` numerators `v[]` over the common denominator `den`. */
+typedef struct {
+  int flag, unit;
+  float size;
+  ent den;
+  ent *v;
+} orow;
+typedef struct otab {
+  int nrows, caprows, width;
+  int ldet;
+  ent det[MAXDET];
+  orow *row;
+} otab;
+
+struct ora {
+  /* arena of tableaux (tab.c high-water-mark allocator, tab.c:54-156) */
+  void **blk;
+  int nblk, capblk;
+  /* solution tape (sol.c:52-102) */
+  ora_cell *cell;
+  int ncell;
+  int deepest;
+  long long pivots, cuts;
+  jmp_buf trap;
+  int trapcode;
+};
+
+static void fail(ora *o, int code) {
+  o->trapcode = code;
+  longjmp(o->trap, 1);
+}
+static void *a_calloc(ora *o, size_t n, size_t sz) {
+  void *p = calloc(n ? n : 1, sz);
+  if (!p) fail(o, ORA_ERR_INTERNAL);
+  if (o->nblk == o->capblk) {
+    o->capblk = o->capblk ? 2 * o->capblk : 256;
+    o->blk = realloc(o->blk, sizeof(void *) * o->capblk);
+  }
+  o->blk[o->nblk++] = p;
+  return p;
+}
+static int a_mark(ora *o) { return o->nblk; }
+static void a_reset(ora *o, int mark) {
+  while (o->nblk > mark) free(o->blk[--o->nblk]);
+}
+
+/* tab.c:158-220 tab_alloc: `n` leading unit rows, then `h` zeroed real rows */
+static otab *tab_new(ora *o, int h, int w, int n) {
+  otab *t = a_calloc(o, 1, sizeof *t);
+  int i;
+  t->nrows = t->caprows = h + n;
+  t->width = w;
+  t->row = a_calloc(o, (size_t)(h + n), sizeof(orow));
+  t->det[0] = 1;
+  t->ldet = 1;
+  for (i = 0; i < n; i++) {
+    t->row[i].flag = OF_UNIT;
+    t->row[i].unit = i;
+    t->row[i].den = 1;
+  }
+  for (i = n; i < h + n; i++) t->row[i].v = a_calloc(o, (size_t)w, sizeof(ent));
+  return t;
+}
+/* traiter.c:55-88 expanser: copy `virt+reel-off` rows of tp (first ncol
+ * columns) into a fresh tableau with dh spare rows and dw spare columns,
+ * shifted down by `off` rows. */
+static otab *tab_grow(ora *o, const otab *tp, int virt, int reel, int ncol, int off, int dh, int dw) {
+  otab *r;
+  int i, j;
+  if (!tp) return NULL;
+  r = tab_new(o, reel + dh, ncol + dw, virt);
+  r->ldet = tp->ldet;
+  for (i = 0; i < tp->ldet; i++) r->det[i] = tp->det[i];
+  for (i = off; i < virt + reel; i++) {
+    const orow *s = &tp->row[i - off];
+    orow *d = &r->row[i];
+    d->flag = s->flag;
+    d->den = s->den;
+    if (s->flag & OF_UNIT) {
+      d->unit = s->unit;
+    } else {
+      if (!d->v) d->v = a_calloc(o, (size_t)(ncol + dw), sizeof(ent));
+      for (j = 0; j < ncol; j++) d->v[j] = s->v[j];
+    }
+  }
+  return r;
+}
+/* make sure logical row `r` exists as a real row and the width is >= w
+ * (the reference does this with expanser + spare rows, integrer.c:410-415,
+ * 500-506; only memory, no arithmetic) */
+static void tab_reserve(ora *o, otab *t, int r, int w) {
+  int i;
+  if (w > t->width) {
+    for (i = 0; i < t->caprows; i++)
+      if (t->row[i].v) {
+        ent *nv = a_calloc(o, (size_t)w, sizeof(ent));
+        memcpy(nv, t->row[i].v, sizeof(ent) * (size_t)t->width);
+        t->row[i].v = nv;
+      }
+    t->width = w;
+  }
+  if (r >= t->caprows) {
+    int nc = r + 16;
+    orow *nr = a_calloc(o, (size_t)nc, sizeof(orow));
+    memcpy(nr, t->row, sizeof(orow) * (size_t)t->caprows);
+    t->row = nr;
+    t->caprows = nc;
+  }
+  if (r >= t->nrows) t->nrows = r + 1;
+  if (!t->row[r].v) t->row[r].v = a_calloc(o, (size_t)t->width, sizeof(ent));
+}
+/* traiter.c:246-252 valeur */
+static inline ent cell_at(const otab *t, int i, int j) {
+  const orow *r = &t->row[i];
+  if (r->flag & OF_UNIT) return r->unit == j ? r->den : 0;
+  return r->v[j];
+}
+
+/* ------------------------------------------------------------ solution tape
+ * sol.c:89-226 */
+static ora_cell *tape_push(ora *o, int kind, ent a, ent b) {
+  ora_cell *c;
+  if (!o->cell) o->cell = malloc(sizeof(ora_cell) * SOL_SIZE);
+  c = &o->cell[o->ncell];
+  c->kind = kind;
+  c->a = a;
+  c->b = b;
+  o->ncell++;
+  if (o->ncell >= SOL_SIZE) fail(o, ORA_ERR_SOLSIZE); /* sol.c:96-100 */
+  return c;
+}
+static void tape_nil(ora *o) { tape_push(o, OS_NIL, 0, 0); }
+static void tape_if(ora *o) { tape_push(o, OS_IF, 0, 0); }
+static void tape_list(ora *o, int n) { tape_push(o, OS_LIST, n, 0); }
+static void tape_form(ora *o, int n) { tape_push(o, OS_FORM, n, 0); }
+static void tape_new(ora *o, int k) { tape_push(o, OS_NEW, k, 0); }
+static void tape_div(ora *o) { tape_push(o, OS_DIV, 0, 0); }
+static void tape_val(ora *o, ent n, ent d) { tape_push(o, OS_VAL, n, d); }
+
+/* ------------------------------------------------------------------ pivoting */
+/* traiter.c:39-44 chercher */
+static int first_flagged(const otab *t, int mask, int n) {
+  int i;
+  for (i = 0; i < n; i++)
+    if (t->row[i].flag & mask) break;
+  return i;
+}
+static inline int sgn_flag(ent x) { return x < 0 ? OF_MINUS : (x > 0 ? OF_PLUS : OF_ZERO); }
+
+/* traiter.c:101-159 exam_coef: settle "obvious" signs of Unknown rows from
+ * the parametric part; stop at the first row proven negative. */
+static int classify_rows(otab *t, int nvar, int ncol, int bigparm, int nligne) {
+  int i, j;
+  if (bigparm >= 0)
+    for (i = 0; i < nligne; i++) {
+      orow *r = &t->row[i];
+      if (r->flag != OF_UNKNOWN) continue;
+      if (r->v[bigparm] < 0) {
+        r->flag = OF_MINUS;
+        return i;
+      } else if (r->v[bigparm] > 0)
+        r->flag = OF_PLUS;
+    }
+  for (i = 0; i < nligne; i++) {
+    orow *r = &t->row[i];
+    int ff = r->flag, fc;
+    if (ff == 0) break;
+    if (ff != OF_UNKNOWN) continue;
+    ff = OF_ZERO;
+    for (j = nvar + 1; j < ncol; j++) {
+      int fj = sgn_flag(r->v[j]);
+      if (fj != OF_ZERO && fj != ff) {
+        if (ff == OF_ZERO)
+          ff = fj;
+        else {
+          ff = OF_UNKNOWN;
+          break;
+        }
+      }
+    }
+    fc = sgn_flag(r->v[nvar]); /* constant term, traiter.c:138-140 */
+    if (ff == OF_PLUS) {
+      if (fc == OF_MINUS) ff = OF_UNKNOWN;
+    } else if (ff == OF_ZERO) {
+      ff = fc;
+    } else if (ff == OF_MINUS) {
+      if (fc != OF_MINUS) ff = OF_UNKNOWN;
+    }
+    r->flag = ff;
+    if (ff == OF_MINUS) return i;
+  }
+  return i;
+}
+
+/* traiter.c:297-341 choisir_piv: among the columns with a positive entry in
+ * the pivot row, the one whose column vector divided by that entry is
+ * lexicographically smallest (cross-multiplied, first difference decides). */
+static int pick_column(const otab *t, int pivi, int nvar, int nligne) {
+  int j, k, pivj = -1;
+  ent pivot = 0, x = 0;
+  for (j = 0; j < nvar; j++) {
+    ent foo = t->row[pivi].v[j];
+    if (!(foo > 0)) continue;
+    if (pivj < 0) {
+      pivj = j;
+      pivot = foo;
+      continue;
+    }
+    for (k = 0; k < nligne; k++) {
+      x = e_sub(e_mul(pivot, cell_at(t, k, j)), e_mul(cell_at(t, k, pivj), foo));
+      if (x != 0) break;
+    }
+    if (x < 0) {
+      pivj = j;
+      pivot = foo;
+    }
+  }
+  return pivj;
+}
+
+/* traiter.c:345-548 pivoter */
+static int pivot_step(ora *o, otab *t, int pivi, int nvar, int nparm, int ni) {
+  int ncol = nvar + nparm + 1, nligne = nvar + ni;
+  int i, j, k, pivj;
+  ent pivot, dpiv, d, ppivot, dppiv, *fresh, *prow;
+  if (pivi < 0 || pivi >= nligne || t->row[pivi].flag == OF_UNIT) fail(o, ORA_ERR_INTERNAL);
+  o->pivots++;
+  pivj = pick_column(t, pivi, nvar, nligne);
+  if (pivj < 0) return -1;
+  prow = t->row[pivi].v;
+  pivot = prow[pivj];
+  dpiv = t->row[pivi].den;
+  d = e_gcd(pivot, dpiv);
+  ppivot = e_quo(pivot, d);
+  dppiv = e_quo(dpiv, d);
+  /* multi-limb determinant bookkeeping, traiter.c:412-446 */
+  for (i = 0; i < t->ldet; i++) {
+    d = e_gcd(t->det[i], dppiv);
+    t->det[i] = e_quo(t->det[i], d);
+    dppiv = e_quo(dppiv, d);
+  }
+  if (dppiv != 1) fail(o, ORA_ERR_OVERFLOW);
+  for (i = 0; i < t->ldet; i++)
+    if (e_log2(t->det[i]) + e_log2(ppivot) < ENT_BITS) {
+      t->det[i] = e_mul(t->det[i], ppivot);
+      break;
+    }
+  if (i >= t->ldet) {
+    t->ldet++;
+    if (t->ldet >= MAXDET) fail(o, ORA_ERR_OVERFLOW);
+    t->det[i] = ppivot;
+  }
+  /* the row that will replace the unit row of column pivj, traiter.c:461-465 */
+  fresh = a_calloc(o, (size_t)t->width, sizeof(ent));
+  for (j = 0; j < ncol; j++) fresh[j] = (j == pivj) ? dpiv : e_neg(prow[j]);
+  /* eliminate column pivj from every other real row, traiter.c:467-502 */
+  for (k = 0; k < nligne; k++) {
+    orow *r = &t->row[k];
+    ent foo, lpiv, g;
+    if ((r->flag & OF_UNIT) || k == pivi) continue;
+    foo = r->v[pivj];
+    d = e_gcd(pivot, foo);
+    lpiv = e_quo(pivot, d);
+    foo = e_quo(foo, d);
+    g = e_mul(lpiv, r->den);
+    r->den = g;
+    for (j = 0; j < ncol; j++) {
+      ent z = (j == pivj) ? e_mul(dpiv, foo) : e_sub(e_mul(r->v[j], lpiv), e_mul(prow[j], foo));
+      r->v[j] = z;
+      if (g != 1) g = e_gcd(g, z);
+    }
+    if (g != 1) {
+      for (j = 0; j < ncol; j++) r->v[j] = e_quo(r->v[j], g);
+      r->den = e_quo(r->den, g);
+    }
+  }
+  /* swap roles: unit row of pivj becomes real, pivot row becomes unit,
+   * traiter.c:503-516 */
+  for (k = 0; k < nligne; k++)
+    if ((t->row[k].flag & OF_UNIT) && t->row[k].unit == pivj) break;
+  if (k >= nligne) fail(o, ORA_ERR_INTERNAL);
+  t->row[k].flag = OF_PLUS;
+  t->row[k].v = fresh;
+  t->row[k].den = pivot;
+  t->row[pivi].flag = OF_UNIT | OF_ZERO;
+  t->row[pivi].den = 1;
+  t->row[pivi].unit = pivj;
+  t->row[pivi].v = NULL;
+  /* sign hints after the pivot, traiter.c:518-529 */
+  for (k = 0; k < nligne; k++) {
+    orow *r = &t->row[k];
+    int ff = r->flag, fff;
+    if (ff & OF_UNIT) continue;
+    fff = sgn_flag(r->v[pivj]);
+    if (fff != OF_ZERO && fff != ff) {
+      if (ff == OF_ZERO)
+        ff = (fff == OF_MINUS) ? OF_UNKNOWN : fff;
+      else
+        ff = OF_UNKNOWN;
+    }
+    r->flag = ff;
+  }
+  return 0;
+}
+
+/* traiter.c:556-623 tab_sort_rows: selection sort of the non-unit rows
+ * nvar..nligne-1 by max |trunc(coef/denominator)| over the unknowns. */
+static int x86_trunc_int(double t) {
+  /* (int)t as cvttsd2si computes it: out-of-range -> INT_MIN */
+  if (!(t > -2147483649.0 && t < 2147483648.0)) return (int)0x80000000;
+  return (int)t;
+}
+static int *sort_rows(ora *o, otab *t, int nvar, int nligne, int flags) {
+  int i, j, pivi, *pos = NULL, *ineq = NULL;
+  double s, smax = 0;
+  if (flags & OT_DUAL) {
+    ineq = a_calloc(o, (size_t)t->nrows + 1, sizeof(int));
+    pos = a_calloc(o, (size_t)(t->nrows - nvar) + 1, sizeof(int));
+  }
+  for (i = nvar; i < nligne; i++) {
+    orow *r = &t->row[i];
+    double d;
+    if (r->flag & OF_UNIT) continue;
+    s = 0;
+    d = (double)r->den;
+    for (j = 0; j < nvar; j++) {
+      int q = x86_trunc_int((double)r->v[j] / d);
+      double a = (double)(q < 0 ? (int)(0u - (unsigned)q) : q); /* abs() incl. INT_MIN */
+      s = s > a ? s : a;
+    }
+    r->size = (float)s;
+    smax = s > smax ? s : smax;
+    if (ineq) ineq[i] = i - nvar;
+  }
+  for (i = nvar; i < nligne; i++) {
+    if (t->row[i].flag & OF_UNIT) continue;
+    s = smax;
+    pivi = i;
+    for (j = i; j < nligne; j++) {
+      if (t->row[j].flag & OF_UNIT) continue;
+      if (t->row[j].size < s) {
+        s = t->row[j].size;
+        pivi = j;
+      }
+    }
+    if (pivi != i) {
+      orow tmp = t->row[pivi];
+      t->row[pivi] = t->row[i];
+      t->row[i] = tmp;
+      if (ineq) {
+        j = ineq[i];
+        ineq[i] = ineq[pivi];
+        ineq[pivi] = j;
+      }
+    }
+  }
+  if (ineq)
+    for (i = nvar; i < nligne; i++) pos[ineq[i]] = i;
+  return pos;
+}
+
+static void solve_node(ora *o, otab *tp, otab *ctxt, int nvar, int nparm, int ni, int nc, int bigparm,
+                       int flags);
+
+/* traiter.c:162-243 compa_test: for every Critic/Unknown row decide, by two
+ * integer feasibility problems over the context, whether the row's
+ * parametric value can be >0 / <0 there. */
+static void context_tests(ora *o, otab *tp, otab *context, int ni, int nvar, int nparm, int nc) {
+  int i, j, mark;
+  if (nparm == 0) return;
+  if (nparm >= MAXPARM) fail(o, ORA_ERR_PARMS);
+  mark = a_mark(o);
+  for (i = 0; i < ni + nvar; i++) {
+    orow *r = &tp->row[i];
+    int critic = 1, can_pos, can_neg, p;
+    otab *tt;
+    orow *last;
+    if (!(r->flag & (OF_CRITIC | OF_UNKNOWN))) continue;
+    for (j = 0; j < nvar; j++)
+      if (r->v[j] > 0) {
+        critic = 0;
+        break;
+      }
+    /* "row >= 1" (or >= 0 for a critical row) added to the context */
+    tt = tab_grow(o, context, nparm, nc, nparm + 1, nparm, 1, 0);
+    last = &tt->row[nparm + nc];
+    last->flag = OF_UNKNOWN;
+    for (j = 0; j < nparm; j++) last->v[j] = r->v[j + nvar + 1];
+    last->v[nparm] = r->v[nvar];
+    if (!critic) last->v[nparm] = e_sub(last->v[nparm], 1);
+    last->den = 1;
+    p = o->ncell;
+    solve_node(o, tt, NULL, nparm, 0, nc + 1, 0, -1, OT_INT);
+    can_pos = o->cell[p].kind != OS_NIL;
+    o->ncell = p;
+    /* "-row >= 1" */
+    tt = tab_grow(o, context, nparm, nc, nparm + 1, nparm, 1, 0);
+    last = &tt->row[nparm + nc];
+    last->flag = OF_UNKNOWN;
+    for (j = 0; j < nparm; j++) last->v[j] = e_neg(r->v[j + nvar + 1]);
+    last->v[nparm] = e_sub(e_neg(r->v[nvar]), 1);
+    last->den = 1;
+    solve_node(o, tt, NULL, nparm, 0, nc + 1, 0, -1, OT_INT);
+    can_neg = o->cell[p].kind != OS_NIL;
+    o->ncell = p;
+    if (can_pos && can_neg)
+      r->flag = critic ? OF_CRITIC : OF_UNKNOWN;
+    else if (can_neg) {
+      r->flag = OF_MINUS;
+      break;
+    } else
+      r->flag = can_pos ? OF_PLUS : OF_ZERO;
+  }
+  a_reset(o, mark);
+}
+
+/* traiter.c:255-294 solution / solution_dual */
+static void emit_solution(ora *o, const otab *tp, int nvar, int nparm) {
+  int i, j, ncol = nvar + nparm + 1;
+  tape_list(o, nvar);
+  for (i = 0; i < nvar; i++) {
+    tape_form(o, nparm + 1);
+    for (j = nvar + 1; j < ncol; j++) tape_val(o, cell_at(tp, i, j), tp->row[i].den);
+    tape_val(o, cell_at(tp, i, nvar), tp->row[i].den);
+  }
+}
+static void emit_dual(ora *o, const otab *tp, int nvar, const int *pos, int height) {
+  int i;
+  tape_list(o, height - nvar);
+  for (i = 0; i < height - nvar; i++) {
+    tape_form(o, 1);
+    if (tp->row[pos[i]].flag & OF_UNIT)
+      tape_val(o, cell_at(tp, 0, tp->row[pos[i]].unit), tp->row[0].den);
+    else
+      tape_val(o, 0, 1);
+  }
+}
+
+/* ------------------------------------------------------------- Gomory cuts */
+/* integrer.c:98-150 bezout: z with z*y == x (mod delta) when gcd(y,delta)==1 */
+static ent bezout(ent x, ent y, ent delta) {
+  ent a = 1, b = 0, c = 0, d = 1, u = y, v = delta;
+  for (;;) {
+    ent q = e_floordiv(u, v), r = e_mod(u, v), e, f;
+    if (r == 0) break;
+    u = v;
+    v = r;
+    e = e_sub(a, e_mul(q, c));
+    f = e_sub(b, e_mul(q, d));
+    a = c;
+    b = d;
+    c = e;
+    d = f;
+  }
+  if (v != 1) return 0;
+  return e_mod(e_mul(c, x), delta);
+}
+/* context kept as an otab with nparm+1 (+spare) columns: parameters | constant */
+/* integrer.c:230-254 has_cut */
+static int ctx_has_cut(const otab *cx, int nr, int nparm, int p, const ent *cut) {
+  int row, col;
+  for (row = 0; row < nr; row++) {
+    const ent *v = cx->row[row].v;
+    if (v[p] != cut[1 + nparm]) continue;
+    if (v[nparm] != cut[0]) continue;
+    for (col = p + 1; col < nparm; col++)
+      if (v[col] != 0) break;
+    if (col < nparm) continue;
+    for (col = 0; col < p; col++)
+      if (v[col] != cut[1 + col]) break;
+    if (col < p) continue;
+    return 1;
+  }
+  return 0;
+}
+/* integrer.c:258-291 find_parm: is the quotient this cut needs already a
+ * parameter defined by an earlier cut?  cut = constant | parameters | divisor */
+static int ctx_find_parm(const otab *cx, int nr, int nparm, ent *cut) {
+  int p, col, found;
+  if (cut[1 + nparm - 1] != 0) return -1;
+  cut[0] = e_sub(e_add(cut[0], cut[1 + nparm]), 1);
+  for (p = nparm - 1; p >= 0; --p) {
+    if (cut[1 + p] != 0) break;
+    if (!ctx_has_cut(cx, nr, nparm, p, cut)) continue;
+    cut[0] = e_sub(e_add(cut[0], 1), cut[1 + nparm]);
+    for (col = 0; col < 1 + nparm + 1; col++) cut[col] = e_neg(cut[col]);
+    found = ctx_has_cut(cx, nr, nparm, p, cut);
+    for (col = 0; col < 1 + nparm + 1; col++) cut[col] = e_neg(cut[col]);
+    if (found) return p;
+    cut[0] = e_sub(e_add(cut[0], cut[1 + nparm]), 1);
+  }
+  cut[0] = e_sub(e_add(cut[0], 1), cut[1 + nparm]);
+  return -1;
+}
+/* integrer.c:156-227 add_parm: declare q = floor(-(cut . (1,p))/D) as a new
+ * parameter: tape entry + two context rows 0 <= -cut.(1,p) - D q < D. */
+static void ctx_add_parm(ora *o, otab *cx, int nr, int *pnparm, int *pnc, const ent *cut) {
+  int nparm = *pnparm, j, k;
+  ent x;
+  tape_new(o, nparm);
+  tape_div(o);
+  tape_form(o, nparm + 1);
+  for (j = 0; j < nparm; j++) tape_val(o, e_neg(cut[1 + j]), 1);
+  tape_val(o, e_neg(cut[0]), 1);
+  tape_val(o, cut[1 + nparm], 1);
+  tab_reserve(o, cx, nr + 1, nparm + 2);
+  tab_reserve(o, cx, nr, nparm + 2);
+  for (k = 0; k < nr; k++) {
+    cx->row[k].v[nparm + 1] = cx->row[k].v[nparm];
+    cx->row[k].v[nparm] = 0;
+  }
+  for (j = 0; j < nparm; j++) {
+    cx->row[nr].v[j] = e_neg(cut[1 + j]);
+    cx->row[nr + 1].v[j] = cut[1 + j];
+  }
+  cx->row[nr].v[nparm] = e_neg(cut[1 + nparm]);
+  cx->row[nr + 1].v[nparm] = cut[1 + nparm];
+  x = cut[0];
+  cx->row[nr].v[nparm + 1] = e_neg(x);
+  x = e_sub(x, 1);
+  cx->row[nr + 1].v[nparm + 1] = e_add(x, cut[1 + nparm]);
+  cx->row[nr].flag = cx->row[nr + 1].flag = OF_UNKNOWN;
+  cx->row[nr].den = cx->row[nr + 1].den = 1;
+  (*pnparm)++;
+  (*pnc) += 2;
+}
+
+/* integrer.c:305-534 integrer: returns the index of a freshly appended
+ * (negative) cut row, 0 when the first nvar rows are integral, -1 when no
+ * integral point exists. */
+static int gomory(ora *o, otab *tp, otab *cx, int *pnvar, int *pnparm, int *pni, int *pnc, int bigparm) {
+  int nvar = *pnvar, nparm = *pnparm, ni = *pni, nc = *pnc;
+  int ncol = nvar + nparm + 1, nligne = nvar + ni;
+  int i, j, parm;
+  ent cut[MAXCOL + 1];
+  if (ncol >= MAXCOL) fail(o, ORA_ERR_COLS);
+  for (i = 0; i < nvar; i++) {
+    orow *r = &tp->row[i];
+    ent D = r->den, x;
+    int ok_var = 0, ok_const, ok_parm = 0;
+    if (D == 1) continue;
+    if (r->flag & OF_UNIT) continue;
+    for (j = 0; j < nvar; j++) {
+      x = e_mod(r->v[j], D);
+      cut[j] = x;
+      if (x > 0) ok_var = 1;
+    }
+    x = e_neg(e_mod(e_neg(r->v[nvar]), D));
+    cut[nvar] = x;
+    ok_const = (x != 0);
+    for (j = nvar + 1; j < ncol; j++) {
+      if (j == bigparm) { /* the big parameter is a multiple of everything */
+        cut[j] = 0;
+        continue;
+      }
+      cut[j] = e_neg(e_mod(e_neg(r->v[j]), D));
+      if (cut[j] != 0) ok_parm = 1;
+    }
+    cut[ncol] = D;
+    if (!ok_parm && !ok_const) continue; /* integral row */
+    if (!ok_parm) {
+      orow *nr;
+      if (!ok_var) return -1; /* constant fractional, nothing to cut with */
+      /* constant cut, integrer.c:409-481 */
+      if (o->deepest) {
+        ent t = e_neg(cut[nvar]), delta = e_gcd(t, D), tau = e_quo(t, delta), dd = e_quo(D, delta), lambda;
+        t = e_sub(dd, 1);
+        lambda = bezout(t, tau, dd);
+        t = e_gcd(lambda, D);
+        while (t != 1) {
+          lambda = e_add(lambda, dd);
+          t = e_gcd(lambda, D);
+        }
+        for (j = 0; j < nvar; j++) cut[j] = e_mod(e_mul(lambda, cut[j]), D);
+        t = e_mod(e_mul(cut[nvar], lambda), D);
+        t = e_sub(D, t);
+        cut[nvar] = e_neg(t);
+      }
+      tab_reserve(o, tp, nligne, tp->width);
+      nr = &tp->row[nligne];
+      nr->flag = OF_MINUS;
+      nr->den = D;
+      for (j = 0; j < ncol; j++) nr->v[j] = cut[j];
+      (*pni)++;
+      o->cuts++;
+      return nligne;
+    }
+    /* parametric cut, integrer.c:487-520 */
+    parm = ctx_find_parm(cx, nc, nparm, cut + nvar);
+    if (parm == -1) {
+      ctx_add_parm(o, cx, nc, pnparm, pnc, cut + nvar);
+      parm = nparm;
+    }
+    if (!ok_var) fail(o, ORA_ERR_ASSERT);
+    tab_reserve(o, tp, nligne, ncol + 1 > tp->width ? ncol + 1 : tp->width);
+    {
+      orow *nr = &tp->row[nligne];
+      nr->flag = OF_MINUS;
+      nr->den = D;
+      for (j = 0; j < ncol; j++) nr->v[j] = cut[j];
+      nr->v[nvar + 1 + parm] = e_add(nr->v[nvar + 1 + parm], cut[ncol]);
+    }
+    (*pni)++;
+    o->cuts++;
+    return nligne;
+  }
+  return 0;
+}
+
+/* ----------------------------------------------------------------- traiter
+ * traiter.c:628-791 */
+static void solve_node(ora *o, otab *tp, otab *ctxt, int nvar, int nparm, int ni, int nc, int bigparm,
+                       int flags) {
+  int mark = a_mark(o), j, pivi, nligne, ncol, *pos;
+  otab *context = tab_grow(o, ctxt, 0, nc, nparm + 1, 0, 4, 2);
+  nligne = nvar + ni;
+  pos = sort_rows(o, tp, nvar, nligne, flags);
+  for (;;) {
+    nligne = nvar + ni;
+    ncol = nvar + nparm + 1;
+    pivi = first_flagged(tp, OF_MINUS, nligne);
+    if (pivi < nligne) goto pirouette;
+    pivi = classify_rows(tp, nvar, ncol, bigparm, nligne);
+    if (pivi < nligne) goto pirouette;
+    context_tests(o, tp, context, ni, nvar, nparm, nc);
+    pivi = first_flagged(tp, OF_MINUS, nligne);
+    if (pivi < nligne) goto pirouette;
+    pivi = first_flagged(tp, OF_CRITIC, nligne);
+    if (pivi >= nligne) pivi = first_flagged(tp, OF_UNKNOWN, nligne);
+    if (pivi < nligne) {
+      /* the quast forks on the sign of row pivi, traiter.c:695-759 */
+      otab *ntp;
+      ent g = 0;
+      int q;
+      orow *cr;
+      if (nparm >= MAXPARM) fail(o, ORA_ERR_PARMS);
+      tab_reserve(o, context, nc, nparm + 1);
+      q = a_mark(o);
+      ntp = tab_grow(o, tp, nvar, ni, ncol, 0, 0, 0);
+      tape_if(o);
+      tape_form(o, nparm + 1);
+      for (j = 0; j < nparm; j++) g = e_gcd(g, tp->row[pivi].v[j + nvar + 1]);
+      if (!(flags & OT_INT)) g = e_gcd(g, tp->row[pivi].v[nvar]);
+      cr = &context->row[nc];
+      for (j = 0; j < nparm; j++) {
+        cr->v[j] = e_quo(tp->row[pivi].v[j + nvar + 1], g);
+        tape_val(o, cr->v[j], 1);
+      }
+      if (!(flags & OT_INT))
+        cr->v[nparm] = e_quo(tp->row[pivi].v[nvar], g);
+      else
+        cr->v[nparm] = e_floordiv(tp->row[pivi].v[nvar], g);
+      tape_val(o, cr->v[nparm], 1);
+      cr->flag = OF_UNKNOWN;
+      cr->den = 1;
+      ntp->row[pivi].flag = OF_PLUS;
+      solve_node(o, ntp, context, nvar, nparm, ni, nc + 1, bigparm, flags);
+      a_reset(o, q);
+      for (j = 0; j < nparm; j++) cr->v[j] = e_neg(cr->v[j]);
+      cr->v[nparm] = e_neg(e_add(cr->v[nparm], 1));
+      tp->row[pivi].flag = OF_MINUS;
+      cr->den = 1;
+      nc++;
+      goto pirouette;
+    }
+    if (!(flags & OT_INT)) {
+      emit_solution(o, tp, nvar, nparm);
+      if (flags & OT_DUAL) emit_dual(o, tp, nvar, pos, tp->nrows);
+      break;
+    }
+    pivi = gomory(o, tp, context, &nvar, &nparm, &ni, &nc, bigparm);
+    if (pivi > 0) goto pirouette;
+    if (pivi == 0)
+      emit_solution(o, tp, nvar, nparm);
+    else
+      tape_nil(o);
+    break;
+  pirouette:
+    if (pivot_step(o, tp, pivi, nvar, nparm, ni) < 0) {
+      tape_nil(o);
+      break;
+    }
+  }
+  a_reset(o, mark);
+}
+
+/* tab.c:396-427 tab_simplify */
+static void simplify_rows(otab *t, int cst) {
+  int i, j;
+  for (i = 0; i < t->nrows; i++) {
+    orow *r = &t->row[i];
+    ent g = 0;
+    if (r->flag & OF_UNIT) continue;
+    for (j = 0; j < t->width; j++) {
+      if (j == cst) continue;
+      g = e_gcd(g, r->v[j]);
+      if (g == 1) break;
+    }
+    if (g == 0 || g == 1) continue;
+    for (j = 0; j < t->width; j++)
+      r->v[j] = (j == cst) ? e_floordiv(r->v[j], g) : e_quo(r->v[j], g);
+  }
+}
+
+/* ------------------------------------------------------------------- public */
+ora *ora_new(void) { return calloc(1, sizeof(ora)); }
+void ora_free(ora *o) {
+  if (!o) return;
+  a_reset(o, 0);
+  free(o->blk);
+  free(o->cell);
+  free(o);
+}
+void ora_set_deepest_cut(ora *o, int on) { o->deepest = on; }
+long long ora_pivots(const ora *o) { return o->pivots; }
+long long ora_cuts(const ora *o) { return o->cuts; }
+int ora_ncells(const ora *o) { return o->ncell; }
+const ora_cell *ora_cells(const ora *o) { return o->cell; }
+
+/* maind.c:196-231 / piplib.c:813-871: context emptiness test, then traiter */
+static int run_front(ora *o, otab *ineq, otab *context, int nvar, int nparm, int ni, int nc, int bigparm,
+                     int tflags) {
+  int non_vide = 1;
+  if (nc) {
+    otab *c2 = tab_grow(o, context, nparm, nc, nparm + 1, nparm, 0, 0);
+    int p = o->ncell;
+    solve_node(o, c2, NULL, nparm, 0, nc, 0, -1, OT_INT);
+    non_vide = o->cell[p].kind != OS_NIL;
+    o->ncell = p;
+  }
+  if (!non_vide) return ORA_VOID;
+  solve_node(o, ineq, context, nvar, nparm, ni, nc, bigparm, tflags);
+  return ORA_OK;
+}
+
+int ora_solve_tableau(ora *o, int nvar, int nparm, int ni, int nc, int bigparm, int nq, const int64_t *ineq,
+                      const int64_t *ctx, int simplify_inputs) {
+  int ncol = nvar + nparm + 1, i, j, rc;
+  otab *ti, *tc;
+  a_reset(o, 0);
+  o->ncell = 0;
+  o->pivots = o->cuts = 0;
+  if (setjmp(o->trap)) {
+    a_reset(o, 0);
+    return o->trapcode;
+  }
+  /* tab.c:222-248 tab_get */
+  ti = tab_new(o, ni, ncol, nvar);
+  for (i = 0; i < ni; i++) {
+    ti->row[nvar + i].flag = OF_UNKNOWN;
+    ti->row[nvar + i].den = 1;
+    for (j = 0; j < ncol; j++) ti->row[nvar + i].v[j] = ineq[(size_t)i * ncol + j];
+  }
+  tc = tab_new(o, nc, nparm + 1, 0);
+  for (i = 0; i < nc; i++) {
+    tc->row[i].flag = OF_UNKNOWN;
+    tc->row[i].den = 1;
+    for (j = 0; j <= nparm; j++) tc->row[i].v[j] = ctx[(size_t)i * (nparm + 1) + j];
+  }
+  if (nq && simplify_inputs) {
+    simplify_rows(ti, nvar);
+    simplify_rows(tc, nparm);
+  }
+  rc = run_front(o, ti, tc, nvar, nparm, ni, nc, bigparm, nq ? OT_INT : 0);
+  a_reset(o, 0);
+  return rc;
+}
+
+/* --------------------------------------------------------------- tape tools
+ * sol.c:236-268 skip / skip_New */
+static int tape_skip(const ora *o, int i);
+static int tape_skip_new(const ora *o, int i) {
+  if (o->cell[i].kind != OS_NEW) return i;
+  return tape_skip(o, i + 1);
+}
+static int tape_skip(const ora *o, int i) {
+  int n;
+  while (o->cell[i].kind == OS_FREE || o->cell[i].kind == OS_ERROR) i++;
+  switch (o->cell[i].kind) {
+    case OS_NIL:
+    case OS_VAL: i++; break;
+    case OS_NEW: i = tape_skip_new(o, i); break;
+    case OS_IF:
+      i = tape_skip(o, i + 1);
+      i = tape_skip(o, i);
+      i = tape_skip(o, i);
+      break;
+    case OS_LIST:
+    case OS_FORM:
+      n = e_get_si(o->cell[i].a);
+      i++;
+      while (n--) i = tape_skip(o, i);
+      break;
+    case OS_DIV:
+      i = tape_skip(o, i + 1);
+      i = tape_skip(o, i);
+      break;
+    default: break;
+  }
+  return tape_skip_new(o, i);
+}
+/* sol.c:272-288 sol_simplify */
+static void tape_simplify(ora *o, int i) {
+  int j, k, l;
+  if (o->cell[i].kind != OS_IF) return;
+  j = tape_skip(o, i + 1);
+  k = tape_skip(o, j);
+  tape_simplify(o, k);
+  tape_simplify(o, j);
+  if (o->cell[j].kind == OS_NIL && o->cell[k].kind == OS_NIL) {
+    o->cell[i].kind = OS_NIL;
+    if (k >= o->ncell - 1)
+      o->ncell = i + 1;
+    else
+      for (l = i + 1; l <= k; l++) o->cell[l].kind = OS_FREE;
+  }
+}
+void ora_simplify(ora *o) {
+  if (o->ncell) tape_simplify(o, 0);
+}
+
+static void print_frac(FILE *f, ent N, ent D) {
+  ent d = e_gcd(N, D);
+  fputc(' ', f);
+  if (d == D) {
+    e_print(f, e_quo(N, d));
+  } else {
+    e_print(f, e_quo(N, d));
+    fputc('/', f);
+    e_print(f, e_quo(D, d));
+  }
+}
+/* sol.c:291-422 sol_edit */
+static int tape_print(const ora *o, FILE *f, int i) {
+  int j, n;
+  for (;;) {
+    if (o->cell[i].kind == OS_FREE) {
+      i++;
+      continue;
+    }
+    if (o->cell[i].kind == OS_NEW) {
+      fprintf(f, "(newparm %d ", e_get_si(o->cell[i].a));
+      i = tape_print(o, f, i + 1);
+      fprintf(f, ")\n");
+      continue;
+    }
+    break;
+  }
+  switch (o->cell[i].kind) {
+    case OS_NIL:
+      fprintf(f, "()\n");
+      i++;
+      break;
+    case OS_ERROR:
+      fprintf(f, "Error %d\n", e_get_si(o->cell[i].a));
+      i++;
+      break;
+    case OS_IF:
+      fprintf(f, "(if ");
+      i = tape_print(o, f, i + 1);
+      i = tape_print(o, f, i);
+      i = tape_print(o, f, i);
+      fprintf(f, ")\n");
+      break;
+    case OS_LIST:
+      fprintf(f, "(list ");
+      n = e_get_si(o->cell[i].a);
+      i++;
+      while (n--) i = tape_print(o, f, i);
+      fprintf(f, ")\n");
+      break;
+    case OS_FORM:
+      fprintf(f, "#[");
+      n = e_get_si(o->cell[i].a);
+      for (j = 0; j < n; j++) {
+        i++;
+        print_frac(f, o->cell[i].a, o->cell[i].b);
+      }
+      fprintf(f, "]\n");
+      i++;
+      break;
+    case OS_DIV:
+      fprintf(f, "(div ");
+      i = tape_print(o, f, i + 1);
+      i = tape_print(o, f, i);
+      fprintf(f, ")\n");
+      break;
+    case OS_VAL:
+      print_frac(f, o->cell[i].a, o->cell[i].b);
+      i++;
+      break;
+    default: fprintf(f, "Inconnu : sol\n");
+  }
+  return i;
+}
+void ora_print(const ora *o, FILE *out) {
+  int i = 0;
+  while (i < o->ncell) i = tape_print(o, out, i);
+}
+
+/* ------------------------------------------------------------ .dat front end
+ * maind.c:75-251 + tab.c:222-248 + piplib.c:76-163, as a character stream. */
+typedef struct {
+  FILE *f;
+} rdr;
+static int rd_int(rdr *r, long long *v) {
+  int c, neg = 0, any = 0;
+  unsigned long long u = 0;
+  do c = fgetc(r->f);
+  while (c == ' ' || c == '\n' || c == '\t' || c == '\r');
+  if (c == '-' || c == '+') {
+    neg = (c == '-');
+    c = fgetc(r->f);
+  }
+  while (c != EOF && isdigit(c)) {
+    u = u * 10 + (unsigned)(c - '0');
+    any = 1;
+    c = fgetc(r->f);
+  }
+  if (c != EOF) ungetc(c, r->f);
+  if (!any) return -1;
+  *v = neg ? (long long)(0 - u) : (long long)u;
+  return 0;
+}
+static int rd_until(rdr *r, int ch) {
+  int c;
+  while ((c = fgetc(r->f)) != EOF)
+    if (c == ch) return 0;
+  return -1;
+}
+static int64_t *rd_tableau(rdr *r, int h, int w) {
+  int64_t *m = calloc((size_t)h * w + 1, sizeof *m);
+  int i, j;
+  rd_until(r, '(');
+  for (i = 0; i < h; i++) {
+    rd_until(r, '[');
+    for (j = 0; j < w; j++) {
+      long long x;
+      if (rd_int(r, &x) < 0) {
+        free(m);
+        return NULL;
+      }
+      m[(size_t)i * w + j] = x;
+    }
+  }
+  rd_until(r, ']');
+  return m;
+}
+static void rd_escape(rdr *r, FILE *out, int level) {
+  int c;
+  while ((c = fgetc(r->f)) != EOF) {
+    if (c == '(')
+      level++;
+    else if (c == ')' && --level == 0) {
+      fprintf(out, "\nSyntax error\n)\n");
+      return;
+    }
+  }
+}
+
+int ora_run_dat(FILE *in, FILE *out, int simplify, int deepest) {
+  rdr r = {in};
+  ora *o = ora_new();
+  int c;
+  o->deepest = deepest;
+  while ((c = fgetc(in)) != EOF) {
+    long long hdr[6];
+    int k, level = 0, rc, bad = 0;
+    int64_t *ineq, *ctx;
+    if (c != '(') continue;
+    fputc('(', out);
+    while ((c = fgetc(in)) != EOF) {
+      if (c == '(')
+        level++;
+      else if (c == ')' && --level == 0)
+        break;
+      fputc(c, out);
+    }
+    for (k = 0; k < 6 && !bad; k++)
+      if (rd_int(&r, &hdr[k]) < 0) bad = 1;
+    if (bad) {
+      rd_escape(&r, out, 1);
+      continue;
+    }
+    ineq = rd_tableau(&r, (int)hdr[2], (int)(hdr[0] + hdr[1] + 1));
+    if (!ineq) {
+      rd_escape(&r, out, 2);
+      continue;
+    }
+    ctx = rd_tableau(&r, (int)hdr[3], (int)hdr[1] + 1);
+    if (!ctx) {
+      free(ineq);
+      rd_escape(&r, out, 2);
+      continue;
+    }
+    rc = ora_solve_tableau(o, (int)hdr[0], (int)hdr[1], (int)hdr[2], (int)hdr[3], (int)hdr[4], (int)hdr[5], ineq,
+                           ctx, 1);
+    free(ineq);
+    free(ctx);
+    if (rc == ORA_OK) {
+      fputs(")\n", out);
+      if (simplify) ora_simplify(o);
+      ora_print(o, out);
+    } else if (rc == ORA_VOID) {
+      fprintf(out, "void\n");
+    } else {
+      if (rc == ORA_ERR_OVERFLOW) fprintf(stderr, "Integer overflow\n");
+      fflush(out);
+      ora_free(o);
+      return rc;
+    }
+    fprintf(out, ")\n");
+    fflush(out);
+  }
+  ora_free(o);
+  return 0;
+}
+
+/* ------------------------------------------------------------ batch front end */
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+int ora_run_batch(const char *in_path, const char *out_path) {
+  FILE *in = fopen(in_path, "rb"), *out = fopen(out_path, "wb");
+  struct batch_hdr bh;
+  struct batch_out_hdr oh;
+  ora *o = ora_new();
+  double t_solve = 0;
+  long long total = 0;
+  unsigned k;
+  if (!in || !out) return 2;
+  if (fread(&bh, sizeof bh, 1, in) != 1 || bh.magic != BATCH_MAGIC) return 3;
+  memset(&oh, 0, sizeof oh);
+  oh.magic = BATCH_MAGIC;
+  oh.count = bh.count;
+  fwrite(&oh, sizeof oh, 1, out);
+  o->deepest = (bh.flags & BATCH_F_DEEPEST) ? 1 : 0;
+  for (k = 0; k < bh.count; k++) {
+    struct batch_prob ph;
+    struct batch_res rh;
+    int64_t *buf;
+    size_t n1, n2;
+    char *txt = NULL;
+    size_t txtlen = 0;
+    double t0;
+    int rc;
+    if (fread(&ph, sizeof ph, 1, in) != 1) return 4;
+    n1 = (size_t)ph.ni * (ph.nvar + ph.nparm + 1);
+    n2 = (size_t)ph.nc * (ph.nparm + 1);
+    buf = malloc(sizeof(int64_t) * (n1 + n2 + 1));
+    if (fread(buf, sizeof(int64_t), n1 + n2, in) != n1 + n2) return 5;
+    memset(&rh, 0, sizeof rh);
+    t0 = now_s();
+    rc = ora_solve_tableau(o, ph.nvar, ph.nparm, ph.ni, ph.nc, ph.bigparm, ph.nq, buf, buf + n1,
+                           !(bh.flags & BATCH_F_NOSIMPLIFY));
+    t_solve += now_s() - t0;
+    if (rc == ORA_OK) {
+      rh.status = BATCH_ST_OK;
+      if (!(bh.flags & BATCH_F_NOTEXT)) {
+        FILE *ms = open_memstream(&txt, &txtlen);
+        ora_print(o, ms);
+        fclose(ms);
+      }
+    } else if (rc == ORA_VOID) {
+      rh.status = BATCH_ST_VOID;
+    } else {
+      rh.status = BATCH_ST_ABORT;
+      rh.abort_code = rc;
+    }
+    rh.pivots = o->pivots;
+    total += o->pivots;
+    rh.text_len = (unsigned)txtlen;
+    fwrite(&rh, sizeof rh, 1, out);
+    if (txtlen) fwrite(txt, 1, txtlen, out);
+    free(txt);
+    free(buf);
+  }
+  oh.solve_seconds = t_solve;
+  oh.total_pivots = total;
+  fseek(out, 0, SEEK_SET);
+  fwrite(&oh, sizeof oh, 1, out);
+  fclose(out);
+  fclose(in);
+  ora_free(o);
+  return 0;
+}
+
+/* =================================================================== pip_solve
+ * The PolyLib-matrix front end: piplib.c:722-880 (pip_solve), tab.c:292-393
+ * (tab_Matrix2Tableau), sol.c:435-734 (tape -> PipQuast), piplib.c:176-317
+ * (printing), as driven by example/example.c. */
+typedef struct {
+  unsigned nr, nc;
+  ent *v; /* nr x nc */
+} omat;
+typedef struct ovec {
+  int n;
+  ent *num, *den;
+} ovec;
+typedef struct onewparm {
+  int rank;
+  ovec *vec;
+  ent deno;
+  struct onewparm *next;
+} onewparm;
+typedef struct olist {
+  ovec *vec;
+  struct olist *next;
+} olist;
+typedef struct oquast {
+  onewparm *newparm;
+  olist *list;
+  ovec *cond;
+  struct oquast *then_, *else_;
+} oquast;
+typedef struct {
+  int Nq, Simplify, Deepest_cut, Maximize, Urs_parms, Urs_unknowns, Compute_dual;
+} oopts;
+enum { SOL_SHIFT = 1, SOL_NEGATE = 2, SOL_REMOVE = 4, SOL_MAX = 3, SOL_DUAL = 8 }; /* sol.h:36-50 */
+
+#define M(m, i, j) ((m)->v[(size_t)(i) * (m)->nc + (j)])
+
+/* tab.c:292-393 */
+static otab *matrix_to_tab(ora *o, const omat *m, int Nineq, int Nv, int n, int Shift, int Bg, int Urs) {
+  int ctx = (n == -1), bignum_is_new, cst;
+  unsigned nb_columns, i, decal = 0;
+  otab *p;
+  if (ctx) n = 0;
+  nb_columns = m->nc - 1;
+  bignum_is_new = Shift && (Bg + ctx > 0) && ((unsigned)(Bg + ctx) > (m->nc - 2));
+  if (bignum_is_new) nb_columns++;
+  if (ctx) {
+    Shift = 0;
+    cst = Nv + Urs;
+  } else
+    cst = Nv;
+  p = tab_new(o, Nineq, (int)nb_columns + Urs, n);
+  for (i = 0; i < m->nr; i++) {
+    unsigned cur = i + (unsigned)n + decal;
+    orow *r = &p->row[cur];
+    ent big = 0;
+    int j, k, inequality = (M(m, i, 0) != 0);
+    r->flag = OF_UNKNOWN;
+    r->den = 1;
+    for (j = 0; j < Nv; j++) {
+      if (bignum_is_new && j == Bg) continue;
+      if (Shift) big = e_add(big, M(m, i, 1 + j));
+      r->v[j] = Shift > 0 ? e_neg(M(m, i, 1 + j)) : M(m, i, 1 + j);
+    }
+    for (k = j = Nv + 1; (unsigned)j < nb_columns; j++) {
+      if (bignum_is_new && j == Bg) continue;
+      r->v[j] = M(m, i, k);
+      k++;
+    }
+    for (j = 0; j < Urs; ++j) {
+      int pos_n = (int)nb_columns - ctx + j, pos = pos_n - Urs;
+      if (pos <= Bg) --pos;
+      r->v[pos_n] = e_neg(r->v[pos]);
+    }
+    r->v[cst] = M(m, i, m->nc - 1);
+    if (Shift) {
+      if (Shift < 0) big = e_neg(big);
+      if (bignum_is_new)
+        r->v[Bg] = big;
+      else
+        r->v[Bg] = e_add(r->v[Bg], big);
+    }
+    if (!inequality) {
+      orow *r2 = &p->row[cur + 1];
+      decal++;
+      r2->flag = OF_UNKNOWN;
+      r2->den = 1;
+      for (j = 0; (unsigned)j < nb_columns + (unsigned)Urs; j++) r2->v[j] = e_neg(r->v[j]);
+    }
+  }
+  return p;
+}
+
+/* sol.c:435-512 sol_vector_edit */
+static ovec *q_vector(const ora *o, int *i, int Bg, int Urs_p, int flags) {
+  const ora_cell *p = &o->cell[*i];
+  int n = e_get_si(p->a), j, k, unbounded = 0, first_urs;
+  ovec *v = calloc(1, sizeof *v);
+  if (flags & SOL_REMOVE) --n;
+  n -= Urs_p;
+  first_urs = Urs_p + (Bg >= 0);
+  v->n = n;
+  v->num = calloc((size_t)(n > 0 ? n : 1), sizeof(ent));
+  v->den = calloc((size_t)(n > 0 ? n : 1), sizeof(ent));
+  for (j = 0, k = 0; k < n; j++) {
+    ent N, D, d;
+    (*i)++;
+    p++;
+    N = p->a;
+    D = p->b;
+    d = e_gcd(N, D);
+    if ((flags & SOL_SHIFT) && j == Bg) {
+      N = e_sub(N, D);
+      if (N != 0) unbounded = 1;
+    }
+    if ((flags & SOL_REMOVE) && j == Bg) continue;
+    if (first_urs <= j && j < first_urs + Urs_p) continue;
+    v->num[k] = e_quo(N, d);
+    if (flags & SOL_NEGATE) v->num[k] = e_neg(v->num[k]);
+    v->den[k] = (d == D) ? 1 : e_quo(D, d);
+    ++k;
+  }
+  if (unbounded)
+    for (k = 0; k < n; k++) v->den[k] = 0;
+  (*i)++;
+  return v;
+}
+/* sol.c:525-577 sol_newparm_edit */
+static onewparm *q_newparm(const ora *o, int *i, int Bg, int Urs_p, int flags) {
+  const ora_cell *p = &o->cell[*i];
+  onewparm *first = NULL, *last = NULL;
+  do {
+    onewparm *np = calloc(1, sizeof *np);
+    (*i) += 2;
+    np->vec = q_vector(o, i, Bg, Urs_p, flags);
+    np->rank = e_get_si(p->a);
+    p = &o->cell[*i];
+    np->deno = p->a;
+    if (flags & SOL_REMOVE) np->rank--;
+    np->rank -= Urs_p;
+    if (last)
+      last->next = np;
+    else
+      first = np;
+    last = np;
+    (*i)++;
+    p = &o->cell[*i];
+  } while (p->kind == OS_NEW);
+  return first;
+}
+/* sol.c:591-638 sol_list_edit */
+static olist *q_list(const ora *o, int *i, int n, int Bg, int Urs_p, int flags) {
+  olist *head = calloc(1, sizeof *head), *cur = head;
+  if (n == 0) return head;
+  head->vec = q_vector(o, i, Bg, Urs_p, flags);
+  while (--n) {
+    olist *nx = calloc(1, sizeof *nx);
+    nx->vec = q_vector(o, i, Bg, Urs_p, flags);
+    cur->next = nx;
+    cur = nx;
+  }
+  return head;
+}
+/* sol.c:664-734 sol_quast_edit */
+static oquast *q_quast(const ora *o, int *i, int Bg, int Urs_p, int flags) {
+  oquast *q = calloc(1, sizeof *q);
+  const ora_cell *p;
+  while (o->cell[*i].kind == OS_FREE) (*i)++;
+  p = &o->cell[*i];
+  if (p->kind == OS_NEW) {
+    q->newparm = q_newparm(o, i, Bg, Urs_p, flags & SOL_REMOVE);
+    p = &o->cell[*i];
+  }
+  (*i)++;
+  switch (p->kind) {
+    case OS_LIST:
+      q->list = q_list(o, i, e_get_si(p->a), Bg, Urs_p, flags);
+      if (flags & SOL_DUAL) q->then_ = q_quast(o, i, Bg, Urs_p, 0);
+      break;
+    case OS_NIL: break;
+    case OS_IF:
+      q->cond = q_vector(o, i, Bg, Urs_p, flags & SOL_REMOVE);
+      q->then_ = q_quast(o, i, Bg, Urs_p, flags);
+      q->else_ = q_quast(o, i, Bg, Urs_p, flags);
+      break;
+    default: break;
+  }
+  return q;
+}
+/* piplib.c:651-690 pip_quast_equalities_dual */
+static void q_equalities_dual(oquast *s, const omat *inequnk) {
+  olist **lp, *l;
+  unsigned i;
+  if (!s) return;
+  if (s->cond) {
+    q_equalities_dual(s->then_, inequnk);
+    q_equalities_dual(s->else_, inequnk);
+  }
+  if (!s->list || !s->then_ || !s->then_->list) return;
+  lp = &s->then_->list;
+  for (i = 0; i < inequnk->nr; ++i) {
+    if (M(inequnk, i, 0) == 0) {
+      if ((*lp)->vec->num[0] != 0) {
+        lp = &(*lp)->next;
+        l = *lp;
+        *lp = l->next;
+      } else {
+        l = *lp;
+        *lp = l->next;
+        (*lp)->vec->num[0] = e_neg((*lp)->vec->num[0]);
+        lp = &(*lp)->next;
+      }
+    } else
+      lp = &(*lp)->next;
+  }
+}
+
+/* piplib.c:198-317 printing */
+static void pr_vector(FILE *f, const ovec *v) {
+  int i;
+  if (!v) return;
+  fprintf(f, "#[");
+  for (i = 0; i < v->n; i++) {
+    fprintf(f, " ");
+    e_print(f, v->num[i]);
+    if (v->den[i] != 1) {
+      fprintf(f, "/");
+      e_print(f, v->den[i]);
+    }
+  }
+  fprintf(f, "]");
+}
+static void pr_indent(FILE *f, int n) {
+  int i;
+  for (i = 0; i < n; i++) fprintf(f, " ");
+}
+static void pr_quast(FILE *f, const oquast *q, int indent) {
+  int ni = indent >= 0 ? indent + 1 : indent;
+  const onewparm *np;
+  const olist *l;
+  if (!q) {
+    pr_indent(f, indent);
+    fprintf(f, "void\n");
+    return;
+  }
+  for (np = q->newparm; np; np = np->next) {
+    pr_indent(f, indent);
+    fprintf(f, "(newparm %d (div ", np->rank);
+    pr_vector(f, np->vec);
+    fprintf(f, " ");
+    e_print(f, np->deno);
+    fprintf(f, "))\n");
+  }
+  if (!q->cond) {
+    if (!q->list) {
+      pr_indent(f, indent);
+      fprintf(f, "()\n");
+    } else {
+      pr_indent(f, indent);
+      fprintf(f, "(list\n");
+      for (l = q->list; l; l = l->next)
+        if (l->vec) {
+          pr_indent(f, indent + 1);
+          pr_vector(f, l->vec);
+          fprintf(f, "\n");
+        }
+      pr_indent(f, indent);
+      fprintf(f, ")\n");
+    }
+    if (q->then_) pr_quast(f, q->then_, ni);
+  } else {
+    pr_indent(f, indent);
+    fprintf(f, "(if ");
+    pr_vector(f, q->cond);
+    fprintf(f, "\n");
+    pr_quast(f, q->then_, ni);
+    pr_quast(f, q->else_, ni);
+    pr_indent(f, indent);
+    fprintf(f, ")\n");
+  }
+}
+
+/* piplib.c:722-880 pip_solve.  Returns NULL for "void". */
+static oquast *pip_solve_o(ora *o, const omat *inequnk, const omat *ineqpar, int Bg, const oopts *opt, int *err) {
+  otab *ineq, *context;
+  unsigned i, Nl;
+  int Np, Nn, Nm, Shift = 0, Urs_parms = 0, sol_flags = 0, non_vide = 1, tflags = 0, xq = 0;
+  omat empty = {0, 2, NULL};
+  oquast *sol;
+  *err = 0;
+  if (!inequnk) return NULL;
+  a_reset(o, 0);
+  o->ncell = 0;
+  o->pivots = o->cuts = 0;
+  o->deepest = opt->Deepest_cut;
+  if (setjmp(o->trap)) {
+    a_reset(o, 0);
+    *err = o->trapcode;
+    return NULL;
+  }
+  Np = ineqpar ? (int)ineqpar->nc - 2 : 0;
+  Nn = (int)inequnk->nc - Np - 2;
+  Nl = inequnk->nr;
+  for (i = 0; i < inequnk->nr; i++)
+    if (M(inequnk, i, 0) == 0) ++Nl;
+  if (opt->Maximize) {
+    sol_flags |= SOL_MAX;
+    Shift = 1;
+  } else if (opt->Urs_unknowns) {
+    sol_flags |= SOL_SHIFT;
+    Shift = -1;
+  }
+  if (opt->Urs_parms) {
+    Urs_parms = Np - (Bg >= 0);
+    Np += Urs_parms;
+  }
+  if (opt->Maximize || opt->Urs_unknowns) {
+    if (Bg < 0) {
+      Bg = (int)inequnk->nc - 1;
+      Np++;
+      sol_flags |= SOL_REMOVE;
+    }
+  }
+  if (ineqpar) {
+    Nm = (int)ineqpar->nr;
+    for (i = 0; i < ineqpar->nr; i++)
+      if (M(ineqpar, i, 0) == 0) Nm++;
+    context = matrix_to_tab(o, ineqpar, Nm, Np - Urs_parms, -1, Shift, Bg - Nn - 1, Urs_parms);
+    if (opt->Nq) simplify_rows(context, Np);
+    if (Nm) {
+      otab *c2 = tab_grow(o, context, Np, Nm, Np + 1, Np, 0, 0);
+      solve_node(o, c2, NULL, Np, 0, Nm, 0, -1, OT_INT);
+      non_vide = o->cell[0].kind != OS_NIL;
+      o->ncell = 0;
+    }
+  } else {
+    Nm = 0;
+    context = matrix_to_tab(o, &empty, Nm, Np - Urs_parms, -1, Shift, Bg - Nn - 1, Urs_parms);
+  }
+  if (!non_vide) {
+    a_reset(o, 0);
+    return NULL;
+  }
+  ineq = matrix_to_tab(o, inequnk, (int)Nl, Nn, Nn, Shift, Bg, Urs_parms);
+  if (opt->Nq) simplify_rows(ineq, Nn);
+  if (opt->Nq)
+    tflags |= OT_INT;
+  else if (opt->Compute_dual) {
+    tflags |= OT_DUAL;
+    sol_flags |= SOL_DUAL;
+  }
+  solve_node(o, ineq, context, Nn, Np, (int)Nl, Nm, Bg, tflags);
+  if (opt->Simplify) tape_simplify(o, 0);
+  sol = q_quast(o, &xq, Bg - Nn - 1, Urs_parms, sol_flags);
+  if ((sol_flags & SOL_DUAL) && Nl > inequnk->nr) q_equalities_dual(sol, inequnk);
+  a_reset(o, 0);
+  return sol;
+}
+
+/* piplib.c:576-619 pip_matrix_read, piplib.c:176-190 pip_matrix_print */
+static omat *mat_read(FILE *f) {
+  char s[1024], *c;
+  unsigned nr, nc, i, j;
+  omat *m;
+  do {
+    if (!fgets(s, sizeof s, f)) return NULL;
+  } while (*s == '#' || *s == '\n' || sscanf(s, " %u %u", &nr, &nc) < 2);
+  m = calloc(1, sizeof *m);
+  m->nr = nr;
+  m->nc = nc;
+  m->v = calloc((size_t)nr * nc + 1, sizeof(ent));
+  for (i = 0; i < nr; i++) {
+    do {
+      c = fgets(s, sizeof s, f);
+      while (c && isspace((unsigned char)*c) && *c != '\n') c++;
+    } while (c && (*c == '#' || *c == '\n'));
+    if (!c) return NULL;
+    for (j = 0; j < nc; j++) {
+      char tok[1024];
+      int n = 0;
+      long long x = 0;
+      if (sscanf(c, "%s%n", tok, &n) < 1) return NULL;
+      sscanf(tok, "%lld", &x);
+      M(m, i, j) = x;
+      c += n;
+    }
+  }
+  return m;
+}
+static void mat_print(FILE *f, const omat *m) {
+  unsigned i, j;
+  fprintf(f, "%d %d\n", m->nr, m->nc);
+  for (i = 0; i < m->nr; i++) {
+    for (j = 0; j < m->nc; j++) {
+      fprintf(f, " ");
+      e_print(f, M(m, i, j));
+    }
+    fprintf(f, "\n");
+  }
+}
+
+/* example/example.c:53-121 */
+int ora_run_pip(FILE *in, FILE *out) {
+  omat *context, *domain;
+  oopts opt = {1, 0, 0, 0, 0, 0, 0};
+  char s[1024];
+  int bignum, err = 0;
+  ora *o = ora_new();
+  oquast *sol;
+  fprintf(out, "[PIP2-like future input] Please enter:\n- the context matrix,\n");
+  context = mat_read(in);
+  if (!context) return 1;
+  mat_print(out, context);
+  fprintf(out, "- the bignum column (start at 0, -1 if no bignum),\n");
+  if (fscanf(in, " %d", &bignum) != 1) return 1;
+  fprintf(out, "%d\n", bignum);
+  fprintf(out, "- the constraint matrix.\n");
+  domain = mat_read(in);
+  if (!domain) return 1;
+  mat_print(out, domain);
+  fprintf(out, "\n");
+  while (fgets(s, sizeof s, in)) {
+    if (!strncasecmp(s, "Maximize", 8)) opt.Maximize = 1;
+    if (!strncasecmp(s, "Urs_parms", 9)) opt.Urs_parms = 1;
+    if (!strncasecmp(s, "Urs_unknowns", 12)) opt.Urs_unknowns = 1;
+    if (!strncasecmp(s, "Rational", 8)) opt.Nq = 0;
+    if (!strncasecmp(s, "Dual", 4)) opt.Compute_dual = 1;
+  }
+  if (bignum > 0) bignum += (int)domain->nc - (int)context->nc;
+  sol = pip_solve_o(o, domain, context, bignum, &opt, &err);
+  if (err) {
+    if (err == ORA_ERR_OVERFLOW) fprintf(stderr, "Integer overflow\n");
+    return err;
+  }
+  pr_quast(out, sol, 0);
+  ora_free(o);
+  return 0;
+}

@@ -1,0 +1,64 @@
+"""Synthetic PIP tableaux (deterministic, numpy only).
+
+Column order is PIP's own (reference tab.c:222-248 / maind.c:190):
+    unknowns (nvar) | constant | parameters (nparm)
+A row ``r`` means  sum_j r[j]*x_j + r[nvar] + sum_k r[nvar+1+k]*p_k >= 0.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class Problem:
+    nvar: int
+    nparm: int
+    ni: int
+    nc: int
+    bigparm: int
+    nq: int
+    ineq: np.ndarray  # (ni, nvar+nparm+1) int64
+    ctx: np.ndarray   # (nc, nparm+1) int64
+
+
+def lexmin_rows(rng, nvar, ni, nnz=4, cmax=5, x0max=9, slackmax=3, pneg=0.25):
+    """One sparse 'polyhedral-like' system A x >= b around a hidden integer point x0.
+
+    Each constraint has 2..nnz non-zeros of magnitude <= cmax; b = A x0 - slack keeps x0
+    feasible, so lexmin exists; non-unimodular coefficients make the rational optimum
+    fractional, which is what exercises the Gomory-cut generator.
+    """
+    A = np.zeros((ni, nvar), dtype=np.int64)
+    for i in range(ni):
+        k = int(rng.integers(2, nnz + 1))
+        cols = rng.choice(nvar, size=min(k, nvar), replace=False)
+        vals = rng.integers(1, cmax + 1, size=len(cols))
+        vals = np.where(rng.random(len(cols)) < pneg, -vals, vals)
+        A[i, cols] = vals
+    x0 = rng.integers(0, x0max + 1, size=nvar)
+    slack = rng.integers(0, slackmax + 1, size=ni)
+    b = A @ x0 - slack
+    return np.concatenate([A, -b[:, None]], axis=1)
+
+
+def lexmin_batch(seed, batch, nvar, ni, **kw):
+    """(batch, ni, nvar+1) int64: non-parametric integer lexmin problems (nparm = 0)."""
+    rng = np.random.default_rng(seed)
+    return np.stack([lexmin_rows(rng, nvar, ni, **kw) for _ in range(batch)])
+
+
+def random_problems(seed, count, nvar, nparm, ni, nc, nq, cmax=4, bmax=12):
+    """Small dense-ish random problems, parametric when nparm > 0 (many are infeasible
+    or split several times: good coverage of Nil / if / newparm paths)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    ncol = nvar + nparm + 1
+    for _ in range(count):
+        T = rng.integers(-cmax, cmax + 1, size=(ni, ncol)).astype(np.int64)
+        T[rng.random((ni, ncol)) < 0.45] = 0
+        T[:, nvar] = rng.integers(-bmax, bmax + 1, size=ni)
+        C = rng.integers(-cmax, cmax + 1, size=(nc, nparm + 1)).astype(np.int64)
+        if nc:
+            C[:, nparm] = rng.integers(0, bmax + 1, size=nc)
+        out.append(Problem(nvar, nparm, ni, nc, -1, nq, T, C))
+    return out

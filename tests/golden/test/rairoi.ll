@@ -1,0 +1,19 @@
+((test du papier RAIRO)
+(if #[ -1 2 1 0]
+(if #[ 1 -2 0 0]
+(list #[ 0 0 0 0]
+#[ -1 2 1 0]
+)
+(newparm 3 (div #[ 1 0 0 0]
+ 2)
+)
+(if #[ -1 0 1 2 0]
+(list #[ 0 1 0 -1 0]
+#[ -1 0 1 2 0]
+)
+()
+)
+)
+()
+)
+)

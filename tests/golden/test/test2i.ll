@@ -1,0 +1,5 @@
+((variables : a b c d ...., pas de parametres)
+(list #[ 2]
+#[ 1]
+)
+)

@@ -1,0 +1,6 @@
+((variables : a b c d ...., pas de parametres)
+(list #[ 2]
+#[ 1/2]
+#[ 4/3]
+)
+)
