@@ -1,0 +1,136 @@
+/* include/piplib_amd.h -- C ABI of the MI355X-native PipLib hot path.
+ *
+ * Plain C, plain pointers and sizes: this is what a PipLib maintainer binds to
+ *  in place of the CPU implementations of
+ *
+ *   traiter()/pivoter()/choisir_piv()/exam_coef()   reference source/traiter.c:101-159,297-548,628-791
+ *   integrer() (Gomory cut rows)                    reference source/integrer.c:305-534
+ *   tab_alloc()/tab_get()/expanser() row store      reference source/tab.c:158-248, traiter.c:55-88
+ *
+ * Three layers, lowest first:
+ *   1. pipamd_batch_*   : a *uniform* batch of tableaux that lives in HBM; one
+ *                         workgroup per tableau runs the whole pivot loop on the GPU.
+ *   2. pipamd_jobs_*    : heterogeneous "jobs" (any shapes) in one arena; the
+ *                         engine advances every job until it is finished or needs a
+ *                         host decision (context test / parametric cut).  This is
+ *                         what the host-side quast builder (layer 3) drives.
+ *   3. pipamd_solve_*   : PipLib's own front-end semantics (maind.c / pip_solve,
+ *                         piplib.c:722-880) with the decision tree on the host and
+ *                         every pivot on the GPU.
+ *
+ * All device pointers are ordinary HIP device pointers (e.g. torch
+ * `tensor.data_ptr()`); `stream` is a hipStream_t passed as void*.
+ * Every function returns 0 on success or a negative PIPAMD_E_* code; nothing
+ * here falls back to a CPU implementation.
+ */
+#ifndef PIPLIB_AMD_H
+#define PIPLIB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (return values) ---- */
+#define PIPAMD_OK 0
+#define PIPAMD_E_INVALID -1   /* bad argument / shape */
+#define PIPAMD_E_HIP -2       /* a HIP runtime call failed (no GPU, OOM, ...) */
+#define PIPAMD_E_TOOLARGE -3  /* shape exceeds the engine's compiled limits */
+#define PIPAMD_E_NOMEM -4
+#define PIPAMD_E_SOLVER -5    /* per-problem failure, see the status array */
+
+/* ---- traiter flags (reference funcall.h:32-33) ---- */
+#define PIPAMD_T_INT 1
+#define PIPAMD_T_DUAL 2
+/* engine-only flags */
+#define PIPAMD_T_SORT 256    /* rows not yet sorted (tab_sort_rows, traiter.c:556) */
+#define PIPAMD_T_DEEPEST 512 /* deepest-cut option (integrer.c:417-438) */
+
+/* ---- per-problem status written by the engine ---- */
+#define PIPAMD_ST_RUN 0          /* not finished (iteration limit reached: relaunch) */
+#define PIPAMD_ST_SOLUTION 1     /* all rows non-negative (and integral if T_INT): solution rows valid */
+#define PIPAMD_ST_NIL 2          /* no solution (traiter.c:782-785, integrer.c:482-485) */
+#define PIPAMD_ST_NEED_COMPA 3   /* parametric signs undecided: host runs compa_test (traiter.c:682) */
+#define PIPAMD_ST_NEED_PARMCUT 4 /* parametric Gomory cut on row `aux`: host runs find/add_parm */
+#define PIPAMD_ST_OVERFLOW 5     /* the reference's "Integer overflow" exit (traiter.c:424,442) */
+#define PIPAMD_ST_CAPACITY 6     /* spare rows/columns exhausted: reload with larger cap_* */
+#define PIPAMD_ST_RANGE 7        /* entries too large for the exact fast pivot-column choice */
+#define PIPAMD_ST_INTERNAL 8
+#define PIPAMD_ST_MAXCOL 9       /* "Too many variables" (integrer.c:324) */
+
+/* ---- row flags (reference tab.h:55-62) ---- */
+#define PIPAMD_F_UNIT 1
+#define PIPAMD_F_PLUS 2
+#define PIPAMD_F_MINUS 4
+#define PIPAMD_F_ZERO 8
+#define PIPAMD_F_CRITIC 16
+#define PIPAMD_F_UNKNOWN 32
+
+typedef struct pipamd_engine pipamd_engine;
+
+/* Engine = device + limits.  `device` is a HIP ordinal (after HIP_VISIBLE_DEVICES). */
+int pipamd_engine_create(pipamd_engine **out, int device);
+void pipamd_engine_destroy(pipamd_engine *e);
+const char *pipamd_last_error(void);
+/* Upper bound on pivots per problem per launch (a problem still PIPAMD_ST_RUN afterwards is
+ * simply resumed by the next pipamd_batch_solve); default 2^20. */
+int pipamd_engine_set_iter_limit(pipamd_engine *e, int pivots_per_launch);
+int pipamd_version(void);
+
+/* ------------------------------------------------------------------ layer 1 */
+typedef struct pipamd_batch_desc {
+  int32_t batch;       /* number of tableaux */
+  int32_t nvar;        /* unknowns */
+  int32_t nparm;       /* parameters (0 => whole solve stays on the GPU) */
+  int32_t ni;          /* inequality rows per tableau */
+  int32_t bigparm;     /* column index of the big parameter or -1 */
+  int32_t tflags;      /* PIPAMD_T_INT ... */
+  int32_t cap_cuts;    /* spare rows per tableau for Gomory cuts */
+  int32_t cap_newparm; /* spare columns per tableau (parametric cuts) */
+} pipamd_batch_desc;
+
+/* bytes of device workspace the batch needs (tableaux + row tables + job table + results) */
+size_t pipamd_batch_workspace_bytes(const pipamd_batch_desc *d);
+
+/* tab_get() for a whole batch: rows[b][i][0..ncol) (ncol = nvar+nparm+1, PIP column
+ * order unknowns|constant|parameters) become Unknown rows with denominator 1 under nvar
+ * unit rows.  `d_rows` is device memory, int64. */
+int pipamd_batch_load(pipamd_engine *e, void *d_workspace, const pipamd_batch_desc *d,
+                      const int64_t *d_rows, void *stream);
+
+/* traiter() on every tableau of the batch.  Asynchronous on `stream`. */
+int pipamd_batch_solve(pipamd_engine *e, void *d_workspace, const pipamd_batch_desc *d, void *stream);
+
+/* Copy out, device to device: status[b], pivots[b], cuts[b] (int32 each, may be NULL),
+ * sol_num[b][i][0..nparm] (parameter coefficients then constant, as solution() emits them,
+ * traiter.c:255-271) and sol_den[b][i], i < nvar (int64). */
+int pipamd_batch_results(pipamd_engine *e, const void *d_workspace, const pipamd_batch_desc *d,
+                         int32_t *d_status, int32_t *d_pivots, int32_t *d_cuts, int64_t *d_sol_num,
+                         int64_t *d_sol_den, void *stream);
+
+/* Algorithmic HBM bytes of ONE pivot of one tableau of this shape (read+write of every
+ * real row): the per-unit figure bench.py's roofline uses (DESIGN.md section "Roofline"). */
+size_t pipamd_pivot_bytes(const pipamd_batch_desc *d);
+
+/* Time of the last pipamd_batch_solve launch in milliseconds, measured with HIP events
+ * on the launch stream (blocks until the kernel finished). */
+int pipamd_last_solve_ms(pipamd_engine *e, float *ms);
+
+/* ------------------------------------------------------------------ layer 3 */
+/* One problem in PIP's native tableau form (what maind.c reads from a .dat file):
+ * host arrays, row-major int64.  `simplify` applies tab_simplify (tab.c:396) first when
+ * nq != 0, as both reference front ends do.  On success *text is a malloc'ed string in
+ * sol_edit format (sol.c:291) -- free with pipamd_free -- or the string "void\n" when the
+ * context is empty.  Returns PIPAMD_E_SOLVER and sets *status (PIPAMD_ST_*) when the
+ * reference would have aborted. */
+int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int nq,
+                         const int64_t *ineq, const int64_t *ctx, int simplify, int deepest_cut,
+                         char **text, int *status, int64_t *pivots);
+void pipamd_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIPLIB_AMD_H */

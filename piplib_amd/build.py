@@ -1,0 +1,39 @@
+"""Build the HIP extension in-tree: piplib_amd/libpipamd.so (gfx950 only).
+
+    python -m piplib_amd.build            # build if sources are newer
+    python -m piplib_amd.build --force
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libpipamd.so")
+SOURCES = ["pip_kernels.hip", "pip_host.cpp", "pip_tree.cpp"]
+HEADERS = ["pip_job.h", "pip_host.h", os.path.join("..", "..", "include", "piplib_amd.h")]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-DNDEBUG",
+           "-Wall", "-Wno-unused-function", "-x", "hip"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,29 @@
+// piplib_amd/csrc/pip_host.h -- internal host-side declarations.
+#ifndef PIP_HOST_H
+#define PIP_HOST_H
+#include <hip/hip_runtime.h>
+
+#include "pip_job.h"
+
+struct pipamd_engine {
+  int device;
+  hipEvent_t ev0, ev1;
+  int timed;
+  int iter_limit;
+  void *d_scratch;
+  size_t scratch_bytes;
+};
+
+void pipamd_set_error(const char *fmt, ...);
+int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t *jobs_bytes);
+
+extern "C" {
+hipError_t pipk_launch_advance(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
+                               hipStream_t stream);
+hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long long *rows, PipBatchLayout lay,
+                                  hipStream_t stream);
+hipError_t pipk_launch_batch_results(const PipJob *jobs, const long long *arena, int njobs, int nvar, int nparm,
+                                     int *status, int *pivots, int *cuts, long long *sol_num, long long *sol_den,
+                                     hipStream_t stream);
+}
+#endif

@@ -1,0 +1,38 @@
+// piplib_amd/csrc/pip_job.h -- structures shared by the HIP kernels and the host side.
+#ifndef PIP_JOB_H
+#define PIP_JOB_H
+#include <stdint.h>
+
+#include "../../include/piplib_amd.h"
+
+#define PIPAMD_MAXDET 4   /* reference tab.h:67 MAX_DETERMINANT */
+#define PIPAMD_MAXCOL 512 /* reference type.h:44 */
+#define PIPAMD_MAXPARM 50 /* reference type.h:45 */
+#define PIPAMD_LMAX 1024  /* logical rows the engine can stage in LDS */
+#define PIPAMD_SMAX 768   /* real rows (slots) per job */
+
+/* One problem ("job") in the device arena.  All offsets are in int64 units from the
+ * arena base and are even (rows are 16-byte aligned).
+ *   rows_off: den[L] (int64) | flag[L] (int32) | ref[L] (int32)      = 2*L int64
+ *   vals_off: S slots of W int64 (zero beyond the live columns)
+ *   sol_off : nvar*(nparm+1) numerators | nvar denominators
+ * Mirrors the reference's struct T / struct L (tab.h:36-85) without pointers. */
+typedef struct PipJob {
+  int64_t vals_off, rows_off, sol_off;
+  int32_t nvar, nparm, ni, bigparm;
+  int32_t tflags;
+  int32_t L, S, W;
+  int32_t status, aux, npiv, ncut;
+  int32_t ldet, pad0;
+  int64_t det[PIPAMD_MAXDET]; /* multi-limb determinant, tab.h:76-81 */
+  uint64_t maxabs;
+} PipJob;
+
+typedef struct PipBatchLayout {
+  int64_t arena_off; /* first job's block, int64 units */
+  int64_t per_job;   /* block size per job, int64 units */
+  int32_t batch, nvar, nparm, ni, bigparm, tflags;
+  int32_t L, S, W;
+} PipBatchLayout;
+
+#endif

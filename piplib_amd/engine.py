@@ -1,0 +1,124 @@
+"""ctypes binding of the C ABI (include/piplib_amd.h) for tests and bench.py.
+
+torch is used only for device memory and streams.  There is NO CPU fallback: if
+libpipamd.so is missing or no GPU is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpipamd.so")
+
+ST_RUN, ST_SOLUTION, ST_NIL, ST_NEED_COMPA, ST_NEED_PARMCUT, ST_OVERFLOW, ST_CAPACITY, ST_RANGE, ST_INTERNAL, ST_MAXCOL = range(10)
+T_INT, T_DUAL = 1, 2
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("batch", "nvar", "nparm", "ni", "bigparm", "tflags", "cap_cuts", "cap_newparm")]
+
+
+_lib = None
+
+
+def lib():
+    """Load libpipamd.so (built by piplib_amd.build); raises if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run `python -m piplib_amd.build` (HIP extension is mandatory)")
+        L = C.CDLL(LIB_PATH)
+        L.pipamd_last_error.restype = C.c_char_p
+        L.pipamd_batch_workspace_bytes.restype = C.c_size_t
+        L.pipamd_batch_workspace_bytes.argtypes = [C.POINTER(BatchDesc)]
+        L.pipamd_pivot_bytes.restype = C.c_size_t
+        L.pipamd_pivot_bytes.argtypes = [C.POINTER(BatchDesc)]
+        L.pipamd_engine_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.pipamd_engine_destroy.argtypes = [C.c_void_p]
+        L.pipamd_engine_set_iter_limit.argtypes = [C.c_void_p, C.c_int]
+        L.pipamd_batch_load.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p, C.c_void_p]
+        L.pipamd_batch_solve.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p]
+        L.pipamd_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc)] + [C.c_void_p] * 6
+        L.pipamd_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.pipamd_solve_tableau.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                                                        C.POINTER(C.c_int64)]
+        L.pipamd_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"piplib_amd error {rc}: {lib().pipamd_last_error().decode()}")
+
+
+class Engine:
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().pipamd_engine_create(C.byref(self._h), int(device)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib().pipamd_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def set_iter_limit(self, n):
+        _check(lib().pipamd_engine_set_iter_limit(self._h, int(n)))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """A uniform batch of tableaux resident in HBM (layer 1 of the C ABI)."""
+
+    def __init__(self, engine, rows, nvar, nparm, bigparm=-1, tflags=T_INT, cap_cuts=None, cap_newparm=0):
+        import torch
+        self.torch = torch
+        self.e = engine
+        B, ni, ncol = rows.shape
+        assert ncol == nvar + nparm + 1
+        if cap_cuts is None:
+            cap_cuts = min(3 * ni + 32, 768 - ni) if (tflags & T_INT) else 0
+        self.desc = BatchDesc(B, nvar, nparm, ni, bigparm, tflags, cap_cuts, cap_newparm)
+        self.dev = torch.device("cuda", engine.device)
+        self.rows = rows if (torch.is_tensor(rows) and rows.is_cuda) else torch.as_tensor(rows, dtype=torch.int64).to(self.dev)
+        self.rows = self.rows.contiguous()
+        nbytes = lib().pipamd_batch_workspace_bytes(C.byref(self.desc))
+        if nbytes == 0:
+            raise RuntimeError(lib().pipamd_last_error().decode())
+        self.ws = torch.empty(nbytes // 8 + 1, dtype=torch.int64, device=self.dev)
+        self.status = torch.empty(B, dtype=torch.int32, device=self.dev)
+        self.pivots = torch.empty(B, dtype=torch.int32, device=self.dev)
+        self.cuts = torch.empty(B, dtype=torch.int32, device=self.dev)
+        self.sol_num = torch.empty(B, nvar, nparm + 1, dtype=torch.int64, device=self.dev)
+        self.sol_den = torch.empty(B, nvar, dtype=torch.int64, device=self.dev)
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def load(self):
+        _check(lib().pipamd_batch_load(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc),
+                                       C.c_void_p(self.rows.data_ptr()), self._stream()))
+
+    def solve(self):
+        _check(lib().pipamd_batch_solve(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc), self._stream()))
+
+    def fetch(self):
+        _check(lib().pipamd_batch_results(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc),
+                                          C.c_void_p(self.status.data_ptr()), C.c_void_p(self.pivots.data_ptr()),
+                                          C.c_void_p(self.cuts.data_ptr()), C.c_void_p(self.sol_num.data_ptr()),
+                                          C.c_void_p(self.sol_den.data_ptr()), self._stream()))
+
+    def last_solve_ms(self):
+        ms = C.c_float()
+        _check(lib().pipamd_last_solve_ms(self.e._h, C.byref(ms)))
+        return float(ms.value)
+
+    def pivot_bytes(self):
+        return int(lib().pipamd_pivot_bytes(C.byref(self.desc)))
