@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- pivots/s of the HIP PIP engine on BASELINE.json's headline workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): per GPU a batch of
+10,000 synthetic 64x128 int64 tableaux (nvar = 127 unknowns, 64 inequality rows, constant
+column; no parameters), integer solve with Gomory cuts, one workgroup per tableau.
+A "step" = tab_get-style load of the batch into the HBM row store + the whole traiter()
+pivot loop for every tableau (inputs are resident in HBM before the timed region).
+Multi-GPU: independent problems, so each rank owns its own batch (weak scaling, no
+data-path collective); RCCL is used only to gather the totals.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+NVAR, NI, NPARM = 127, 64, 0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(rows, max_procs):
+    """Reference CPU path (oracle/_ref, the real piplib int64 build) on a bounded sample of
+    the same workload, one process per host core; falls back to the CPU restatement
+    ("port") if the reference build did not travel."""
+    import concurrent.futures as cf
+    import numpy as np
+    import pipbatch as pb
+    from piplib_amd import synth
+    exe, kind = (pb.REFPIP, "reference") if pb.have_ref() else (pb.ORACLEPIP, "port")
+    if not os.access(exe, os.X_OK):
+        return None
+    cores = max(1, min(max_procs, len(os.sched_getaffinity(0))))
+    per = 640  # ~50k pivots per process: ~0.6-1.3 s each, ~10-20 s of CPU work in all, bounded
+    n = min(rows.shape[0], per * cores)
+    per = max(1, n // cores)
+    chunks = [rows[c * per:(c + 1) * per] for c in range(cores)]
+
+    def run(chunk):
+        probs = [synth.Problem(NVAR, NPARM, NI, 0, -1, 1, chunk[b], np.zeros((0, NPARM + 1), np.int64))
+                 for b in range(chunk.shape[0])]
+        return pb.run_batch(exe, probs, pb.F_NOSIMPLIFY | pb.F_NOTEXT)
+
+    t0 = time.time()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        outs = list(ex.map(run, chunks))
+    wall = time.time() - t0
+    piv = sum(o.total_pivots for o in outs)
+    tmax = max(o.solve_seconds for o in outs)
+    return {"value": piv / tmax, "unit": "pivots/s", "cores": cores, "kind": kind,
+            "sample": f"first {per * cores} tableaux of rank 0's batch ({piv} pivots), {cores} processes x "
+                      f"{per} tableaux, slowest process {tmax:.2f} s solve time (wall {wall:.1f} s incl. I/O)",
+            "per_core": piv / sum(o.solve_seconds for o in outs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=10000, help="tableaux per GPU")
+    ap.add_argument("--waves", type=int, default=0, help="waves per tableau (0 = engine default)")
+    ap.add_argument("--round", type=int, default=0, help="pivots per tableau per launch (0 = engine default)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from piplib_amd import engine as eng
+    from piplib_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    rows_h = synth.lexmin_batch(1000 + rank, args.batch, NVAR, NI)
+    e = eng.Engine(local)
+    if args.waves:
+        e.set_waves_per_job(args.waves)
+    if args.round:
+        e.set_round_pivots(args.round)
+    b = eng.Batch(e, rows_h, NVAR, NPARM, tflags=eng.T_INT)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        b.load()
+        b.solve()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP events recorded on the launch stream around the advance kernel; reading them
+        # after the step keeps the timed loop honest (it includes this sync).
+        kernel_ms.append(b.last_solve_ms())
+    barrier()
+    dt = time.perf_counter() - t0
+
+    b.fetch()
+    torch.cuda.synchronize(dev)
+    st = b.status.cpu().numpy()
+    piv = int(b.pivots.sum().item())
+    cuts = int(b.cuts.sum().item())
+    solved = int(((st == eng.ST_SOLUTION) | (st == eng.ST_NIL)).sum())
+
+    tot = torch.tensor([piv, args.batch, solved, cuts], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tot = tot.cpu().numpy()
+    dt_max = float(tmax.item())
+
+    if rank == 0:
+        ms_step = dt_max / args.steps * 1e3
+        piv_per_step = float(tot[0])
+        k_ms = float(np.mean(kernel_ms))
+        algo_bytes = b.pivot_bytes() * piv  # this rank's launch
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "pivots/sec (batched 64x128 int64 tableaux, integer solve with Gomory cuts)",
+            "value": piv_per_step / (ms_step * 1e-3),
+            "unit": "pivots/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {"workload": "10k-batch synthetic 64x128 tableaux, int64, integer solve with Gomory cuts",
+                       "batch_per_gpu": args.batch, "nvar": NVAR, "nparm": NPARM, "ni": NI,
+                       "parallelism": f"{world} x independent batches (one workgroup per tableau)"},
+            "problems_per_sec": float(tot[1]) / (ms_step * 1e-3),
+            "pivots_per_step": piv_per_step,
+            "cuts_per_step": float(tot[3]),
+            "finished_fraction": float(tot[2]) / float(tot[1]),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pip_advance_kernel", "kernel_ms": k_ms,
+                         "launches_per_step": e.last_solve_launches(),
+                         "algorithmic_bytes_per_pivot": b.pivot_bytes()},
+        }
+        if not args.no_cpu:
+            cb = cpu_baseline(rows_h, 16)
+            if cb:
+                out["cpu_baseline"] = cb
+                out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

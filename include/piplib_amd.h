@@ -47,6 +47,7 @@ extern "C" {
 /* engine-only flags */
 #define PIPAMD_T_SORT 256    /* rows not yet sorted (tab_sort_rows, traiter.c:556) */
 #define PIPAMD_T_DEEPEST 512 /* deepest-cut option (integrer.c:417-438) */
+#define PIPAMD_T_STATE 1024  /* a paused job's LDS summaries are saved in its state block */
 
 /* ---- per-problem status written by the engine ---- */
 #define PIPAMD_ST_RUN 0          /* not finished (iteration limit reached: relaunch) */
@@ -77,6 +78,10 @@ const char *pipamd_last_error(void);
 /* Upper bound on pivots per problem per launch (a problem still PIPAMD_ST_RUN afterwards is
  * simply resumed by the next pipamd_batch_solve); default 2^20. */
 int pipamd_engine_set_iter_limit(pipamd_engine *e, int pivots_per_launch);
+/* Waves (64 lanes each) that share one tableau: 1 keeps more tableaux in flight per CU (best for
+ * large batches of sparse problems), 4 spreads a tableau's rows over four waves (few or dense
+ * tableaux); 0 (default) = 1 when the batch has >= 2048 tableaux, else 4. */
+int pipamd_engine_set_waves_per_job(pipamd_engine *e, int waves);
 int pipamd_version(void);
 
 /* ------------------------------------------------------------------ layer 1 */
@@ -100,7 +105,8 @@ size_t pipamd_batch_workspace_bytes(const pipamd_batch_desc *d);
 int pipamd_batch_load(pipamd_engine *e, void *d_workspace, const pipamd_batch_desc *d,
                       const int64_t *d_rows, void *stream);
 
-/* traiter() on every tableau of the batch.  Asynchronous on `stream`. */
+/* traiter() on every tableau of the batch.  Launches on `stream` and returns when every
+ * tableau has a final status (it synchronises the stream between rounds). */
 int pipamd_batch_solve(pipamd_engine *e, void *d_workspace, const pipamd_batch_desc *d, void *stream);
 
 /* Copy out, device to device: status[b], pivots[b], cuts[b] (int32 each, may be NULL),
@@ -110,13 +116,24 @@ int pipamd_batch_results(pipamd_engine *e, const void *d_workspace, const pipamd
                          int32_t *d_status, int32_t *d_pivots, int32_t *d_cuts, int64_t *d_sol_num,
                          int64_t *d_sol_den, void *stream);
 
+/* Batch totals, device memory, 4 x uint64: [0] pivots (calls of pivoter), [1] Gomory cuts,
+ * [2] rows rewritten by pivots (rows whose pivot-column entry is zero and that are already
+ * reduced are left untouched -- same result as the reference's multiply-by-one pass),
+ * [3] tableaux finished (solution or nil). */
+int pipamd_batch_counters(pipamd_engine *e, const void *d_workspace, const pipamd_batch_desc *d,
+                          uint64_t *d_out4, void *stream);
+
 /* Algorithmic HBM bytes of ONE pivot of one tableau of this shape (read+write of every
  * real row): the per-unit figure bench.py's roofline uses (DESIGN.md section "Roofline"). */
 size_t pipamd_pivot_bytes(const pipamd_batch_desc *d);
 
-/* Time of the last pipamd_batch_solve launch in milliseconds, measured with HIP events
- * on the launch stream (blocks until the kernel finished). */
+/* Sum of the pivot-kernel launch durations of the last pipamd_batch_solve in milliseconds,
+ * measured with HIP events on the launch stream, and the number of those launches. */
 int pipamd_last_solve_ms(pipamd_engine *e, float *ms);
+int pipamd_last_solve_launches(pipamd_engine *e);
+/* Pivots per tableau per launch (default 16): pipamd_batch_solve runs the pivot loop in
+ * rounds so that every CU stays busy although tableaux need different numbers of pivots. */
+int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots);
 
 /* ------------------------------------------------------------------ layer 3 */
 /* One problem in PIP's native tableau form (what maind.c reads from a .dat file):

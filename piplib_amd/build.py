@@ -21,19 +21,27 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, profile=False):
+    """profile=True builds the diagnostic variant libpipamd_prof.so (-DPIP_PROFILE: per-phase
+    cycle stamps in the kernel; never used for timing or shipped results)."""
+    if profile:
+        return _compile(os.path.join(HERE, "libpipamd_prof.so"), ["-DPIP_PROFILE"], verbose)
     if not force and not needs_build():
         return OUT
+    return _compile(OUT, [], verbose)
+
+
+def _compile(out, extra, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-DNDEBUG",
-           "-Wall", "-Wno-unused-function", "-x", "hip"]
+           "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-x", "hip"] + extra
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", OUT]
+    cmd += ["-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, profile="--profile" in sys.argv)

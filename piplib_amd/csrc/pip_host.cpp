@@ -42,16 +42,15 @@ extern "C" int pipamd_engine_create(pipamd_engine **out, int device) {
   if (!e) return PIPAMD_E_NOMEM;
   e->device = device;
   e->iter_limit = 1 << 20;
-  HIPCHK(hipEventCreate(&e->ev0));
-  HIPCHK(hipEventCreate(&e->ev1));
   *out = e;
   return PIPAMD_OK;
 }
 
 extern "C" void pipamd_engine_destroy(pipamd_engine *e) {
   if (!e) return;
-  hipEventDestroy(e->ev0);
-  hipEventDestroy(e->ev1);
+  for (int i = 0; i < 2 * e->nev; i++) hipEventDestroy(e->ev[i]);
+  if (e->d_run) hipFree(e->d_run);
+  if (e->h_run) hipHostFree(e->h_run);
   if (e->d_scratch) hipFree(e->d_scratch);
   free(e);
 }
@@ -84,7 +83,11 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
     return PIPAMD_E_INVALID;
   }
   const int64_t sol = round_even(d->nvar * (d->nparm + d->cap_newparm + 1) + d->nvar);
-  lay->per_job = 2 * (int64_t)lay->L + (int64_t)lay->S * lay->W + sol;
+  const int nm = lay->W <= 128 ? 2 : (lay->W <= 256 ? 4 : 8);
+  const int64_t state = round_even(lay->S * nm + (3 * lay->L + 7) / 8);
+  lay->sol_words = (int32_t)sol;
+  lay->state_words = (int32_t)state;
+  lay->per_job = 2 * (int64_t)lay->L + (int64_t)lay->S * lay->W + sol + state;
   lay->arena_off = 0;
   *jobs_bytes = ((size_t)d->batch * sizeof(PipJob) + 255) & ~(size_t)255;
   return PIPAMD_OK;
@@ -115,6 +118,12 @@ extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batc
   return PIPAMD_OK;
 }
 
+// traiter() for the whole batch.  The pivot loop runs in rounds of at most `round_pivots`
+// pivots per tableau: a round ends for a tableau when it is finished, has used its pivot
+// budget, or has no room left in the LDS image of that launch; it is then resumed by the
+// next launch.  Rounds keep every CU busy although tableaux need very different numbers of
+// pivots, and let each launch size its LDS image to the rows the running tableaux have *now*
+// (Gomory cuts add rows as the solve goes on).
 extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, void *stream) {
   PipBatchLayout lay;
   size_t jb;
@@ -124,17 +133,65 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
   PipJob *jobs = (PipJob *)d_ws;
   long long *arena = (long long *)((char *)d_ws + jb);
   hipStream_t st = (hipStream_t)stream;
-  HIPCHK(hipEventRecord(e->ev0, st));
-  HIPCHK(pipk_launch_advance(jobs, arena, lay.batch, lay.L, lay.S, lay.W, e->iter_limit, st));
-  HIPCHK(hipEventRecord(e->ev1, st));
+  if (!e->d_run) {
+    HIPCHK(hipMalloc((void **)&e->d_run, 2 * sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&e->h_run, 2 * sizeof(int), hipHostMallocDefault));
+  }
+  int running = lay.batch, max_ni = lay.ni;
+  e->nlaunch = 0;
+  const int K = e->round_pivots > 0 ? e->round_pivots : 16;
+  while (running > 0) {
+    if (e->nlaunch >= PIPAMD_MAX_ROUNDS) {
+      pipamd_set_error("batch_solve: more than %d rounds", PIPAMD_MAX_ROUNDS);
+      return PIPAMD_E_SOLVER;
+    }
+    int budget = K;
+    if (e->iter_limit < budget) budget = e->iter_limit;
+    int smax = max_ni + budget;  // a cut is always followed by a pivot: at most `budget` new rows
+    if (smax > lay.S) smax = lay.S;
+    if (smax < max_ni) smax = max_ni;
+    const int lmax = lay.nvar + smax;
+    const int waves = e->waves_per_job ? e->waves_per_job : (running >= 2048 ? 1 : 4);
+    if (e->nlaunch >= e->nev) {
+      HIPCHK(hipEventCreate(&e->ev[2 * e->nev]));
+      HIPCHK(hipEventCreate(&e->ev[2 * e->nev + 1]));
+      e->nev++;
+    }
+    HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch], st));
+    HIPCHK(pipk_launch_advance(jobs, arena, lay.batch, lmax, smax, lay.W, budget, waves, e->d_prof, st));
+    HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
+    e->nlaunch++;
+    HIPCHK(pipk_launch_batch_running(jobs, lay.batch, e->d_run, st));
+    HIPCHK(hipMemcpyAsync(e->h_run, e->d_run, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    running = e->h_run[0];
+    max_ni = e->h_run[1];
+    if (e->single_launch) break;
+  }
   e->timed = 1;
   return PIPAMD_OK;
 }
 
+// Sum of the advance-kernel launch durations of the last pipamd_batch_solve (HIP events on
+// the launch stream) and their number.
 extern "C" int pipamd_last_solve_ms(pipamd_engine *e, float *ms) {
   if (!e || !ms || !e->timed) return PIPAMD_E_INVALID;
-  HIPCHK(hipEventSynchronize(e->ev1));
-  HIPCHK(hipEventElapsedTime(ms, e->ev0, e->ev1));
+  float tot = 0;
+  for (int i = 0; i < e->nlaunch; i++) {
+    float t = 0;
+    HIPCHK(hipEventSynchronize(e->ev[2 * i + 1]));
+    HIPCHK(hipEventElapsedTime(&t, e->ev[2 * i], e->ev[2 * i + 1]));
+    tot += t;
+  }
+  *ms = tot;
+  return PIPAMD_OK;
+}
+
+extern "C" int pipamd_last_solve_launches(pipamd_engine *e) { return e ? e->nlaunch : 0; }
+
+extern "C" int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots) {
+  if (!e || pivots < 1) return PIPAMD_E_INVALID;
+  e->round_pivots = pivots;
   return PIPAMD_OK;
 }
 
@@ -150,6 +207,38 @@ extern "C" int pipamd_batch_results(pipamd_engine *e, const void *d_ws, const pi
   const long long *arena = (const long long *)((const char *)d_ws + jb);
   HIPCHK(pipk_launch_batch_results(jobs, arena, lay.batch, lay.nvar, lay.nparm, d_status, d_pivots, d_cuts,
                                    (long long *)d_sol_num, (long long *)d_sol_den, (hipStream_t)stream));
+  return PIPAMD_OK;
+}
+
+extern "C" int pipamd_batch_counters(pipamd_engine *e, const void *d_ws, const pipamd_batch_desc *d, uint64_t *d_out4,
+                                     void *stream) {
+  PipBatchLayout lay;
+  size_t jb;
+  if (!e || !d_ws || !d_out4) return PIPAMD_E_INVALID;
+  int rc = pipamd_batch_layout(d, &lay, &jb);
+  if (rc) return rc;
+  HIPCHK(pipk_launch_batch_counters((const PipJob *)d_ws, lay.batch, (unsigned long long *)d_out4, (hipStream_t)stream));
+  return PIPAMD_OK;
+}
+
+// Diagnostic only: per-phase cycle sums of the advance kernel (needs a -DPIP_PROFILE build).
+extern "C" int pipamd_debug_profile(pipamd_engine *e, int enable, uint64_t *host_out10) {
+  if (!e) return PIPAMD_E_INVALID;
+  if (enable && !e->d_prof) {
+    HIPCHK(hipMalloc((void **)&e->d_prof, 10 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(e->d_prof, 0, 10 * sizeof(unsigned long long)));
+  }
+  if (host_out10 && e->d_prof) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host_out10, e->d_prof, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->d_prof, 0, 10 * sizeof(unsigned long long)));
+  }
+  return PIPAMD_OK;
+}
+
+extern "C" int pipamd_engine_set_waves_per_job(pipamd_engine *e, int waves) {
+  if (!e || (waves != 0 && waves != 1 && waves != 4)) return PIPAMD_E_INVALID;
+  e->waves_per_job = waves;
   return PIPAMD_OK;
 }
 

@@ -5,11 +5,19 @@
 
 #include "pip_job.h"
 
+#define PIPAMD_MAX_ROUNDS 512
+
 struct pipamd_engine {
   int device;
-  hipEvent_t ev0, ev1;
+  hipEvent_t ev[2 * PIPAMD_MAX_ROUNDS];
+  int nev, nlaunch;
   int timed;
+  int round_pivots;  /* pivots per tableau per launch (0 = default) */
+  int single_launch; /* debug: stop after one launch */
+  int *d_run, *h_run;
   int iter_limit;
+  int waves_per_job; /* 0 = choose by batch size */
+  unsigned long long *d_prof; /* diagnostic builds only (-DPIP_PROFILE) */
   void *d_scratch;
   size_t scratch_bytes;
 };
@@ -19,11 +27,13 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
 
 extern "C" {
 hipError_t pipk_launch_advance(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
-                               hipStream_t stream);
+                               int waves_per_job, unsigned long long *prof, hipStream_t stream);
 hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long long *rows, PipBatchLayout lay,
                                   hipStream_t stream);
 hipError_t pipk_launch_batch_results(const PipJob *jobs, const long long *arena, int njobs, int nvar, int nparm,
                                      int *status, int *pivots, int *cuts, long long *sol_num, long long *sol_den,
                                      hipStream_t stream);
+hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, int *out2, hipStream_t stream);
+hipError_t pipk_launch_batch_counters(const PipJob *jobs, int njobs, unsigned long long *out, hipStream_t stream);
 }
 #endif

@@ -16,14 +16,15 @@
  *   rows_off: den[L] (int64) | flag[L] (int32) | ref[L] (int32)      = 2*L int64
  *   vals_off: S slots of W int64 (zero beyond the live columns)
  *   sol_off : nvar*(nparm+1) numerators | nvar denominators
+ *   state_off: LDS summaries of a paused job: nzm[S][NM] (u64) | sig[L] (u16) | rbits[L] (u8)
  * Mirrors the reference's struct T / struct L (tab.h:36-85) without pointers. */
 typedef struct PipJob {
-  int64_t vals_off, rows_off, sol_off;
+  int64_t vals_off, rows_off, sol_off, state_off;
   int32_t nvar, nparm, ni, bigparm;
   int32_t tflags;
   int32_t L, S, W;
   int32_t status, aux, npiv, ncut;
-  int32_t ldet, pad0;
+  int32_t ldet, nupd; /* nupd: rows rewritten by pivots so far (excludes skipped zero-multiplier rows) */
   int64_t det[PIPAMD_MAXDET]; /* multi-limb determinant, tab.h:76-81 */
   uint64_t maxabs;
 } PipJob;
@@ -33,6 +34,7 @@ typedef struct PipBatchLayout {
   int64_t per_job;   /* block size per job, int64 units */
   int32_t batch, nvar, nparm, ni, bigparm, tflags;
   int32_t L, S, W;
+  int32_t sol_words, state_words;
 } PipBatchLayout;
 
 #endif

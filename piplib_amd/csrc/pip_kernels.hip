@@ -4,11 +4,11 @@
 // PipLib's dual-simplex pivot loop on it:
 //
 //   traiter()      reference source/traiter.c:628-791   -> pip_advance_kernel main loop
-//   chercher()     traiter.c:39-44                      -> phase A (first Minus row)
+//   chercher()     traiter.c:39-44                      -> first-Minus search fused into phase C
 //   exam_coef()    traiter.c:101-159                    -> exam_rows()   (from per-row sign summaries)
 //   choisir_piv()  traiter.c:297-341                    -> choose_column() (wave 0, row-ordered tournament)
-//   pivoter()      traiter.c:345-548                    -> phases C1..C5
-//   integrer()     integrer.c:305-534 (constant cuts)   -> gomory_cut()
+//   pivoter()      traiter.c:345-548                    -> phases A (wave 0), B (all waves), C (all threads)
+//   integrer()     integrer.c:305-534 (constant cuts)   -> phase G
 //   tab_sort_rows  traiter.c:556-623                    -> sort_rows()
 //
 // Data layout (all int64 "Entier" numerators, wrap-around arithmetic exactly as
@@ -17,11 +17,17 @@
 //     aligned rows so a wave reads/writes a row with 16 B per lane, coalesced);
 //   * logical row i is either a unit row (identity on column ref[i]) or a real
 //     row stored in slot ref[i]; flags/denominators/ref of all logical rows are
-//     staged in LDS for the whole solve, as are the pivot row, the per-row
-//     multipliers derived from the pivot column, and a per-row sign summary so
-//     that sign tests never touch HBM;
+//     staged in LDS for the whole solve, together with
+//       - the pivot row,
+//       - a per-row sign summary (so sign tests never touch HBM),
+//       - a per-row non-zero bitmap (so the pivot-column tournament and the
+//         elimination step only load rows that can matter);
 //   * wave-level ballots / shuffles implement the pivot-column tournament, the
 //     row-gcd refinement and all sign tests.  No MFMA: exact integer work.
+//
+// Rows whose pivot-column entry is zero and whose gcd with their denominator is
+// already 1 are not rewritten: the reference multiplies them by 1, subtracts 0
+// and divides by gcd 1 (traiter.c:470-501), i.e. leaves the same bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,10 +35,11 @@
 
 typedef long long i64;
 typedef unsigned long long u64;
+typedef unsigned short u16;
+typedef unsigned char u8;
 
-#define NT 256
-#define NW 4
 #define BIG_I 0x7fffffff
+#define NOROW 0xffff
 
 // ---------------------------------------------------------------- integer ops
 // piplib.h:128-169 + integrer.c:43-74 on wrap-around 64-bit integers.
@@ -59,15 +66,50 @@ __device__ __forceinline__ u64 gcd_u64(u64 a, u64 b) {
   } while (b);
   return a << sh;
 }
-__device__ __forceinline__ i64 gcd_i64(i64 a, i64 b) { return (i64)gcd_u64(uabs64(a), uabs64(b)); }
+__device__ __forceinline__ unsigned gcd_u32(unsigned a, unsigned b) {
+  if (a == 0) return b;
+  if (b == 0) return a;
+  int sh = __builtin_ctz(a | b);
+  a >>= __builtin_ctz(a);
+  do {
+    b >>= __builtin_ctz(b);
+    if (a > b) {
+      unsigned t = a;
+      a = b;
+      b = t;
+    }
+    b -= a;
+  } while (b);
+  return a << sh;
+}
+__device__ __forceinline__ u64 gcd_mag(u64 a, u64 b) {
+  if (((a | b) >> 32) == 0) return gcd_u32((unsigned)a, (unsigned)b);
+  return gcd_u64(a, b);
+}
+__device__ __forceinline__ i64 gcd_i64(i64 a, i64 b) { return (i64)gcd_mag(uabs64(a), uabs64(b)); }
+// wave-uniform values: pin them to scalar registers so that the gcd / division / inverse
+// chains that follow run on the scalar unit instead of occupying all 64 vector lanes
+__device__ __forceinline__ i64 uni64(i64 v) {
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(u64)v);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((u64)v >> 32));
+  return (i64)(((u64)hi << 32) | lo);
+}
+__device__ __forceinline__ i64 readlane64(i64 v, int src) {
+  unsigned lo = __builtin_amdgcn_readlane((unsigned)(u64)v, src);
+  unsigned hi = __builtin_amdgcn_readlane((unsigned)((u64)v >> 32), src);
+  return (i64)(((u64)hi << 32) | lo);
+}
 // C '/' and '%' made total (the CPU traps on x / 0 and MIN / -1).
 __device__ __forceinline__ i64 cquo(i64 a, i64 b) {
+  if (b == 1) return a;
   if (b == 0) return 0;
   if (b == -1) return wneg(a);
+  if ((i64)(int)a == a && (i64)(int)b == b) return (i64)((int)a / (int)b);
   return a / b;
 }
 __device__ __forceinline__ i64 crem(i64 a, i64 b) {
-  if (b == 0 || b == -1) return 0;
+  if (b == 0 || b == -1 || b == 1) return 0;
+  if ((i64)(int)a == a && (i64)(int)b == b) return (i64)((int)a % (int)b);
   return a % b;
 }
 // integrer.c:69-74 piplib_llmod
@@ -82,6 +124,7 @@ __device__ __forceinline__ int log2_64(i64 x) {
   int n = 64 - __builtin_clzll(u | 1ull);
   return u == 0 ? 1 : n;
 }
+__device__ __forceinline__ int bitlen64(u64 u) { return u ? 64 - __builtin_clzll(u) : 0; }
 // inverse of an odd number modulo 2^64 (Newton), for exact division
 __device__ __forceinline__ u64 inv_odd64(u64 m) {
   u64 x = m;  // 3 correct bits
@@ -106,6 +149,15 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
   return v;
 }
 
+// workgroup barrier; a single-wave workgroup only needs the compiler to keep LDS order
+template <int NW>
+__device__ __forceinline__ void bsync() {
+  if (NW > 1)
+    __syncthreads();
+  else
+    __builtin_amdgcn_wave_barrier();
+}
+
 // per-row sign summary kept in LDS (exam_coef and the post-pivot flag update read only this)
 //  bits 0-1 constant term, bit 2 some parameter coef > 0, bit 3 some < 0,
 //  bits 4-5 big-parameter coef, bits 6-7 coef in the column just pivoted on.
@@ -114,26 +166,50 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
 #define SIG_PNEG(s) (((s) >> 3) & 1)
 #define SIG_BIG(s) (((s) >> 4) & 3)
 #define SIG_PIV(s) (((s) >> 6) & 3)
+#define SIG_RED 256  // gcd(row, denominator) is known to be 1 (the row needs no reduction)
 
+// Optional phase profile (diagnostic build only: -DPIP_PROFILE; never shipped/timed).
+#ifdef PIP_PROFILE
+#define PROF_DECL u64 pf_t = __builtin_readcyclecounter(), pf_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(i)                                \
+  do {                                         \
+    u64 pf_n = __builtin_readcyclecounter();   \
+    pf_acc[i] += pf_n - pf_t;                  \
+    pf_t = pf_n;                               \
+  } while (0)
+#define PROF_FLUSH(buf)                                                \
+  do {                                                                 \
+    if (threadIdx.x == 0 && buf)                                       \
+      for (int q_ = 0; q_ < 10; q_++) atomicAdd(&buf[q_], pf_acc[q_]); \
+  } while (0)
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_FLUSH(buf)
+#endif
+
+// LDS image of one job.  L = logical rows, S = row slots, WP = NCH*128 columns,
+// NM = 2*NCH mask words per row.  Column j of a row is owned by lane (j%128)/2 of
+// the wave that holds the row, register (c = j/128, h = j&1); a row's non-zero
+// bitmap uses the same geometry: word 2c+h, bit (j%128)/2.
 struct Shared {
-  i64 *den;    // [Lmax] denominators by logical row
-  i64 *prow;   // [Wmax] pivot row (zero beyond ncol)
-  i64 *lpiv;   // [Smax] per slot: pivot / gcd(pivot, foo)
-  i64 *foo;    // [Smax] per slot: foo / gcd
-  i64 *g0;     // [Smax] per slot: lpiv * old denominator
-  int *flag;   // [Lmax]
-  int *ref;    // [Lmax] slot (real row) or unit column
-  int *sig;    // [Lmax]
-  int *srow;   // [Smax] slot -> logical row
-  int *urow;   // [Wmax] unknown column -> logical row of its unit row (or -1)
-  float *size; // [Lmax] tab_sort_rows key
+  i64 *den;     // [L]  denominators by logical row
+  i64 *prow;    // [WP] pivot row (zero beyond ncol)
+  u64 *nzm;     // [S][NM] non-zero bitmap of each slot
+  float *size;  // [L]  tab_sort_rows key (entry only)
+  u16 *ref;     // [L]  slot (real row) or unit column
+  u16 *sig;     // [L]  sign summary
+  u16 *srow;    // [S]  slot -> logical row
+  u16 *work;    // [S]  slots the current pivot rewrites
+  u16 *urow;    // [WP] unknown column -> logical row of its unit row
+  u8 *flag;     // [L]
+  u8 *rbits;    // [L]  bit length of the row's max |entry|
 };
 
 struct Scalars {
-  int pivi, pivj, tmp, tmp2, status, aux;
-  int flagor;
-  u64 maxabs;
-  i64 pivot, dpiv;
+  int pivi, pivj, tmp, tmp2, aux;
+  int flagor, nwork, bad;
+  u64 smaxbits;
 };
 
 template <int NCH>
@@ -171,12 +247,15 @@ __device__ __forceinline__ void row_store(const RowRegs<NCH> &r, i64 *row, int n
   }
 }
 
-// sign summary + running max|entry| of a row held in registers (wave-collective)
+// Sign summary, non-zero bitmap and max|entry| of a row held in registers
+// (wave-collective).  Lane 0 publishes them for logical row k / slot s.
 template <int NCH>
-__device__ __forceinline__ int row_signature(const RowRegs<NCH> &r, int nvar, int ncol, int bigparm, int pivj,
-                                              int lane, u64 &maxabs) {
+__device__ __forceinline__ void row_publish(const RowRegs<NCH> &r, const Shared &S, int k, int s, int nvar, int ncol,
+                                            int bigparm, int pivj, int extra_sig, int lane) {
   int cs = 0, bs = 0, ps = 0;
   bool ppos = false, pneg = false;
+  u64 mx = 0;
+  u64 nz[2 * NCH];
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
@@ -184,7 +263,7 @@ __device__ __forceinline__ int row_signature(const RowRegs<NCH> &r, int nvar, in
       int j = c * 128 + 2 * lane + h;
       i64 z = r.v[c][h];
       u64 a = uabs64(z);
-      maxabs = a > maxabs ? a : maxabs;
+      mx = a > mx ? a : mx;
       if (j == nvar) cs = sign_code(z);
       if (j == bigparm) bs = sign_code(z);
       if (j == pivj) ps = sign_code(z);
@@ -192,14 +271,20 @@ __device__ __forceinline__ int row_signature(const RowRegs<NCH> &r, int nvar, in
         ppos |= z > 0;
         pneg |= z < 0;
       }
+      nz[2 * c + h] = __ballot(z != 0);
     }
-  // every field is owned by exactly one lane (or is an OR): combine with ballots
-  int sig = 0;
+  int sig = extra_sig;
   sig |= (__ballot(cs == 1) ? 1 : 0) | (__ballot(cs == 2) ? 2 : 0);
   sig |= (__ballot(ppos) ? 4 : 0) | (__ballot(pneg) ? 8 : 0);
   sig |= (__ballot(bs == 1) ? 16 : 0) | (__ballot(bs == 2) ? 32 : 0);
   sig |= (__ballot(ps == 1) ? 64 : 0) | (__ballot(ps == 2) ? 128 : 0);
-  return sig;
+  mx = wave_max_u64(mx);
+  if (lane == 0) {
+    S.sig[k] = (u16)sig;
+    S.rbits[k] = (u8)bitlen64(mx);
+#pragma unroll
+    for (int e = 0; e < 2 * NCH; e++) S.nzm[(size_t)s * (2 * NCH) + e] = nz[e];
+  }
 }
 
 // pivoter()'s inner loop for one row (traiter.c:470-501), one wave per row.
@@ -212,6 +297,7 @@ __device__ __forceinline__ int row_signature(const RowRegs<NCH> &r, int nvar, in
 template <int NCH>
 __device__ __forceinline__ bool update_row(RowRegs<NCH> &r, const i64 *prow, int pivj, i64 lpiv, i64 foo, i64 dpiv,
                                            i64 g0, int lane, i64 &newden) {
+  u64 mx = 0;
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
@@ -221,10 +307,15 @@ __device__ __forceinline__ bool update_row(RowRegs<NCH> &r, const i64 *prow, int
       i64 z = wsub(wmul(r.v[c][h], lpiv), wmul(q, foo));
       if (j == pivj) z = wmul(dpiv, foo);
       r.v[c][h] = z;
+      u64 a = uabs64(z);
+      mx = a > mx ? a : mx;
     }
   newden = g0;
   if (g0 == 1) return true;
-  u64 g = uabs64(g0);
+  u64 g = (u64)uni64((i64)uabs64(g0));
+  // 32-bit remainders when everything fits (the common case): one v_rcp-based
+  // division instead of the 64-bit software routine
+  const bool small = (__ballot((mx >> 32) != 0) == 0) && (g >> 32) == 0;
   for (;;) {
     u64 rr = 0;
 #pragma unroll
@@ -232,14 +323,20 @@ __device__ __forceinline__ bool update_row(RowRegs<NCH> &r, const i64 *prow, int
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         u64 a = uabs64(r.v[c][h]);
-        u64 m = g ? a % g : a;
+        u64 m;
+        if (g == 0)
+          m = a;
+        else if (small)
+          m = (unsigned)a % (unsigned)g;
+        else
+          m = a % g;
         rr = rr ? rr : m;
       }
     u64 nz = __ballot(rr != 0);
     if (!nz) break;
     int src = __ffsll((long long)nz) - 1;
-    u64 r0 = (u64)shfl64((i64)rr, src);
-    g = gcd_u64(g, r0);
+    u64 r0 = (u64)readlane64((i64)rr, src);
+    g = gcd_mag(g, r0);
     if (g == 1) break;
   }
   if (g == 1) return true;
@@ -257,14 +354,17 @@ __device__ __forceinline__ bool update_row(RowRegs<NCH> &r, const i64 *prow, int
 // ------------------------------------------------------------------ exam_coef
 // traiter.c:101-159 from the LDS sign summaries.  Block-collective; returns the
 // first row proven negative or BIG_I.
+template <int NW>
 __device__ int exam_rows(const Shared &S, Scalars *sc, int nligne, int bigparm) {
+  constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
+  u8 *nf = (u8 *)S.size;  // the sort keys are dead after entry: reuse them for the tentative flags
   if (bigparm >= 0) {
     if (tid == 0) sc->tmp = BIG_I;
-    __syncthreads();
+    bsync<NW>();
     for (int i = tid; i < nligne; i += NT)
       if (S.flag[i] == PIPAMD_F_UNKNOWN && SIG_BIG(S.sig[i]) == 2) atomicMin(&sc->tmp, i);
-    __syncthreads();
+    bsync<NW>();
     int i1 = sc->tmp;
     for (int i = tid; i < nligne; i += NT)
       if (S.flag[i] == PIPAMD_F_UNKNOWN) {
@@ -273,14 +373,12 @@ __device__ int exam_rows(const Shared &S, Scalars *sc, int nligne, int bigparm) 
         else if (i < i1 && SIG_BIG(S.sig[i]) == 1)
           S.flag[i] = PIPAMD_F_PLUS;
       }
-    __syncthreads();
+    bsync<NW>();
     if (i1 != BIG_I) return i1;
   }
   if (tid == 0) sc->tmp = BIG_I;
-  __syncthreads();
-  int nf[4];  // up to 1024 logical rows / 256 threads
-  int cnt = 0;
-  for (int i = tid; i < nligne; i += NT, cnt++) {
+  bsync<NW>();
+  for (int i = tid; i < nligne; i += NT) {
     int f = 0;
     if (S.flag[i] == PIPAMD_F_UNKNOWN) {
       int sg = S.sig[i];
@@ -296,14 +394,13 @@ __device__ int exam_rows(const Shared &S, Scalars *sc, int nligne, int bigparm) 
         f = fc;
       if (f == PIPAMD_F_MINUS) atomicMin(&sc->tmp, i);
     }
-    nf[cnt & 3] = f;
+    nf[i] = (u8)f;
   }
-  __syncthreads();
+  bsync<NW>();
   int i2 = sc->tmp;
-  cnt = 0;
-  for (int i = tid; i < nligne; i += NT, cnt++)
-    if (nf[cnt & 3] && i <= i2) S.flag[i] = nf[cnt & 3];
-  __syncthreads();
+  for (int i = tid; i < nligne; i += NT)
+    if (nf[i] && i <= i2) S.flag[i] = nf[i];
+  bsync<NW>();
   return i2;
 }
 
@@ -315,35 +412,48 @@ __device__ int exam_rows(const Shared &S, Scalars *sc, int nligne, int bigparm) 
 //   * a unit row (identity on column u) is > 0 only in column u: it removes u
 //     from the tied set unless u is the last one left;
 //   * a real row keeps the columns with minimal v[k][j]/a_j (exact
-//     cross-multiplication, ties kept);
-// and stop when one column is left.  Executed by wave 0 only.
+//     cross-multiplication, ties kept); a real row that is zero in every tied
+//     column cannot separate them, so it is skipped on its LDS bitmap alone;
+// and stop when one column is left.  Executed by wave 0 only; `a` holds the
+// pivot row in the wave's lane geometry.
 // Exact while (max a_j) * (max |entry|) < 2^62, which the caller guarantees.
 template <int NCH>
-__device__ int choose_column(const Shared &S, const i64 *vals, int W, int nvar, int nligne, int pivi, int ncolp,
-                             Scalars *sc) {
+__device__ int choose_column(const Shared &S, const RowRegs<NCH> &prow, const i64 *vals, int W, int nvar, int nligne,
+                             int pivi, int ncolp, Scalars *sc) {
+  constexpr int NM = 2 * NCH;
   const int lane = threadIdx.x & 63;
   i64 a[NCH][2];
   int u[NCH][2];
   bool cand[NCH][2];
+  u64 cm[NM];
   int count = 0;
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       int j = c * 128 + 2 * lane + h;
-      a[c][h] = j < nvar ? S.prow[j] : 0;
+      a[c][h] = j < nvar ? prow.v[c][h] : 0;
       cand[c][h] = a[c][h] > 0;
-      u[c][h] = cand[c][h] ? S.urow[j] : -1;
-      count += __popcll(__ballot(cand[c][h]));
+      u[c][h] = cand[c][h] ? (int)S.urow[j] : -1;
+      cm[2 * c + h] = __ballot(cand[c][h]);
+      count += __popcll(cm[2 * c + h]);
     }
   if (count == 0) return -1;
   for (int k0 = 0; k0 < nligne && count > 1; k0 += 64) {
-    int k = k0 + lane;
-    bool real = k < nligne && !(S.flag[k] & PIPAMD_F_UNIT) && k != pivi;
-    u64 realmask = __ballot(real);
-    while (realmask && count > 1) {
-      int kk = k0 + __ffsll((long long)realmask) - 1;
-      realmask &= realmask - 1;
+    const int k = k0 + lane;
+    bool rel = false;
+    if (k < nligne && k != pivi && !(S.flag[k] & PIPAMD_F_UNIT)) {
+      const u64 *m = S.nzm + (size_t)S.ref[k] * NM;
+      u64 x = 0;
+#pragma unroll
+      for (int e = 0; e < NM; e++) x |= m[e] & cm[e];
+      rel = x != 0;
+    }
+    u64 relmask = __ballot(rel);
+    while (relmask && count > 1) {
+      const int kk = k0 + __ffsll((long long)relmask) - 1;
+      relmask &= relmask - 1;
+      const int sl = S.ref[kk];
       // unit rows above kk knock out their own column
       int nel = 0;
 #pragma unroll
@@ -355,14 +465,22 @@ __device__ int choose_column(const Shared &S, const i64 *vals, int W, int nvar, 
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
-          for (int h = 0; h < 2; h++)
+          for (int h = 0; h < 2; h++) {
             if (u[c][h] < kk) cand[c][h] = false;
+            cm[2 * c + h] = __ballot(cand[c][h]);
+          }
         count -= nel;
         if (count == 1) break;
       }
+      {  // still able to separate the remaining columns?
+        u64 x = 0;
+#pragma unroll
+        for (int e = 0; e < NM; e++) x |= S.nzm[(size_t)sl * NM + e] & cm[e];
+        if (!x) continue;
+      }
       // real row kk: keep the minimal ratios
       RowRegs<NCH> n;
-      row_load<NCH>(n, vals + (size_t)S.ref[kk] * W, ncolp, lane);
+      row_load<NCH>(n, vals + (size_t)sl * W, ncolp, lane);
       for (;;) {
         // reference column b = first remaining candidate
         i64 ab = 0, nb = 0;
@@ -371,11 +489,11 @@ __device__ int choose_column(const Shared &S, const i64 *vals, int W, int nvar, 
         for (int c = 0; c < NCH; c++)
 #pragma unroll
           for (int h = 0; h < 2; h++) {
-            u64 m = __ballot(cand[c][h]);
+            u64 m = cm[2 * c + h];
             if (!got && m) {
               int src = __ffsll((long long)m) - 1;
-              ab = shfl64(a[c][h], src);
-              nb = shfl64(n.v[c][h], src);
+              ab = readlane64(a[c][h], src);
+              nb = readlane64(n.v[c][h], src);
               got = true;
             }
           }
@@ -394,26 +512,26 @@ __device__ int choose_column(const Shared &S, const i64 *vals, int W, int nvar, 
           }
         if (nneg == 0) {
           count = nzero;
-          break;
+        } else {
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) cand[c][h] = neg[c][h];
+          count = nneg;
         }
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
-          for (int h = 0; h < 2; h++) cand[c][h] = neg[c][h];
-        count = nneg;
-        if (count == 1) break;
+          for (int h = 0; h < 2; h++) cm[2 * c + h] = __ballot(cand[c][h]);
+        if (nneg == 0 || count == 1) break;
       }
     }
   }
   if (count == 1) {
     int res = -1;
 #pragma unroll
-    for (int c = 0; c < NCH; c++)
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        u64 m = __ballot(cand[c][h]);
-        if (m) res = c * 128 + 2 * (__ffsll((long long)m) - 1) + h;
-      }
+    for (int e = 0; e < NM; e++)
+      if (cm[e]) res = (e >> 1) * 128 + 2 * (__ffsll((long long)cm[e]) - 1) + (e & 1);
     return res;
   }
 last_unit_wins:
@@ -432,11 +550,10 @@ last_unit_wins:
 // ------------------------------------------------------------ tab_sort_rows
 // traiter.c:591-614: selection sort of the real rows nvar..nligne-1 by `size`
 // (first minimum strictly below the running bound, swap into place).  Wave 0.
-__device__ void sort_rows(const Shared &S, int nvar, int nligne, float smaxf, double smax) {
+__device__ void sort_rows(const Shared &S, int nvar, int nligne, double smax) {
   const int lane = threadIdx.x & 63;
   for (int i = nvar; i < nligne; i++) {
     if (S.flag[i] & PIPAMD_F_UNIT) continue;
-    // first argmin of size[j], j >= i, among real rows with size < smax
     float best = 0;
     int bj = BIG_I;
     for (int j = i + lane; j < nligne; j += 64) {
@@ -458,22 +575,24 @@ __device__ void sort_rows(const Shared &S, int nvar, int nligne, float smaxf, do
     }
     int pv = (bj == BIG_I) ? i : bj;
     if (pv != i && lane == 0) {
-      int tf = S.flag[pv], tr = S.ref[pv], tg = S.sig[pv];
+      u8 tf = S.flag[pv], tb = S.rbits[pv];
+      u16 tr = S.ref[pv], tg = S.sig[pv];
       i64 td = S.den[pv];
       float ts = S.size[pv];
       S.flag[pv] = S.flag[i];
+      S.rbits[pv] = S.rbits[i];
       S.ref[pv] = S.ref[i];
       S.sig[pv] = S.sig[i];
       S.den[pv] = S.den[i];
       S.size[pv] = S.size[i];
       S.flag[i] = tf;
+      S.rbits[i] = tb;
       S.ref[i] = tr;
       S.sig[i] = tg;
       S.den[i] = td;
       S.size[i] = ts;
     }
     __builtin_amdgcn_wave_barrier();
-    (void)smaxf;
   }
 }
 
@@ -483,34 +602,49 @@ __device__ __forceinline__ int trunc_int_x86(double t) {
   return (int)t;
 }
 
-// ================================================================ main kernel
+// select the register that holds column pivj (uniform c,h) and broadcast it from its owner lane
 template <int NCH>
-__global__ __launch_bounds__(NT) void pip_advance_kernel(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax,
-                                                         int Wmax, int iter_limit) {
+__device__ __forceinline__ i64 row_entry(const RowRegs<NCH> &r, int pc, int ph, int pl) {
+  i64 mine = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (c == pc && h == ph) mine = r.v[c][h];
+  return readlane64(mine, pl);
+}
+
+// ================================================================ main kernel
+template <int NCH, int NW>
+__global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax,
+                                                         int Wmax, int iter_limit, u64 *prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Scalars sc;
   const int jb = blockIdx.x;
   if (jb >= njobs) return;
   PipJob *J = &jobs[jb];
   if (J->status != PIPAMD_ST_RUN) return;
+  constexpr int NT = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int WP = NCH * 128;  // columns a wave's registers cover; prow/urow are padded to it
+  constexpr int NM = 2 * NCH;
   (void)Wmax;
+  PROF_DECL;
 
   Shared S;
   {
     unsigned char *p = smem;
-    S.den = (i64 *)p;   p += sizeof(i64) * Lmax;
-    S.prow = (i64 *)p;  p += sizeof(i64) * WP;
-    S.lpiv = (i64 *)p;  p += sizeof(i64) * Smax;
-    S.foo = (i64 *)p;   p += sizeof(i64) * Smax;
-    S.g0 = (i64 *)p;    p += sizeof(i64) * Smax;
-    S.flag = (int *)p;  p += sizeof(int) * Lmax;
-    S.ref = (int *)p;   p += sizeof(int) * Lmax;
-    S.sig = (int *)p;   p += sizeof(int) * Lmax;
-    S.srow = (int *)p;  p += sizeof(int) * Smax;
-    S.urow = (int *)p;  p += sizeof(int) * WP;
-    S.size = (float *)p;
+    S.den = (i64 *)p;    p += sizeof(i64) * Lmax;
+    S.prow = (i64 *)p;   p += sizeof(i64) * WP;
+    S.nzm = (u64 *)p;    p += sizeof(u64) * (size_t)Smax * NM;
+    S.size = (float *)p; p += sizeof(float) * Lmax;
+    S.ref = (u16 *)p;    p += sizeof(u16) * Lmax;
+    S.sig = (u16 *)p;    p += sizeof(u16) * Lmax;
+    S.srow = (u16 *)p;   p += sizeof(u16) * Smax;
+    S.work = (u16 *)p;   p += sizeof(u16) * Smax;
+    S.urow = (u16 *)p;   p += sizeof(u16) * WP;
+    S.flag = (u8 *)p;    p += Lmax;
+    S.rbits = (u8 *)p;
   }
 
   const int nvar = J->nvar, nparm = J->nparm, bigparm = J->bigparm;
@@ -524,113 +658,113 @@ __global__ __launch_bounds__(NT) void pip_advance_kernel(PipJob *jobs, i64 *aren
   int *g_flag = (int *)(g_den + L);
   int *g_ref = g_flag + L;
   int nligne = nvar + ni;
-  int npiv = J->npiv, ncut = J->ncut;
+  int npiv = J->npiv, ncut = J->ncut, nupd = J->nupd;
   int ldet = J->ldet;
   i64 det[PIPAMD_MAXDET];
   for (int i = 0; i < PIPAMD_MAXDET; i++) det[i] = J->det[i];
+  if (ni > Smax || nligne > Lmax) return;  // this launch's LDS image is too small: stay RUN for a larger one
+  // saved LDS state of a paused job (bitmaps, sign summaries, magnitudes)
+  u64 *g_nzm = (u64 *)(arena + J->state_off);
+  u16 *g_sig = (u16 *)(g_nzm + (size_t)Sl * NM);
+  u8 *g_rbits = (u8 *)(g_sig + L);
 
   // ---- stage the row tables in LDS -------------------------------------
   for (int i = tid; i < nligne; i += NT) {
     S.den[i] = g_den[i];
-    S.flag[i] = g_flag[i];
-    S.ref[i] = g_ref[i];
+    S.flag[i] = (u8)g_flag[i];
+    S.ref[i] = (u16)g_ref[i];
     S.sig[i] = 0;
     S.size[i] = 0.f;
+    S.rbits[i] = 0;
   }
   for (int j = tid; j < WP; j += NT) {
-    S.urow[j] = -1;
+    S.urow[j] = NOROW;
     S.prow[j] = 0;
   }
   if (tid == 0) {
-    sc.maxabs = 0;
-    sc.status = PIPAMD_ST_RUN;
     sc.aux = 0;
+    sc.smaxbits = 0;
+    sc.pivi = BIG_I;
+    sc.flagor = 0;
+    sc.bad = 0;
   }
-  __syncthreads();
+  bsync<NW>();
   for (int i = tid; i < nligne; i += NT) {
     if (S.flag[i] & PIPAMD_F_UNIT)
-      S.urow[S.ref[i]] = i;
+      S.urow[S.ref[i]] = (u16)i;
     else
-      S.srow[S.ref[i]] = i;
+      S.srow[S.ref[i]] = (u16)i;
   }
-  __syncthreads();
-  // ---- one pass over the tableau: sign summaries, max |entry|, sort keys --
-  {
-    u64 mx = 0;
-    for (int s = wave; s < ni; s += NW) {
-      RowRegs<NCH> r;
-      int k = S.srow[s];
-      row_load<NCH>(r, vals + (size_t)s * W, ncolp, lane);
-      int sg = row_signature<NCH>(r, nvar, ncol, bigparm, -1, lane, mx);
-      if (tflags & PIPAMD_T_SORT) {
-        // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns
-        double d = (double)S.den[k], sz = 0;
-#pragma unroll
-        for (int c = 0; c < NCH; c++)
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            int j = c * 128 + 2 * lane + h;
-            if (j < nvar) {
-              int q = trunc_int_x86((double)r.v[c][h] / d);
-              double aq = (double)(q < 0 ? (int)(0u - (unsigned)q) : q);
-              sz = sz > aq ? sz : aq;
-            }
-          }
-        for (int o = 32; o; o >>= 1) {
-          double t = __shfl(sz, lane ^ o);
-          sz = sz > t ? sz : t;
-        }
-        if (lane == 0) S.size[k] = (float)sz;
-        if (lane == 0) S.lpiv[s] = (i64)__double_as_longlong(sz);  // exact double key for smax
-      }
-      if (lane == 0) S.sig[k] = sg;
+  bsync<NW>();
+  if (tflags & PIPAMD_T_STATE) {
+    // resumed job: the summaries were saved when it paused
+    for (int i = tid; i < nligne; i += NT) {
+      S.sig[i] = g_sig[i];
+      S.rbits[i] = g_rbits[i];
     }
-    mx = wave_max_u64(mx);
-    if (lane == 0) atomicMax(&sc.maxabs, mx);
-  }
-  __syncthreads();
-  if (tflags & PIPAMD_T_SORT) {
-    if (wave == 0) {
-      // smax over rows nvar..nligne-1 only (traiter.c:576-586)
-      double smax = 0;
-      for (int i = nvar + lane; i < nligne; i += 64)
-        if (!(S.flag[i] & PIPAMD_F_UNIT)) {
-          double t = __longlong_as_double(S.lpiv[S.ref[i]]);
-          smax = smax > t ? smax : t;
+    for (int e = tid; e < ni * NM; e += NT) S.nzm[e] = g_nzm[e];
+  } else
+  // ---- one pass over the tableau: sign summaries, bitmaps, max |entry|, sort keys
+  for (int s = wave; s < ni; s += NW) {
+    RowRegs<NCH> r;
+    const int k = S.srow[s];
+    row_load<NCH>(r, vals + (size_t)s * W, ncolp, lane);
+    // rows with a denominator other than 1 are conservatively treated as not yet reduced
+    row_publish<NCH>(r, S, k, s, nvar, ncol, bigparm, -1, S.den[k] == 1 ? SIG_RED : 0, lane);
+    if (tflags & PIPAMD_T_SORT) {
+      // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns
+      double d = (double)S.den[k], sz = 0;
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          int j = c * 128 + 2 * lane + h;
+          if (j < nvar) {
+            int q = trunc_int_x86((double)r.v[c][h] / d);
+            double aq = (double)(q < 0 ? (int)(0u - (unsigned)q) : q);
+            sz = sz > aq ? sz : aq;
+          }
         }
       for (int o = 32; o; o >>= 1) {
-        double t = __shfl(smax, lane ^ o);
-        smax = smax > t ? smax : t;
+        double t = __shfl(sz, lane ^ o);
+        sz = sz > t ? sz : t;
       }
-      sort_rows(S, nvar, nligne, 0.f, smax);
+      if (lane == 0) {
+        S.size[k] = (float)sz;
+        // smax is taken over rows nvar..nligne-1 only (traiter.c:576-586); sizes are >= 0,
+        // so their bit patterns order like the doubles
+        if (k >= nvar) atomicMax(&sc.smaxbits, (u64)__double_as_longlong(sz));
+      }
     }
-    __syncthreads();
-    for (int i = tid; i < nligne; i += NT)
-      if (!(S.flag[i] & PIPAMD_F_UNIT)) S.srow[S.ref[i]] = i;
-    tflags &= ~PIPAMD_T_SORT;
-    __syncthreads();
   }
+  bsync<NW>();
+  if (tflags & PIPAMD_T_SORT) {
+    if (wave == 0) sort_rows(S, nvar, nligne, __longlong_as_double((i64)sc.smaxbits));
+    bsync<NW>();
+    for (int i = tid; i < nligne; i += NT)
+      if (!(S.flag[i] & PIPAMD_F_UNIT)) S.srow[S.ref[i]] = (u16)i;
+    tflags &= ~PIPAMD_T_SORT;
+    bsync<NW>();
+  }
+  // chercher(Minus) for the first iteration; later ones get it from phase C
+  for (int i = tid; i < nligne; i += NT)
+    if (S.flag[i] & PIPAMD_F_MINUS) atomicMin(&sc.pivi, i);
+  bsync<NW>();
 
   int status = PIPAMD_ST_RUN;
+  PROF(0);
   for (int iter = 0;; iter++) {
     if (iter >= iter_limit) break;  // status stays RUN: the host relaunches
-    // ---------------- A: chercher(Minus), then exam_coef ------------------
-    if (tid == 0) {
-      sc.pivi = BIG_I;
-      sc.flagor = 0;
-    }
-    __syncthreads();
-    for (int i = tid; i < nligne; i += NT)
-      if (S.flag[i] & PIPAMD_F_MINUS) atomicMin(&sc.pivi, i);
-    __syncthreads();
     int pivi = sc.pivi;
     if (pivi == BIG_I) {
-      pivi = exam_rows(S, &sc, nligne, bigparm);
+      // -------------- exam_coef, then (if nothing is negative) integrer ---------
+      pivi = exam_rows<NW>(S, &sc, nligne, bigparm);
+      PROF(1);
       if (pivi == BIG_I) {
         if (nparm > 0) {
           for (int i = tid; i < nligne; i += NT)
             if (S.flag[i] & (PIPAMD_F_CRITIC | PIPAMD_F_UNKNOWN)) atomicOr(&sc.flagor, 1);
-          __syncthreads();
+          bsync<NW>();
           if (sc.flagor) {
             status = PIPAMD_ST_NEED_COMPA;
             break;
@@ -646,7 +780,7 @@ __global__ __launch_bounds__(NT) void pip_advance_kernel(PipJob *jobs, i64 *aren
           break;
         }
         if (tid == 0) sc.tmp = BIG_I;
-        __syncthreads();
+        bsync<NW>();
         for (int i = tid; i < nvar; i += NT) {
           i64 D = S.den[i];
           if (D == 1 || (S.flag[i] & PIPAMD_F_UNIT)) continue;
@@ -656,103 +790,136 @@ __global__ __launch_bounds__(NT) void pip_advance_kernel(PipJob *jobs, i64 *aren
             if (j != bigparm && fmod64(wneg(row[j]), D) != 0) ok = true;
           if (ok) atomicMin(&sc.tmp, i);
         }
-        __syncthreads();
-        int ci = sc.tmp;
+        bsync<NW>();
+        const int ci = sc.tmp;
         if (ci == BIG_I) {
           status = PIPAMD_ST_SOLUTION;
           break;
         }
-        // build the cut in the pivot-row buffer (integrer.c:357-386)
-        {
+        // wave 0 builds the cut in its registers (integrer.c:357-386) and appends it
+        if (wave == 0) {
           const i64 D = S.den[ci];
-          const i64 *row = vals + (size_t)S.ref[ci] * W;
-          int okv = 0, okp = 0;
-          for (int j = tid; j < WP; j += NT) {
-            i64 x = 0;
-            if (j < ncol) {
-              i64 v = row[j];
+          RowRegs<NCH> r;
+          row_load<NCH>(r, vals + (size_t)S.ref[ci] * W, ncolp, lane);
+          bool okv = false, okp = false;
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              int j = c * 128 + 2 * lane + h;
+              i64 v = r.v[c][h], x = 0;
               if (j < nvar) {
                 x = fmod64(v, D);
                 okv |= x > 0;
               } else if (j == nvar) {
                 x = wneg(fmod64(wneg(v), D));
-              } else if (j != bigparm) {
+              } else if (j < ncol && j != bigparm) {
                 x = wneg(fmod64(wneg(v), D));
                 okp |= x != 0;
               }
+              r.v[c][h] = x;
             }
-            S.prow[j] = x;
+          const bool any_v = __ballot(okv) != 0, any_p = __ballot(okp) != 0;
+          int verdict;
+          if (any_p)
+            verdict = PIPAMD_ST_NEED_PARMCUT;  // the host owns the context (find_parm/add_parm)
+          else if (!any_v)
+            verdict = PIPAMD_ST_NIL;  // integrer.c:482-485 case (b)
+          else if (tflags & PIPAMD_T_DEEPEST)
+            verdict = PIPAMD_ST_INTERNAL;  // deepest cut is not available on the device path
+          else if (ni >= Sl || nligne >= L)
+            verdict = PIPAMD_ST_CAPACITY;
+          else if (ni >= Smax || nligne >= Lmax)
+            verdict = -1;  // no room in this launch's LDS image: pause, the host relaunches with more
+          else {
+            verdict = PIPAMD_ST_RUN;
+            // append the cut as logical row nligne in slot ni (integrer.c:440-446)
+            row_store<NCH>(r, vals + (size_t)ni * W, ncolp, lane);
+            row_publish<NCH>(r, S, nligne, ni, nvar, ncol, bigparm, -1, 0, lane);
+            if (lane == 0) {
+              S.flag[nligne] = PIPAMD_F_MINUS;
+              S.den[nligne] = D;
+              S.ref[nligne] = (u16)ni;
+              S.srow[ni] = (u16)nligne;
+              S.size[nligne] = 0.f;
+            }
           }
-          if (okv) atomicOr(&sc.flagor, 2);
-          if (okp) atomicOr(&sc.flagor, 4);
-          __syncthreads();
-          int fo = sc.flagor;
-          if (fo & 4) {  // parametric cut: the host owns the context (find_parm/add_parm)
-            status = PIPAMD_ST_NEED_PARMCUT;
-            if (tid == 0) sc.aux = ci;
-            break;
+          if (lane == 0) {
+            sc.tmp2 = verdict;
+            sc.aux = ci;
           }
-          if (!(fo & 2)) {  // integrer.c:482-485 case (b)
-            status = PIPAMD_ST_NIL;
-            break;
-          }
-          if (tflags & PIPAMD_T_DEEPEST) {
-            status = PIPAMD_ST_INTERNAL;  // deepest cut is applied by the host path only
-            break;
-          }
-          if (ni >= Sl || nligne >= L) {
-            status = PIPAMD_ST_CAPACITY;
-            break;
-          }
-          // append the cut as logical row nligne in slot ni (integrer.c:440-446)
-          i64 *nrow = vals + (size_t)ni * W;
-          u64 mx = 0;
-          for (int j = tid; j < ncolp; j += NT) {
-            nrow[j] = S.prow[j];
-            u64 a = uabs64(S.prow[j]);
-            mx = a > mx ? a : mx;
-          }
-          mx = wave_max_u64(mx);
-          if (lane == 0) atomicMax(&sc.maxabs, mx);
-          if (tid == 0) {
-            S.flag[nligne] = PIPAMD_F_MINUS;
-            S.den[nligne] = D;
-            S.ref[nligne] = ni;
-            S.srow[ni] = nligne;
-            S.sig[nligne] = sign_code(S.prow[nvar]);  // parameters are all zero here
-            S.size[nligne] = 0.f;
-          }
-          pivi = nligne;
-          ni++;
-          nligne++;
-          ncut++;
-          __syncthreads();
         }
+        bsync<NW>();
+        if (sc.tmp2 != PIPAMD_ST_RUN) {
+          status = sc.tmp2 < 0 ? PIPAMD_ST_RUN : sc.tmp2;
+          break;
+        }
+        pivi = nligne;
+        ni++;
+        nligne++;
+        ncut++;
       }
+      PROF(2);
     }
-    // ---------------- C1: stage the pivot row ------------------------------
+    // ---------------- A (wave 0): pivot row, choisir_piv, work list ------------
     npiv++;
     const int pslot = S.ref[pivi];
-    {
-      const i64 *row = vals + (size_t)pslot * W;
-      for (int j = tid; j < WP; j += NT) S.prow[j] = j < ncol ? row[j] : 0;
-    }
-    __syncthreads();
-    // ---------------- C2: choisir_piv (wave 0) ------------------------------
     if (wave == 0) {
-      // exactness guard of the tournament: (max candidate a_j) * (max |entry|) < 2^62
+      RowRegs<NCH> pr;
+      row_load<NCH>(pr, vals + (size_t)pslot * W, ncolp, lane);
       u64 amax = 0;
-      for (int j = lane; j < nvar; j += 64) {
-        i64 a = S.prow[j];
-        if (a > 0 && (u64)a > amax) amax = (u64)a;
-      }
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          int j = c * 128 + 2 * lane + h;
+          if (j >= ncol) pr.v[c][h] = 0;
+          S.prow[j] = pr.v[c][h];
+          if (j < nvar && pr.v[c][h] > 0 && (u64)pr.v[c][h] > amax) amax = (u64)pr.v[c][h];
+        }
+      // exactness guard of the tournament: (max candidate a_j) * (max |entry|) < 2^62
       amax = wave_max_u64(amax);
-      u64 mx = sc.maxabs;
-      bool safe = amax == 0 || mx == 0 || (__umul64hi(amax, mx) == 0 && amax * mx < (1ull << 62));
-      int pj = safe ? choose_column<NCH>(S, vals, W, nvar, nligne, pivi, ncolp, &sc) : -2;
+      int mb = 0;
+      for (int i = lane; i < nligne; i += 64)
+        if (!(S.flag[i] & PIPAMD_F_UNIT) && S.rbits[i] > mb) mb = S.rbits[i];
+      for (int o = 32; o; o >>= 1) {
+        int t = __shfl(mb, lane ^ o);
+        mb = t > mb ? t : mb;
+      }
+      const bool safe = bitlen64(amax) + mb <= 62;
+      PROF(3);
+      int pj = safe ? choose_column<NCH>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc) : -2;
+      PROF(4);
+      if (pj >= 0) {
+        // slots the elimination has to rewrite: the recycled pivot slot plus every real row
+        // that is non-zero in column pj or not yet reduced
+        const int pe = ((pj >> 7) << 1) | (pj & 1), pl = (pj & 127) >> 1;
+        int base = 0;
+        for (int s0 = 0; s0 < ni; s0 += 64) {
+          const int s = s0 + lane;
+          bool need = false;
+          if (s < ni) {
+            if (s == pslot)
+              need = true;
+            else {
+              const int k = S.srow[s];
+              const bool nzb = (S.nzm[(size_t)s * NM + pe] >> pl) & 1;
+              if (nzb || !(S.sig[k] & SIG_RED))
+                need = true;
+              else
+                S.sig[k] &= ~0xC0;  // entry in the pivot column is 0: sign hint "zero"
+            }
+          }
+          const u64 m = __ballot(need);
+          if (need) S.work[base + __popcll(m & ((1ull << lane) - 1))] = (u16)s;
+          base += __popcll(m);
+        }
+        if (lane == 0) sc.nwork = base;
+      }
       if (lane == 0) sc.pivj = pj;
     }
-    __syncthreads();
+    bsync<NW>();
+    if (tid == 0) sc.pivi = BIG_I;  // every wave has read it by now; phase C refills it
     const int pivj = sc.pivj;
     if (pivj == -1) {  // traiter.c:782-785
       status = PIPAMD_ST_NIL;
@@ -762,14 +929,9 @@ __global__ __launch_bounds__(NT) void pip_advance_kernel(PipJob *jobs, i64 *aren
       status = PIPAMD_ST_RANGE;
       break;
     }
-    // ---------------- C3: pivot scalars + per-row multipliers ---------------
-    const i64 pivot = S.prow[pivj];
-    const i64 dpiv = S.den[pivi];
-    if (tid == 0) {
-      // determinant bookkeeping, traiter.c:394-446 (every thread keeps det[] in
-      // registers identically; thread 0 publishes the verdict)
-      sc.tmp = 0;
-    }
+    // pivot scalars + determinant bookkeeping, traiter.c:394-446 (uniform, every thread)
+    const i64 pivot = uni64(S.prow[pivj]);
+    const i64 dpiv = uni64(S.den[pivi]);
     {
       i64 d = gcd_i64(pivot, dpiv);
       i64 ppivot = cquo(pivot, d), dppiv = cquo(dpiv, d);
@@ -799,26 +961,23 @@ __global__ __launch_bounds__(NT) void pip_advance_kernel(PipJob *jobs, i64 *aren
         break;
       }
     }
-    for (int s = tid; s < ni; s += NT) {
-      if (s == pslot) continue;
-      int k = S.srow[s];
-      i64 foo = vals[(size_t)s * W + pivj];
-      i64 d = gcd_i64(pivot, foo);
-      i64 lp = cquo(pivot, d);
-      S.lpiv[s] = lp;
-      S.foo[s] = cquo(foo, d);
-      S.g0[s] = wmul(lp, S.den[k]);
-    }
     const int ku = S.urow[pivj];  // unit row of the entering column
-    if (tid == 0) sc.maxabs = 0;
-    __syncthreads();
-    // ---------------- C4: eliminate the pivot column from every real row ----
+    const int pred = S.sig[pivi] & SIG_RED;
+    const int pc = pivj >> 7, ph = pivj & 1, pl = (pivj & 127) >> 1;
+    PROF(5);
+    // ---------------- B: eliminate the pivot column (all waves) ----------------
     {
-      u64 mx = 0;
-      bool bad = false;
-      for (int s = wave; s < ni; s += NW) {
-        RowRegs<NCH> r;
+      const int nwork = sc.nwork;
+      nupd += nwork - 1;
+      // rows are double-buffered in registers: the next row's load is in flight while this one
+      // is being reduced
+      RowRegs<NCH> r, rn;
+      if (wave < nwork && S.work[wave] != pslot) row_load<NCH>(r, vals + (size_t)S.work[wave] * W, ncolp, lane);
+      for (int w = wave; w < nwork; w += NW) {
+        const int s = S.work[w];
         i64 *row = vals + (size_t)s * W;
+        if (w + NW < nwork && S.work[w + NW] != pslot)
+          row_load<NCH>(rn, vals + (size_t)S.work[w + NW] * W, ncolp, lane);
         if (s == pslot) {
           // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
 #pragma unroll
@@ -829,64 +988,80 @@ __global__ __launch_bounds__(NT) void pip_advance_kernel(PipJob *jobs, i64 *aren
               r.v[c][h] = (j == pivj) ? dpiv : wneg(S.prow[j]);
             }
           row_store<NCH>(r, row, ncolp, lane);
-          int sg = row_signature<NCH>(r, nvar, ncol, bigparm, pivj, lane, mx);
-          if (lane == 0) S.sig[ku] = sg;
+          row_publish<NCH>(r, S, ku, s, nvar, ncol, bigparm, pivj, pred, lane);
         } else {
-          int k = S.srow[s];
+          const int k = S.srow[s];
           i64 nd;
-          row_load<NCH>(r, row, ncolp, lane);
-          if (!update_row<NCH>(r, S.prow, pivj, S.lpiv[s], S.foo[s], dpiv, S.g0[s], lane, nd)) bad = true;
-          row_store<NCH>(r, row, ncolp, lane);
-          int sg = row_signature<NCH>(r, nvar, ncol, bigparm, pivj, lane, mx);
-          if (lane == 0) {
-            S.sig[k] = sg;
-            S.den[k] = nd;
+          // multipliers from the row's own pivot-column entry (traiter.c:470-476)
+          i64 foo = row_entry<NCH>(r, pc, ph, pl);
+          const i64 d = gcd_i64(pivot, foo);
+          const i64 lp = cquo(pivot, d);
+          foo = cquo(foo, d);
+          const i64 g0 = wmul(lp, uni64(S.den[k]));
+          if (!update_row<NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
+            if (lane == 0) sc.bad = 1;
           }
+          row_store<NCH>(r, row, ncolp, lane);
+          row_publish<NCH>(r, S, k, s, nvar, ncol, bigparm, pivj, SIG_RED, lane);
+          if (lane == 0) S.den[k] = nd;
         }
+        r = rn;
       }
-      mx = wave_max_u64(mx);
-      if (lane == 0) atomicMax(&sc.maxabs, mx);
-      if (bad && lane == 0) atomicOr(&sc.tmp, 1);
     }
-    __syncthreads();
-    if (sc.tmp) {
+    bsync<NW>();
+    PROF(6);
+    if (sc.bad) {
       status = PIPAMD_ST_OVERFLOW;
       break;
     }
-    // ---------------- C5: swap roles, refresh the sign hints -----------------
-    if (tid == 0) {
-      S.flag[ku] = PIPAMD_F_PLUS;
-      S.den[ku] = pivot;
-      S.ref[ku] = pslot;
-      S.srow[pslot] = ku;
-      S.flag[pivi] = PIPAMD_F_UNIT | PIPAMD_F_ZERO;
-      S.den[pivi] = 1;
-      S.ref[pivi] = pivj;
-      S.urow[pivj] = pivi;
-    }
-    __syncthreads();
-    for (int i = tid; i < nligne; i += NT) {  // traiter.c:518-529
+    // ---------------- C: swap roles, refresh the sign hints, next chercher ------
+    for (int i = tid; i < nligne; i += NT) {
+      if (i == pivi) {  // traiter.c:514-516
+        S.flag[i] = PIPAMD_F_UNIT | PIPAMD_F_ZERO;
+        S.den[i] = 1;
+        S.ref[i] = (u16)pivj;
+        S.urow[pivj] = (u16)i;
+        continue;
+      }
       int ff = S.flag[i];
-      if (ff & PIPAMD_F_UNIT) continue;
-      int ps = SIG_PIV(S.sig[i]);
-      int fff = ps == 1 ? PIPAMD_F_PLUS : (ps == 2 ? PIPAMD_F_MINUS : PIPAMD_F_ZERO);
+      if (i == ku) {  // traiter.c:503-513
+        ff = PIPAMD_F_PLUS;
+        S.den[i] = pivot;
+        S.ref[i] = (u16)pslot;
+        S.srow[pslot] = (u16)i;
+      } else if (ff & PIPAMD_F_UNIT)
+        continue;
+      // traiter.c:518-529
+      const int ps = SIG_PIV(S.sig[i]);
+      const int fff = ps == 1 ? PIPAMD_F_PLUS : (ps == 2 ? PIPAMD_F_MINUS : PIPAMD_F_ZERO);
       if (fff != PIPAMD_F_ZERO && fff != ff) {
         if (ff == PIPAMD_F_ZERO)
           ff = (fff == PIPAMD_F_MINUS) ? PIPAMD_F_UNKNOWN : fff;
         else
           ff = PIPAMD_F_UNKNOWN;
       }
-      S.flag[i] = ff;
+      S.flag[i] = (u8)ff;
+      if (ff & PIPAMD_F_MINUS) atomicMin(&sc.pivi, i);
     }
-    __syncthreads();
+    bsync<NW>();
+    PROF(7);
   }
 
   // ---- epilogue: publish the row tables, the header and (if any) the solution
-  __syncthreads();
+  bsync<NW>();
   for (int i = tid; i < nligne; i += NT) {
     g_den[i] = S.den[i];
     g_flag[i] = S.flag[i];
     g_ref[i] = S.ref[i];
+  }
+  if (status == PIPAMD_ST_RUN) {
+    // paused (pivot budget of this launch spent, or LDS image full): save the summaries
+    for (int i = tid; i < nligne; i += NT) {
+      g_sig[i] = S.sig[i];
+      g_rbits[i] = S.rbits[i];
+    }
+    for (int e = tid; e < ni * NM; e += NT) g_nzm[e] = S.nzm[e];
+    tflags |= PIPAMD_T_STATE;
   }
   if (status == PIPAMD_ST_SOLUTION) {
     // solution(), traiter.c:255-271: rows 0..nvar-1, parameters then constant
@@ -902,16 +1077,22 @@ __global__ __launch_bounds__(NT) void pip_advance_kernel(PipJob *jobs, i64 *aren
     for (int i = tid; i < nvar; i += NT) sol_den[i] = S.den[i];
   }
   if (tid == 0) {
+    u64 mb = 0;
+    for (int i = 0; i < nligne; i++)
+      if (!(S.flag[i] & PIPAMD_F_UNIT) && S.rbits[i] > mb) mb = S.rbits[i];
     J->ni = ni;
     J->npiv = npiv;
     J->ncut = ncut;
+    J->nupd = nupd;
     J->ldet = ldet;
     for (int i = 0; i < PIPAMD_MAXDET; i++) J->det[i] = det[i];
     J->tflags = tflags;
-    J->maxabs = sc.maxabs;
+    J->maxabs = mb;  // bit length of the largest entry
     J->aux = sc.aux;
     J->status = status;
   }
+  PROF(8);
+  PROF_FLUSH(prof);
 }
 
 // ---------------------------------------------------------------- batch load
@@ -951,6 +1132,7 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
     J->rows_off = base;
     J->vals_off = base + 2 * (int64_t)lay.L;
     J->sol_off = base + 2 * (int64_t)lay.L + (int64_t)lay.S * lay.W;
+    J->state_off = J->sol_off + lay.sol_words;
     J->nvar = lay.nvar;
     J->nparm = lay.nparm;
     J->ni = lay.ni;
@@ -963,6 +1145,7 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
     J->aux = 0;
     J->npiv = 0;
     J->ncut = 0;
+    J->nupd = 0;
     J->ldet = 1;
     J->det[0] = 1;
     J->det[1] = J->det[2] = J->det[3] = 0;
@@ -988,24 +1171,79 @@ __global__ void pip_batch_results_kernel(const PipJob *jobs, const i64 *arena, i
     for (int i = threadIdx.x; i < nvar; i += blockDim.x) sol_den[(size_t)b * nvar + i] = ok ? sn[nn + i] : 0;
 }
 
+// totals over a batch: [0] pivots [1] cuts [2] rows rewritten [3] jobs finished (solution or nil)
+__global__ void pip_batch_counters_kernel(const PipJob *jobs, int njobs, unsigned long long *out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= njobs) return;
+  const PipJob *J = &jobs[b];
+  atomicAdd(&out[0], (unsigned long long)J->npiv);
+  atomicAdd(&out[1], (unsigned long long)J->ncut);
+  atomicAdd(&out[2], (unsigned long long)J->nupd);
+  if (J->status == PIPAMD_ST_SOLUTION || J->status == PIPAMD_ST_NIL) atomicAdd(&out[3], 1ull);
+}
+
+// [0] jobs still PIPAMD_ST_RUN, [1] the largest current row count among them
+__global__ void pip_batch_running_kernel(const PipJob *jobs, int njobs, int *out2) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= njobs) return;
+  const PipJob *J = &jobs[b];
+  if (J->status == PIPAMD_ST_RUN) {
+    atomicAdd(&out2[0], 1);
+    atomicMax(&out2[1], J->ni);
+  }
+}
+
 // ------------------------------------------------------------------ launchers
-extern "C" hipError_t pipk_launch_advance(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
-                                          int iter_limit, hipStream_t stream) {
-  if (njobs <= 0) return hipSuccess;
+extern "C" hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, int *out2, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(out2, 0, 2 * sizeof(int), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(pip_batch_running_kernel, dim3((njobs + 255) / 256), dim3(256), 0, stream, jobs, njobs, out2);
+  return hipGetLastError();
+}
+
+extern "C" size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax) {
   const size_t WP = Wmax <= 128 ? 128 : (Wmax <= 256 ? 256 : 512);
-  size_t shm = sizeof(i64) * ((size_t)Lmax + WP + 3 * (size_t)Smax) +
-               sizeof(int) * (3 * (size_t)Lmax + Smax + WP) + sizeof(float) * (size_t)Lmax;
-  shm = (shm + 15) & ~(size_t)15;
-  dim3 grid(njobs), block(NT);
+  const size_t NM = WP / 64;
+  size_t shm = sizeof(i64) * ((size_t)Lmax + WP) + sizeof(u64) * (size_t)Smax * NM + sizeof(float) * (size_t)Lmax +
+               sizeof(u16) * (2 * (size_t)Lmax + 2 * (size_t)Smax + WP) + 2 * (size_t)Lmax;
+  return (shm + 15) & ~(size_t)15;
+}
+
+extern "C" hipError_t pipk_launch_batch_counters(const PipJob *jobs, int njobs, unsigned long long *out,
+                                                 hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(out, 0, 4 * sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(pip_batch_counters_kernel, dim3((njobs + 255) / 256), dim3(256), 0, stream, jobs, njobs, out);
+  return hipGetLastError();
+}
+
+template <int NCH, int NW>
+static void launch_advance_t(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
+                             unsigned long long *prof, size_t shm, hipStream_t stream) {
+  hipLaunchKernelGGL((pip_advance_kernel<NCH, NW>), dim3(njobs), dim3(64 * NW), shm, stream, jobs, arena, njobs, Lmax,
+                     Smax, Wmax, iter_limit, prof);
+}
+
+// waves_per_job: 1 = one wave64 per tableau (latency-bound sparse batches: more tableaux in
+// flight per CU), 4 = four waves share a tableau's rows (few, large tableaux).
+extern "C" hipError_t pipk_launch_advance(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
+                                          int iter_limit, int waves_per_job, unsigned long long *prof,
+                                          hipStream_t stream) {
+  if (njobs <= 0) return hipSuccess;
+  // LDS arrays are carved at 8/4/2/1-byte granularity in that order: keep Lmax, Smax multiples of 4
+  Lmax = (Lmax + 3) & ~3;
+  Smax = (Smax + 3) & ~3;
+  const size_t shm = pipk_advance_lds_bytes(Lmax, Smax, Wmax);
+  const bool one = waves_per_job == 1;
   if (Wmax <= 128) {
-    hipLaunchKernelGGL(pip_advance_kernel<1>, grid, block, shm, stream, jobs, arena, njobs, Lmax, Smax, Wmax,
-                       iter_limit);
+    if (one) launch_advance_t<1, 1>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
+    else launch_advance_t<1, 4>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
   } else if (Wmax <= 256) {
-    hipLaunchKernelGGL(pip_advance_kernel<2>, grid, block, shm, stream, jobs, arena, njobs, Lmax, Smax, Wmax,
-                       iter_limit);
+    if (one) launch_advance_t<2, 1>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
+    else launch_advance_t<2, 4>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
   } else if (Wmax <= 512) {
-    hipLaunchKernelGGL(pip_advance_kernel<4>, grid, block, shm, stream, jobs, arena, njobs, Lmax, Smax, Wmax,
-                       iter_limit);
+    if (one) launch_advance_t<4, 1>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
+    else launch_advance_t<4, 4>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
   } else
     return hipErrorInvalidValue;
   return hipGetLastError();

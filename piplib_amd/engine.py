@@ -25,6 +25,9 @@ def lib():
     """Load libpipamd.so (built by piplib_amd.build); raises if it is not there."""
     global _lib
     if _lib is None:
+        # torch first: its wheel bundles the HIP runtime; loading ours before it would put a
+        # second libamdhip64 in the process and torch would then see no GPU.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} missing: run `python -m piplib_amd.build` (HIP extension is mandatory)")
         L = C.CDLL(LIB_PATH)
@@ -36,9 +39,13 @@ def lib():
         L.pipamd_engine_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         L.pipamd_engine_destroy.argtypes = [C.c_void_p]
         L.pipamd_engine_set_iter_limit.argtypes = [C.c_void_p, C.c_int]
+        L.pipamd_engine_set_waves_per_job.argtypes = [C.c_void_p, C.c_int]
+        L.pipamd_engine_set_round_pivots.argtypes = [C.c_void_p, C.c_int]
+        L.pipamd_last_solve_launches.argtypes = [C.c_void_p]
         L.pipamd_batch_load.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p, C.c_void_p]
         L.pipamd_batch_solve.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p]
         L.pipamd_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc)] + [C.c_void_p] * 6
+        L.pipamd_batch_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p, C.c_void_p]
         L.pipamd_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.pipamd_solve_tableau.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                                         C.POINTER(C.c_void_p), C.POINTER(C.c_int),
@@ -67,6 +74,15 @@ class Engine:
     def set_iter_limit(self, n):
         _check(lib().pipamd_engine_set_iter_limit(self._h, int(n)))
 
+    def set_round_pivots(self, n):
+        _check(lib().pipamd_engine_set_round_pivots(self._h, int(n)))
+
+    def last_solve_launches(self):
+        return int(lib().pipamd_last_solve_launches(self._h))
+
+    def set_waves_per_job(self, n):
+        _check(lib().pipamd_engine_set_waves_per_job(self._h, int(n)))
+
     def __del__(self):
         try:
             self.close()
@@ -84,7 +100,7 @@ class Batch:
         B, ni, ncol = rows.shape
         assert ncol == nvar + nparm + 1
         if cap_cuts is None:
-            cap_cuts = min(3 * ni + 32, 768 - ni) if (tflags & T_INT) else 0
+            cap_cuts = min(ni + 64, 768 - ni) if (tflags & T_INT) else 0
         self.desc = BatchDesc(B, nvar, nparm, ni, bigparm, tflags, cap_cuts, cap_newparm)
         self.dev = torch.device("cuda", engine.device)
         self.rows = rows if (torch.is_tensor(rows) and rows.is_cuda) else torch.as_tensor(rows, dtype=torch.int64).to(self.dev)
@@ -114,6 +130,14 @@ class Batch:
                                           C.c_void_p(self.status.data_ptr()), C.c_void_p(self.pivots.data_ptr()),
                                           C.c_void_p(self.cuts.data_ptr()), C.c_void_p(self.sol_num.data_ptr()),
                                           C.c_void_p(self.sol_den.data_ptr()), self._stream()))
+
+    def counters(self):
+        """dict of batch totals (pivots, cuts, rows_rewritten, finished) -- synchronises."""
+        out = self.torch.zeros(4, dtype=self.torch.int64, device=self.dev)
+        _check(lib().pipamd_batch_counters(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc),
+                                           C.c_void_p(out.data_ptr()), self._stream()))
+        v = out.cpu().tolist()
+        return {"pivots": v[0], "cuts": v[1], "rows_rewritten": v[2], "finished": v[3]}
 
     def last_solve_ms(self):
         ms = C.c_float()

@@ -41,10 +41,25 @@ def lexmin_rows(rng, nvar, ni, nnz=4, cmax=5, x0max=9, slackmax=3, pneg=0.25):
     return np.concatenate([A, -b[:, None]], axis=1)
 
 
-def lexmin_batch(seed, batch, nvar, ni, **kw):
-    """(batch, ni, nvar+1) int64: non-parametric integer lexmin problems (nparm = 0)."""
+def lexmin_batch(seed, batch, nvar, ni, nnz=4, cmax=5, x0max=9, slackmax=3, pneg=0.25):
+    """(batch, ni, nvar+1) int64: non-parametric lexmin problems (nparm = 0), vectorised.
+
+    Same family as lexmin_rows (sparse rows, hidden feasible integer point); duplicate
+    column draws inside a row simply collapse, so a row has 1..nnz non-zeros."""
     rng = np.random.default_rng(seed)
-    return np.stack([lexmin_rows(rng, nvar, ni, **kw) for _ in range(batch)])
+    k = rng.integers(2, nnz + 1, size=(batch, ni))
+    cols = rng.integers(0, nvar, size=(batch, ni, nnz))
+    vals = rng.integers(1, cmax + 1, size=(batch, ni, nnz))
+    vals = np.where(rng.random((batch, ni, nnz)) < pneg, -vals, vals)
+    live = np.arange(nnz)[None, None, :] < k[..., None]
+    T = np.zeros((batch, ni, nvar + 1), dtype=np.int64)
+    A = T[:, :, :nvar]
+    bi, ii, _ = np.nonzero(live)
+    A[bi, ii, cols[live]] = vals[live]
+    x0 = rng.integers(0, x0max + 1, size=(batch, nvar))
+    slack = rng.integers(0, slackmax + 1, size=(batch, ni))
+    T[:, :, nvar] = slack - np.einsum("bij,bj->bi", A, x0)
+    return T
 
 
 def random_problems(seed, count, nvar, nparm, ni, nc, nq, cmax=4, bmax=12):

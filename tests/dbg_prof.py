@@ -1,0 +1,25 @@
+"""Diagnostic (not a test): per-phase cycle shares of pip_advance_kernel, -DPIP_PROFILE build."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from piplib_amd import engine as eng, synth
+eng.LIB_PATH = os.path.join(eng.HERE, "libpipamd_prof.so")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+rows = synth.lexmin_batch(1000, B, 127, 64)
+e = eng.Engine(0)
+if len(sys.argv) > 2: e.set_waves_per_job(int(sys.argv[2]))
+L = eng.lib()
+L.pipamd_debug_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+b = eng.Batch(e, rows, 127, 0, tflags=eng.T_INT)
+L.pipamd_debug_profile(e._h, 1, None)
+for it in range(2):
+    b.load(); b.solve()
+    out = (C.c_uint64 * 10)()
+    L.pipamd_debug_profile(e._h, 1, out)
+    ms = b.last_solve_ms()
+    v = np.array(list(out), dtype=np.float64)
+    c = b.counters()
+    names = ["entry", "exam", "integrer", "A prow+guard", "A column", "A worklist+det", "B update", "C flags", "epilogue", "-"]
+    print(f"kernel {ms:.2f} ms pivots {c['pivots']} rows_rewritten {c['rows_rewritten']} cuts {c['cuts']}")
+    for n, x in zip(names, v):
+        print(f"  {n:10s} {100*x/v.sum():5.1f}%  {x/c['pivots']:9.0f} cycles/pivot")
