@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=10000, help="tableaux per GPU")
     ap.add_argument("--waves", type=int, default=0, help="waves per tableau (0 = engine default)")
     ap.add_argument("--round", type=int, default=0, help="pivots per tableau per launch (0 = engine default)")
+    ap.add_argument("--no-dense", action="store_true", help="skip the row-skipping-off measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -78,20 +79,15 @@ def main():
     from piplib_amd import engine as eng
     from piplib_amd import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from piplib_amd import dist as pdist
+    rank, world, local = pdist.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    pdist.init("nccl", dev)  # nccl == RCCL on ROCm
 
-    rows_h = synth.lexmin_batch(1000 + rank, args.batch, NVAR, NI)
+    rows_h = synth.lexmin_batch(pdist.shard_seed(1000, rank), args.batch, NVAR, NI)
     e = eng.Engine(local)
     if args.waves:
         e.set_waves_per_job(args.waves)
@@ -101,8 +97,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        pdist.barrier()
         torch.cuda.synchronize(dev)
 
     def step():
@@ -129,20 +124,52 @@ def main():
     cuts = int(b.cuts.sum().item())
     solved = int(((st == eng.ST_SOLUTION) | (st == eng.ST_NIL)).sum())
 
-    tot = torch.tensor([piv, args.batch, solved, cuts], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tot = tot.cpu().numpy()
-    dt_max = float(tmax.item())
+    rowsw = b.counters()["rows_rewritten"]
+    tot, dt_max = pdist.gather_totals([piv, args.batch, solved, cuts, rowsw], dt, dev)
+
+    # Same workload once more with row skipping off: every real row is read and written on
+    # every pivot, which is the reference's access pattern (traiter.c:467-502) and the regime
+    # in which the row-update path is HBM-bound.  Reported beside the main number.
+    dense = None
+    if rank == 0 and not args.no_dense:
+        bd = eng.Batch(e, b.rows, NVAR, NPARM, tflags=eng.T_INT | eng.T_NOSKIP)
+        dms = []
+        for i in range(3):
+            bd.load()
+            bd.solve()
+            if i:
+                dms.append(bd.last_solve_ms())
+        cd = bd.counters()
+        dk = float(np.mean(dms))
+        dbytes = bd.pivot_bytes() * cd["pivots"]
+        dense = {"bound": "hbm", "achieved": dbytes / (dk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": dbytes / (dk * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": dk, "pivots": cd["pivots"],
+                 "algorithmic_bytes_per_pivot": bd.pivot_bytes(),
+                 "note": "row skipping disabled (PIPAMD_T_NOSKIP): 2*ni*ncol*8 bytes per pivot, lower bound "
+                         "(cut rows add to it)"}
+        del bd
 
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
         piv_per_step = float(tot[0])
         k_ms = float(np.mean(kernel_ms))
-        algo_bytes = b.pivot_bytes() * piv  # this rank's launch
+        # Algorithmic HBM bytes of one pivot of THIS algorithm (DESIGN.md "Roofline"): read the
+        # pivot row, write the row that replaces the entering unit row, read+write every row that
+        # actually changes (counted by the kernel) -- rows with a zero multiplier keep their bits.
+        ncol = NVAR + NPARM + 1
+        rows_rw = float(tot[4]) / max(1.0, float(world))  # this rank's share is what its launch moved
+        piv_rank = piv
+        algo_bytes = 8.0 * ncol * (2.0 * b.counters()["rows_rewritten"] + 2.0 * piv_rank)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+        if os.path.exists(tp):
+            try:
+                t = json.load(open(tp))
+                if t.get("batch_per_gpu") == args.batch:
+                    traffic = t["hbm_bytes_per_step"]
+            except Exception:
+                traffic = None
         out = {
             "metric": "pivots/sec (batched 64x128 int64 tableaux, integer solve with Gomory cuts)",
             "value": piv_per_step / (ms_step * 1e-3),
@@ -163,21 +190,26 @@ def main():
             "pivots_per_step": piv_per_step,
             "cuts_per_step": float(tot[3]),
             "finished_fraction": float(tot[2]) / float(tot[1]),
+            "rows_rewritten_per_pivot": float(tot[4]) / max(1.0, piv_per_step),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pip_advance_kernel", "kernel_ms": k_ms,
                          "launches_per_step": e.last_solve_launches(),
-                         "algorithmic_bytes_per_pivot": b.pivot_bytes()},
+                         "algorithmic_bytes_per_step": algo_bytes,
+                         "dense_equivalent_GBps": b.pivot_bytes() * piv_rank / (k_ms * 1e-3) / 1e9,
+                         "note": "sparse workload: ~2.7 of ~80 rows change per pivot, so the pivot loop is "
+                                 "latency/issue-bound, not HBM-bound; see roofline_dense_mode for the "
+                                 "HBM-bound regime of the same kernel"},
         }
+        if dense:
+            out["roofline_dense_mode"] = dense
         if not args.no_cpu:
             cb = cpu_baseline(rows_h, 16)
             if cb:
                 out["cpu_baseline"] = cb
                 out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    pdist.finish()
 
 
 if __name__ == "__main__":

@@ -47,6 +47,8 @@ extern "C" {
 /* engine-only flags */
 #define PIPAMD_T_SORT 256    /* rows not yet sorted (tab_sort_rows, traiter.c:556) */
 #define PIPAMD_T_DEEPEST 512 /* deepest-cut option (integrer.c:417-438) */
+#define PIPAMD_T_NOSKIP 2048 /* measurement aid: rewrite every real row on every pivot, as the
+                               reference's loop does (traiter.c:467-502); results are identical */
 #define PIPAMD_T_STATE 1024  /* a paused job's LDS summaries are saved in its state block */
 
 /* ---- per-problem status written by the engine ---- */
@@ -131,7 +133,7 @@ size_t pipamd_pivot_bytes(const pipamd_batch_desc *d);
  * measured with HIP events on the launch stream, and the number of those launches. */
 int pipamd_last_solve_ms(pipamd_engine *e, float *ms);
 int pipamd_last_solve_launches(pipamd_engine *e);
-/* Pivots per tableau per launch (default 16): pipamd_batch_solve runs the pivot loop in
+/* Pivots per tableau per launch (default 48): pipamd_batch_solve runs the pivot loop in
  * rounds so that every CU stays busy although tableaux need different numbers of pivots. */
 int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots);
 

@@ -139,7 +139,7 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
   }
   int running = lay.batch, max_ni = lay.ni;
   e->nlaunch = 0;
-  const int K = e->round_pivots > 0 ? e->round_pivots : 16;
+  const int K = e->round_pivots > 0 ? e->round_pivots : 48;
   while (running > 0) {
     if (e->nlaunch >= PIPAMD_MAX_ROUNDS) {
       pipamd_set_error("batch_solve: more than %d rounds", PIPAMD_MAX_ROUNDS);

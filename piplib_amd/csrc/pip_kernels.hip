@@ -167,6 +167,7 @@ __device__ __forceinline__ void bsync() {
 #define SIG_BIG(s) (((s) >> 4) & 3)
 #define SIG_PIV(s) (((s) >> 6) & 3)
 #define SIG_RED 256  // gcd(row, denominator) is known to be 1 (the row needs no reduction)
+#define UNITBIT 0x8000
 
 // Optional phase profile (diagnostic build only: -DPIP_PROFILE; never shipped/timed).
 #ifdef PIP_PROFILE
@@ -188,26 +189,31 @@ __device__ __forceinline__ void bsync() {
 #define PROF_FLUSH(buf)
 #endif
 
-// LDS image of one job.  L = logical rows, S = row slots, WP = NCH*128 columns,
-// NM = 2*NCH mask words per row.  Column j of a row is owned by lane (j%128)/2 of
-// the wave that holds the row, register (c = j/128, h = j&1); a row's non-zero
-// bitmap uses the same geometry: word 2c+h, bit (j%128)/2.
+// LDS image of one job.  L = logical rows, S = row slots (real rows), WP = NCH*128 columns,
+// NM = 2*NCH mask words per row.  Column j of a row is owned by lane (j%128)/2 of the wave
+// that holds the row, register (c = j/128, h = j&1); a row's non-zero bitmap uses the same
+// geometry: word 2c+h, bit (j%128)/2.  Everything that only real rows have is indexed by
+// slot, so the per-pivot loops run over the real rows only.
 struct Shared {
-  i64 *den;     // [L]  denominators by logical row
+  i64 *den;     // [S]  denominator of the row in slot s
   i64 *prow;    // [WP] pivot row (zero beyond ncol)
-  u64 *nzm;     // [S][NM] non-zero bitmap of each slot
-  float *size;  // [L]  tab_sort_rows key (entry only)
-  u16 *ref;     // [L]  slot (real row) or unit column
-  u16 *sig;     // [L]  sign summary
+  u64 *nzm;     // [S][NM] non-zero bitmap
+  float *size;  // [S]  tab_sort_rows key (entry only)
+  u16 *sig;     // [S]  sign summary
   u16 *srow;    // [S]  slot -> logical row
   u16 *work;    // [S]  slots the current pivot rewrites
+  u16 *ref;     // [L]  logical row -> slot, or UNITBIT | column for a unit row
   u16 *urow;    // [WP] unknown column -> logical row of its unit row
-  u8 *flag;     // [L]
-  u8 *rbits;    // [L]  bit length of the row's max |entry|
+  u8 *fl;       // [S]  flag of the row in slot s (Plus/Minus/Zero/Critic/Unknown)
+  u8 *nf;       // [S]  flag exam_coef would give an Unknown row
+  u8 *rcls;     // [S]  magnitude class of the row's largest entry (see CLS_BITS)
+  u8 *uflag;    // [L]  flag of a unit row (Unit or Unit|Zero)
 };
+// magnitude classes: every entry of a class-c row is below 2^CLS_BITS[c]
+__device__ __forceinline__ int cls_bits(int c) { return c == 0 ? 15 : (c == 1 ? 31 : (c == 2 ? 47 : 64)); }
 
 struct Scalars {
-  int pivi, pivj, tmp, tmp2, aux;
+  int pivi, pivi2, pivj, tmp, tmp2, aux;
   int flagor, nwork, bad;
   u64 smaxbits;
 };
@@ -247,11 +253,11 @@ __device__ __forceinline__ void row_store(const RowRegs<NCH> &r, i64 *row, int n
   }
 }
 
-// Sign summary, non-zero bitmap and max|entry| of a row held in registers
-// (wave-collective).  Lane 0 publishes them for logical row k / slot s.
+// Sign summary, non-zero bitmap and magnitude class of a row held in registers
+// (wave-collective).  Lane 0 publishes them for slot s.
 template <int NCH>
-__device__ __forceinline__ void row_publish(const RowRegs<NCH> &r, const Shared &S, int k, int s, int nvar, int ncol,
-                                            int bigparm, int pivj, int extra_sig, int lane) {
+__device__ __forceinline__ void row_publish(const RowRegs<NCH> &r, const Shared &S, int s, int nvar, int ncol,
+                                            int bigparm, int pivj, int extra_sig, bool has_parm, int lane) {
   int cs = 0, bs = 0, ps = 0;
   bool ppos = false, pneg = false;
   u64 mx = 0;
@@ -262,26 +268,29 @@ __device__ __forceinline__ void row_publish(const RowRegs<NCH> &r, const Shared 
     for (int h = 0; h < 2; h++) {
       int j = c * 128 + 2 * lane + h;
       i64 z = r.v[c][h];
-      u64 a = uabs64(z);
-      mx = a > mx ? a : mx;
+      mx |= uabs64(z);
       if (j == nvar) cs = sign_code(z);
-      if (j == bigparm) bs = sign_code(z);
       if (j == pivj) ps = sign_code(z);
-      if (j > nvar && j < ncol) {
-        ppos |= z > 0;
-        pneg |= z < 0;
+      if (has_parm) {
+        if (j == bigparm) bs = sign_code(z);
+        if (j > nvar && j < ncol) {
+          ppos |= z > 0;
+          pneg |= z < 0;
+        }
       }
       nz[2 * c + h] = __ballot(z != 0);
     }
   int sig = extra_sig;
   sig |= (__ballot(cs == 1) ? 1 : 0) | (__ballot(cs == 2) ? 2 : 0);
-  sig |= (__ballot(ppos) ? 4 : 0) | (__ballot(pneg) ? 8 : 0);
-  sig |= (__ballot(bs == 1) ? 16 : 0) | (__ballot(bs == 2) ? 32 : 0);
   sig |= (__ballot(ps == 1) ? 64 : 0) | (__ballot(ps == 2) ? 128 : 0);
-  mx = wave_max_u64(mx);
+  if (has_parm) {
+    sig |= (__ballot(ppos) ? 4 : 0) | (__ballot(pneg) ? 8 : 0);
+    sig |= (__ballot(bs == 1) ? 16 : 0) | (__ballot(bs == 2) ? 32 : 0);
+  }
+  const int cls = __ballot((mx >> 47) != 0) ? 3 : (__ballot((mx >> 31) != 0) ? 2 : (__ballot((mx >> 15) != 0) ? 1 : 0));
   if (lane == 0) {
-    S.sig[k] = (u16)sig;
-    S.rbits[k] = (u8)bitlen64(mx);
+    S.sig[s] = (u16)sig;
+    S.rcls[s] = (u8)cls;
 #pragma unroll
     for (int e = 0; e < 2 * NCH; e++) S.nzm[(size_t)s * (2 * NCH) + e] = nz[e];
   }
@@ -307,8 +316,7 @@ __device__ __forceinline__ bool update_row(RowRegs<NCH> &r, const i64 *prow, int
       i64 z = wsub(wmul(r.v[c][h], lpiv), wmul(q, foo));
       if (j == pivj) z = wmul(dpiv, foo);
       r.v[c][h] = z;
-      u64 a = uabs64(z);
-      mx = a > mx ? a : mx;
+      mx |= uabs64(z);
     }
   newden = g0;
   if (g0 == 1) return true;
@@ -351,55 +359,54 @@ __device__ __forceinline__ bool update_row(RowRegs<NCH> &r, const i64 *prow, int
   return true;
 }
 
+// flag exam_coef (traiter.c:121-154) gives an Unknown row, from its sign summary
+__device__ __forceinline__ int exam_class(int sg) {
+  const int fc = SIG_CONST(sg) == 1 ? PIPAMD_F_PLUS : (SIG_CONST(sg) == 2 ? PIPAMD_F_MINUS : PIPAMD_F_ZERO);
+  const int pp = SIG_PPOS(sg), pn = SIG_PNEG(sg);
+  if (pp && pn) return PIPAMD_F_UNKNOWN;
+  if (pp) return (fc == PIPAMD_F_MINUS) ? PIPAMD_F_UNKNOWN : PIPAMD_F_PLUS;
+  if (pn) return (fc != PIPAMD_F_MINUS) ? PIPAMD_F_UNKNOWN : PIPAMD_F_MINUS;
+  return fc;
+}
+
 // ------------------------------------------------------------------ exam_coef
-// traiter.c:101-159 from the LDS sign summaries.  Block-collective; returns the
-// first row proven negative or BIG_I.
+// traiter.c:101-159, general form (used when there is a big parameter).  Block-collective;
+// returns the first row proven negative or BIG_I.  Rows are visited in logical order, which
+// for the slot-indexed tables means "compare srow[s]".
 template <int NW>
-__device__ int exam_rows(const Shared &S, Scalars *sc, int nligne, int bigparm) {
+__device__ int exam_rows(const Shared &S, Scalars *sc, int ni) {
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
-  u8 *nf = (u8 *)S.size;  // the sort keys are dead after entry: reuse them for the tentative flags
-  if (bigparm >= 0) {
-    if (tid == 0) sc->tmp = BIG_I;
-    bsync<NW>();
-    for (int i = tid; i < nligne; i += NT)
-      if (S.flag[i] == PIPAMD_F_UNKNOWN && SIG_BIG(S.sig[i]) == 2) atomicMin(&sc->tmp, i);
-    bsync<NW>();
-    int i1 = sc->tmp;
-    for (int i = tid; i < nligne; i += NT)
-      if (S.flag[i] == PIPAMD_F_UNKNOWN) {
-        if (i == i1)
-          S.flag[i] = PIPAMD_F_MINUS;
-        else if (i < i1 && SIG_BIG(S.sig[i]) == 1)
-          S.flag[i] = PIPAMD_F_PLUS;
-      }
-    bsync<NW>();
-    if (i1 != BIG_I) return i1;
-  }
   if (tid == 0) sc->tmp = BIG_I;
   bsync<NW>();
-  for (int i = tid; i < nligne; i += NT) {
-    int f = 0;
-    if (S.flag[i] == PIPAMD_F_UNKNOWN) {
-      int sg = S.sig[i];
-      int fc = SIG_CONST(sg) == 1 ? PIPAMD_F_PLUS : (SIG_CONST(sg) == 2 ? PIPAMD_F_MINUS : PIPAMD_F_ZERO);
-      int pp = SIG_PPOS(sg), pn = SIG_PNEG(sg);
-      if (pp && pn)
-        f = PIPAMD_F_UNKNOWN;
-      else if (pp)
-        f = (fc == PIPAMD_F_MINUS) ? PIPAMD_F_UNKNOWN : PIPAMD_F_PLUS;
-      else if (pn)
-        f = (fc != PIPAMD_F_MINUS) ? PIPAMD_F_UNKNOWN : PIPAMD_F_MINUS;
-      else
-        f = fc;
-      if (f == PIPAMD_F_MINUS) atomicMin(&sc->tmp, i);
+  for (int s = tid; s < ni; s += NT)
+    if (S.fl[s] == PIPAMD_F_UNKNOWN && SIG_BIG(S.sig[s]) == 2) atomicMin(&sc->tmp, (int)S.srow[s]);
+  bsync<NW>();
+  const int i1 = sc->tmp;
+  for (int s = tid; s < ni; s += NT)
+    if (S.fl[s] == PIPAMD_F_UNKNOWN) {
+      const int k = S.srow[s];
+      if (k == i1)
+        S.fl[s] = PIPAMD_F_MINUS;
+      else if (k < i1 && SIG_BIG(S.sig[s]) == 1)
+        S.fl[s] = PIPAMD_F_PLUS;
     }
-    nf[i] = (u8)f;
+  bsync<NW>();
+  if (i1 != BIG_I) return i1;
+  if (tid == 0) sc->tmp = BIG_I;
+  bsync<NW>();
+  for (int s = tid; s < ni; s += NT) {
+    int f = 0;
+    if (S.fl[s] == PIPAMD_F_UNKNOWN) {
+      f = exam_class(S.sig[s]);
+      if (f == PIPAMD_F_MINUS) atomicMin(&sc->tmp, (int)S.srow[s]);
+    }
+    S.nf[s] = (u8)f;
   }
   bsync<NW>();
-  int i2 = sc->tmp;
-  for (int i = tid; i < nligne; i += NT)
-    if (nf[i] && i <= i2) S.flag[i] = nf[i];
+  const int i2 = sc->tmp;
+  for (int s = tid; s < ni; s += NT)
+    if (S.nf[s] && (int)S.srow[s] <= i2) S.fl[s] = S.nf[s];
   bsync<NW>();
   return i2;
 }
@@ -414,7 +421,7 @@ __device__ int exam_rows(const Shared &S, Scalars *sc, int nligne, int bigparm) 
 //   * a real row keeps the columns with minimal v[k][j]/a_j (exact
 //     cross-multiplication, ties kept); a real row that is zero in every tied
 //     column cannot separate them, so it is skipped on its LDS bitmap alone;
-// and stop when one column is left.  Executed by wave 0 only; `a` holds the
+// and stop when one column is left.  Executed by wave 0 only; `prow` holds the
 // pivot row in the wave's lane geometry.
 // Exact while (max a_j) * (max |entry|) < 2^62, which the caller guarantees.
 template <int NCH>
@@ -442,12 +449,15 @@ __device__ int choose_column(const Shared &S, const RowRegs<NCH> &prow, const i6
   for (int k0 = 0; k0 < nligne && count > 1; k0 += 64) {
     const int k = k0 + lane;
     bool rel = false;
-    if (k < nligne && k != pivi && !(S.flag[k] & PIPAMD_F_UNIT)) {
-      const u64 *m = S.nzm + (size_t)S.ref[k] * NM;
-      u64 x = 0;
+    if (k < nligne && k != pivi) {
+      const int rf = S.ref[k];
+      if (!(rf & UNITBIT)) {
+        const u64 *m = S.nzm + (size_t)rf * NM;
+        u64 x = 0;
 #pragma unroll
-      for (int e = 0; e < NM; e++) x |= m[e] & cm[e];
-      rel = x != 0;
+        for (int e = 0; e < NM; e++) x |= m[e] & cm[e];
+        rel = x != 0;
+      }
     }
     u64 relmask = __ballot(rel);
     while (relmask && count > 1) {
@@ -549,16 +559,18 @@ last_unit_wins:
 
 // ------------------------------------------------------------ tab_sort_rows
 // traiter.c:591-614: selection sort of the real rows nvar..nligne-1 by `size`
-// (first minimum strictly below the running bound, swap into place).  Wave 0.
+// (first minimum strictly below the running bound, swap into place).  With
+// slot-indexed row data a swap of two logical rows is a swap of their slots.  Wave 0.
 __device__ void sort_rows(const Shared &S, int nvar, int nligne, double smax) {
   const int lane = threadIdx.x & 63;
   for (int i = nvar; i < nligne; i++) {
-    if (S.flag[i] & PIPAMD_F_UNIT) continue;
+    if (S.ref[i] & UNITBIT) continue;
     float best = 0;
     int bj = BIG_I;
     for (int j = i + lane; j < nligne; j += 64) {
-      if (S.flag[j] & PIPAMD_F_UNIT) continue;
-      float sj = S.size[j];
+      const int rf = S.ref[j];
+      if (rf & UNITBIT) continue;
+      float sj = S.size[rf];
       if (!((double)sj < smax)) continue;
       if (bj == BIG_I || sj < best) {
         best = sj;
@@ -575,22 +587,9 @@ __device__ void sort_rows(const Shared &S, int nvar, int nligne, double smax) {
     }
     int pv = (bj == BIG_I) ? i : bj;
     if (pv != i && lane == 0) {
-      u8 tf = S.flag[pv], tb = S.rbits[pv];
-      u16 tr = S.ref[pv], tg = S.sig[pv];
-      i64 td = S.den[pv];
-      float ts = S.size[pv];
-      S.flag[pv] = S.flag[i];
-      S.rbits[pv] = S.rbits[i];
+      u16 t = S.ref[pv];
       S.ref[pv] = S.ref[i];
-      S.sig[pv] = S.sig[i];
-      S.den[pv] = S.den[i];
-      S.size[pv] = S.size[i];
-      S.flag[i] = tf;
-      S.rbits[i] = tb;
-      S.ref[i] = tr;
-      S.sig[i] = tg;
-      S.den[i] = td;
-      S.size[i] = ts;
+      S.ref[i] = t;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -602,7 +601,7 @@ __device__ __forceinline__ int trunc_int_x86(double t) {
   return (int)t;
 }
 
-// select the register that holds column pivj (uniform c,h) and broadcast it from its owner lane
+// select the register that holds column pivj (uniform c,h) and read it from its owner lane
 template <int NCH>
 __device__ __forceinline__ i64 row_entry(const RowRegs<NCH> &r, int pc, int ph, int pl) {
   i64 mine = 0;
@@ -634,20 +633,23 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
   Shared S;
   {
     unsigned char *p = smem;
-    S.den = (i64 *)p;    p += sizeof(i64) * Lmax;
+    S.den = (i64 *)p;    p += sizeof(i64) * Smax;
     S.prow = (i64 *)p;   p += sizeof(i64) * WP;
     S.nzm = (u64 *)p;    p += sizeof(u64) * (size_t)Smax * NM;
-    S.size = (float *)p; p += sizeof(float) * Lmax;
-    S.ref = (u16 *)p;    p += sizeof(u16) * Lmax;
-    S.sig = (u16 *)p;    p += sizeof(u16) * Lmax;
+    S.size = (float *)p; p += sizeof(float) * Smax;
+    S.sig = (u16 *)p;    p += sizeof(u16) * Smax;
     S.srow = (u16 *)p;   p += sizeof(u16) * Smax;
     S.work = (u16 *)p;   p += sizeof(u16) * Smax;
+    S.ref = (u16 *)p;    p += sizeof(u16) * Lmax;
     S.urow = (u16 *)p;   p += sizeof(u16) * WP;
-    S.flag = (u8 *)p;    p += Lmax;
-    S.rbits = (u8 *)p;
+    S.fl = (u8 *)p;      p += Smax;
+    S.nf = (u8 *)p;      p += Smax;
+    S.rcls = (u8 *)p;    p += Smax;
+    S.uflag = (u8 *)p;
   }
 
   const int nvar = J->nvar, nparm = J->nparm, bigparm = J->bigparm;
+  const bool has_parm = nparm > 0;
   int tflags = J->tflags;
   int ni = J->ni;
   const int L = J->L, Sl = J->S, W = J->W;
@@ -663,20 +665,12 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
   i64 det[PIPAMD_MAXDET];
   for (int i = 0; i < PIPAMD_MAXDET; i++) det[i] = J->det[i];
   if (ni > Smax || nligne > Lmax) return;  // this launch's LDS image is too small: stay RUN for a larger one
-  // saved LDS state of a paused job (bitmaps, sign summaries, magnitudes)
+  // saved LDS state of a paused job (bitmaps, sign summaries, magnitude classes)
   u64 *g_nzm = (u64 *)(arena + J->state_off);
   u16 *g_sig = (u16 *)(g_nzm + (size_t)Sl * NM);
-  u8 *g_rbits = (u8 *)(g_sig + L);
+  u8 *g_rcls = (u8 *)(g_sig + Sl);
 
   // ---- stage the row tables in LDS -------------------------------------
-  for (int i = tid; i < nligne; i += NT) {
-    S.den[i] = g_den[i];
-    S.flag[i] = (u8)g_flag[i];
-    S.ref[i] = (u16)g_ref[i];
-    S.sig[i] = 0;
-    S.size[i] = 0.f;
-    S.rbits[i] = 0;
-  }
   for (int j = tid; j < WP; j += NT) {
     S.urow[j] = NOROW;
     S.prow[j] = 0;
@@ -685,55 +679,66 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     sc.aux = 0;
     sc.smaxbits = 0;
     sc.pivi = BIG_I;
+    sc.pivi2 = BIG_I;
     sc.flagor = 0;
     sc.bad = 0;
   }
   bsync<NW>();
   for (int i = tid; i < nligne; i += NT) {
-    if (S.flag[i] & PIPAMD_F_UNIT)
-      S.urow[S.ref[i]] = (u16)i;
-    else
-      S.srow[S.ref[i]] = (u16)i;
+    const int f = g_flag[i], rf = g_ref[i];
+    if (f & PIPAMD_F_UNIT) {
+      S.ref[i] = (u16)(UNITBIT | rf);
+      S.uflag[i] = (u8)f;
+      S.urow[rf] = (u16)i;
+    } else {
+      S.ref[i] = (u16)rf;
+      S.uflag[i] = 0;
+      S.srow[rf] = (u16)i;
+      S.fl[rf] = (u8)f;
+      S.den[rf] = g_den[i];
+      S.size[rf] = 0.f;
+      S.nf[rf] = 0;
+    }
   }
   bsync<NW>();
   if (tflags & PIPAMD_T_STATE) {
     // resumed job: the summaries were saved when it paused
-    for (int i = tid; i < nligne; i += NT) {
-      S.sig[i] = g_sig[i];
-      S.rbits[i] = g_rbits[i];
+    for (int s = tid; s < ni; s += NT) {
+      S.sig[s] = g_sig[s];
+      S.rcls[s] = g_rcls[s];
     }
     for (int e = tid; e < ni * NM; e += NT) S.nzm[e] = g_nzm[e];
-  } else
-  // ---- one pass over the tableau: sign summaries, bitmaps, max |entry|, sort keys
-  for (int s = wave; s < ni; s += NW) {
-    RowRegs<NCH> r;
-    const int k = S.srow[s];
-    row_load<NCH>(r, vals + (size_t)s * W, ncolp, lane);
-    // rows with a denominator other than 1 are conservatively treated as not yet reduced
-    row_publish<NCH>(r, S, k, s, nvar, ncol, bigparm, -1, S.den[k] == 1 ? SIG_RED : 0, lane);
-    if (tflags & PIPAMD_T_SORT) {
-      // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns
-      double d = (double)S.den[k], sz = 0;
+  } else {
+    // one pass over the tableau: sign summaries, bitmaps, magnitudes, sort keys
+    for (int s = wave; s < ni; s += NW) {
+      RowRegs<NCH> r;
+      row_load<NCH>(r, vals + (size_t)s * W, ncolp, lane);
+      // rows with a denominator other than 1 are conservatively treated as not yet reduced
+      row_publish<NCH>(r, S, s, nvar, ncol, bigparm, -1, S.den[s] == 1 ? SIG_RED : 0, has_parm, lane);
+      if (tflags & PIPAMD_T_SORT) {
+        // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns
+        double d = (double)S.den[s], sz = 0;
 #pragma unroll
-      for (int c = 0; c < NCH; c++)
+        for (int c = 0; c < NCH; c++)
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          int j = c * 128 + 2 * lane + h;
-          if (j < nvar) {
-            int q = trunc_int_x86((double)r.v[c][h] / d);
-            double aq = (double)(q < 0 ? (int)(0u - (unsigned)q) : q);
-            sz = sz > aq ? sz : aq;
+          for (int h = 0; h < 2; h++) {
+            int j = c * 128 + 2 * lane + h;
+            if (j < nvar) {
+              int q = trunc_int_x86((double)r.v[c][h] / d);
+              double aq = (double)(q < 0 ? (int)(0u - (unsigned)q) : q);
+              sz = sz > aq ? sz : aq;
+            }
           }
+        for (int o = 32; o; o >>= 1) {
+          double t = __shfl(sz, lane ^ o);
+          sz = sz > t ? sz : t;
         }
-      for (int o = 32; o; o >>= 1) {
-        double t = __shfl(sz, lane ^ o);
-        sz = sz > t ? sz : t;
-      }
-      if (lane == 0) {
-        S.size[k] = (float)sz;
-        // smax is taken over rows nvar..nligne-1 only (traiter.c:576-586); sizes are >= 0,
-        // so their bit patterns order like the doubles
-        if (k >= nvar) atomicMax(&sc.smaxbits, (u64)__double_as_longlong(sz));
+        if (lane == 0) {
+          S.size[s] = (float)sz;
+          // smax is taken over rows nvar..nligne-1 only (traiter.c:576-586); sizes are >= 0,
+          // so their bit patterns order like the doubles
+          if ((int)S.srow[s] >= nvar) atomicMax(&sc.smaxbits, (u64)__double_as_longlong(sz));
+        }
       }
     }
   }
@@ -742,13 +747,22 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     if (wave == 0) sort_rows(S, nvar, nligne, __longlong_as_double((i64)sc.smaxbits));
     bsync<NW>();
     for (int i = tid; i < nligne; i += NT)
-      if (!(S.flag[i] & PIPAMD_F_UNIT)) S.srow[S.ref[i]] = (u16)i;
+      if (!(S.ref[i] & UNITBIT)) S.srow[S.ref[i]] = (u16)i;
     tflags &= ~PIPAMD_T_SORT;
     bsync<NW>();
   }
-  // chercher(Minus) for the first iteration; later ones get it from phase C
-  for (int i = tid; i < nligne; i += NT)
-    if (S.flag[i] & PIPAMD_F_MINUS) atomicMin(&sc.pivi, i);
+  // chercher(Minus) and the tentative exam_coef flags for the first iteration; later
+  // iterations get both from phase C
+  for (int s = tid; s < ni; s += NT) {
+    const int ff = S.fl[s];
+    if (ff & PIPAMD_F_MINUS)
+      atomicMin(&sc.pivi, (int)S.srow[s]);
+    else if (ff == PIPAMD_F_UNKNOWN && bigparm < 0) {
+      const int ec = exam_class(S.sig[s]);
+      S.nf[s] = (u8)ec;
+      if (ec == PIPAMD_F_MINUS) atomicMin(&sc.pivi2, (int)S.srow[s]);
+    }
+  }
   bsync<NW>();
 
   int status = PIPAMD_ST_RUN;
@@ -758,12 +772,21 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     int pivi = sc.pivi;
     if (pivi == BIG_I) {
       // -------------- exam_coef, then (if nothing is negative) integrer ---------
-      pivi = exam_rows<NW>(S, &sc, nligne, bigparm);
+      if (bigparm >= 0) {
+        pivi = exam_rows<NW>(S, &sc, ni);
+      } else {
+        // the flags exam_coef would assign were computed with the post-pivot hints; they are
+        // applied up to the first row it proves negative (traiter.c:154-156)
+        pivi = sc.pivi2;
+        for (int s = tid; s < ni; s += NT)
+          if (S.fl[s] == PIPAMD_F_UNKNOWN && (int)S.srow[s] <= pivi) S.fl[s] = S.nf[s];
+        bsync<NW>();
+      }
       PROF(1);
       if (pivi == BIG_I) {
-        if (nparm > 0) {
-          for (int i = tid; i < nligne; i += NT)
-            if (S.flag[i] & (PIPAMD_F_CRITIC | PIPAMD_F_UNKNOWN)) atomicOr(&sc.flagor, 1);
+        if (has_parm) {
+          for (int s = tid; s < ni; s += NT)
+            if (S.fl[s] & (PIPAMD_F_CRITIC | PIPAMD_F_UNKNOWN)) atomicOr(&sc.flagor, 1);
           bsync<NW>();
           if (sc.flagor) {
             status = PIPAMD_ST_NEED_COMPA;
@@ -782,9 +805,11 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
         if (tid == 0) sc.tmp = BIG_I;
         bsync<NW>();
         for (int i = tid; i < nvar; i += NT) {
-          i64 D = S.den[i];
-          if (D == 1 || (S.flag[i] & PIPAMD_F_UNIT)) continue;
-          const i64 *row = vals + (size_t)S.ref[i] * W;
+          const int rf = S.ref[i];
+          if (rf & UNITBIT) continue;
+          const i64 D = S.den[rf];
+          if (D == 1) continue;
+          const i64 *row = vals + (size_t)rf * W;
           bool ok = wneg(fmod64(wneg(row[nvar]), D)) != 0;
           for (int j = nvar + 1; j < ncol && !ok; j++)
             if (j != bigparm && fmod64(wneg(row[j]), D) != 0) ok = true;
@@ -798,9 +823,10 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
         }
         // wave 0 builds the cut in its registers (integrer.c:357-386) and appends it
         if (wave == 0) {
-          const i64 D = S.den[ci];
+          const int cslot = S.ref[ci];
+          const i64 D = uni64(S.den[cslot]);
           RowRegs<NCH> r;
-          row_load<NCH>(r, vals + (size_t)S.ref[ci] * W, ncolp, lane);
+          row_load<NCH>(r, vals + (size_t)cslot * W, ncolp, lane);
           bool okv = false, okp = false;
 #pragma unroll
           for (int c = 0; c < NCH; c++)
@@ -835,13 +861,14 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
             verdict = PIPAMD_ST_RUN;
             // append the cut as logical row nligne in slot ni (integrer.c:440-446)
             row_store<NCH>(r, vals + (size_t)ni * W, ncolp, lane);
-            row_publish<NCH>(r, S, nligne, ni, nvar, ncol, bigparm, -1, 0, lane);
+            row_publish<NCH>(r, S, ni, nvar, ncol, bigparm, -1, 0, has_parm, lane);
             if (lane == 0) {
-              S.flag[nligne] = PIPAMD_F_MINUS;
-              S.den[nligne] = D;
+              S.fl[ni] = PIPAMD_F_MINUS;
+              S.nf[ni] = 0;
+              S.den[ni] = D;
               S.ref[nligne] = (u16)ni;
+              S.uflag[nligne] = 0;
               S.srow[ni] = (u16)nligne;
-              S.size[nligne] = 0.f;
             }
           }
           if (lane == 0) {
@@ -875,18 +902,16 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
           int j = c * 128 + 2 * lane + h;
           if (j >= ncol) pr.v[c][h] = 0;
           S.prow[j] = pr.v[c][h];
-          if (j < nvar && pr.v[c][h] > 0 && (u64)pr.v[c][h] > amax) amax = (u64)pr.v[c][h];
+          if (j < nvar && pr.v[c][h] > 0) amax |= (u64)pr.v[c][h];
         }
       // exactness guard of the tournament: (max candidate a_j) * (max |entry|) < 2^62
-      amax = wave_max_u64(amax);
-      int mb = 0;
-      for (int i = lane; i < nligne; i += 64)
-        if (!(S.flag[i] & PIPAMD_F_UNIT) && S.rbits[i] > mb) mb = S.rbits[i];
-      for (int o = 32; o; o >>= 1) {
-        int t = __shfl(mb, lane ^ o);
-        mb = t > mb ? t : mb;
-      }
-      const bool safe = bitlen64(amax) + mb <= 62;
+      const int abits = __ballot((amax >> 47) != 0) ? 64
+                        : (__ballot((amax >> 31) != 0) ? 47 : (__ballot((amax >> 15) != 0) ? 31 : 15));
+      int mc = 0;
+      for (int s = lane; s < ni; s += 64)
+        if (S.rcls[s] > mc) mc = S.rcls[s];
+      mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
+      const bool safe = abits + cls_bits(mc) <= 62;
       PROF(3);
       int pj = safe ? choose_column<NCH>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc) : -2;
       PROF(4);
@@ -902,12 +927,11 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
             if (s == pslot)
               need = true;
             else {
-              const int k = S.srow[s];
               const bool nzb = (S.nzm[(size_t)s * NM + pe] >> pl) & 1;
-              if (nzb || !(S.sig[k] & SIG_RED))
+              if (nzb || !(S.sig[s] & SIG_RED) || (tflags & PIPAMD_T_NOSKIP))
                 need = true;
               else
-                S.sig[k] &= ~0xC0;  // entry in the pivot column is 0: sign hint "zero"
+                S.sig[s] &= ~0xC0;  // entry in the pivot column is 0: sign hint "zero"
             }
           }
           const u64 m = __ballot(need);
@@ -919,7 +943,10 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
       if (lane == 0) sc.pivj = pj;
     }
     bsync<NW>();
-    if (tid == 0) sc.pivi = BIG_I;  // every wave has read it by now; phase C refills it
+    if (tid == 0) {  // every wave has read them by now; phase C refills them
+      sc.pivi = BIG_I;
+      sc.pivi2 = BIG_I;
+    }
     const int pivj = sc.pivj;
     if (pivj == -1) {  // traiter.c:782-785
       status = PIPAMD_ST_NIL;
@@ -931,7 +958,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     }
     // pivot scalars + determinant bookkeeping, traiter.c:394-446 (uniform, every thread)
     const i64 pivot = uni64(S.prow[pivj]);
-    const i64 dpiv = uni64(S.den[pivi]);
+    const i64 dpiv = uni64(S.den[pslot]);
     {
       i64 d = gcd_i64(pivot, dpiv);
       i64 ppivot = cquo(pivot, d), dppiv = cquo(dpiv, d);
@@ -962,7 +989,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
       }
     }
     const int ku = S.urow[pivj];  // unit row of the entering column
-    const int pred = S.sig[pivi] & SIG_RED;
+    const int pred = S.sig[pslot] & SIG_RED;
     const int pc = pivj >> 7, ph = pivj & 1, pl = (pivj & 127) >> 1;
     PROF(5);
     // ---------------- B: eliminate the pivot column (all waves) ----------------
@@ -988,22 +1015,21 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
               r.v[c][h] = (j == pivj) ? dpiv : wneg(S.prow[j]);
             }
           row_store<NCH>(r, row, ncolp, lane);
-          row_publish<NCH>(r, S, ku, s, nvar, ncol, bigparm, pivj, pred, lane);
+          row_publish<NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
         } else {
-          const int k = S.srow[s];
           i64 nd;
           // multipliers from the row's own pivot-column entry (traiter.c:470-476)
           i64 foo = row_entry<NCH>(r, pc, ph, pl);
           const i64 d = gcd_i64(pivot, foo);
           const i64 lp = cquo(pivot, d);
           foo = cquo(foo, d);
-          const i64 g0 = wmul(lp, uni64(S.den[k]));
+          const i64 g0 = wmul(lp, uni64(S.den[s]));
           if (!update_row<NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
             if (lane == 0) sc.bad = 1;
           }
           row_store<NCH>(r, row, ncolp, lane);
-          row_publish<NCH>(r, S, k, s, nvar, ncol, bigparm, pivj, SIG_RED, lane);
-          if (lane == 0) S.den[k] = nd;
+          row_publish<NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane);
+          if (lane == 0) S.den[s] = nd;
         }
         r = rn;
       }
@@ -1015,24 +1041,27 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
       break;
     }
     // ---------------- C: swap roles, refresh the sign hints, next chercher ------
-    for (int i = tid; i < nligne; i += NT) {
-      if (i == pivi) {  // traiter.c:514-516
-        S.flag[i] = PIPAMD_F_UNIT | PIPAMD_F_ZERO;
-        S.den[i] = 1;
-        S.ref[i] = (u16)pivj;
-        S.urow[pivj] = (u16)i;
-        continue;
-      }
-      int ff = S.flag[i];
-      if (i == ku) {  // traiter.c:503-513
+    if (tid == 0) {  // traiter.c:514-516: the pivot row becomes the unit row of column pivj
+      S.ref[pivi] = (u16)(UNITBIT | pivj);
+      S.uflag[pivi] = PIPAMD_F_UNIT | PIPAMD_F_ZERO;
+      S.urow[pivj] = (u16)pivi;
+    }
+    for (int s = tid; s < ni; s += NT) {
+      int ff, k;
+      if (s == pslot) {  // traiter.c:503-513: its slot now holds the row that replaces ku's unit row
+        k = ku;
         ff = PIPAMD_F_PLUS;
-        S.den[i] = pivot;
-        S.ref[i] = (u16)pslot;
-        S.srow[pslot] = (u16)i;
-      } else if (ff & PIPAMD_F_UNIT)
-        continue;
+        S.den[s] = pivot;
+        S.srow[s] = (u16)ku;
+        S.ref[ku] = (u16)s;
+        S.uflag[ku] = 0;
+      } else {
+        k = S.srow[s];
+        ff = S.fl[s];
+      }
       // traiter.c:518-529
-      const int ps = SIG_PIV(S.sig[i]);
+      const int sg = S.sig[s];
+      const int ps = SIG_PIV(sg);
       const int fff = ps == 1 ? PIPAMD_F_PLUS : (ps == 2 ? PIPAMD_F_MINUS : PIPAMD_F_ZERO);
       if (fff != PIPAMD_F_ZERO && fff != ff) {
         if (ff == PIPAMD_F_ZERO)
@@ -1040,8 +1069,14 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
         else
           ff = PIPAMD_F_UNKNOWN;
       }
-      S.flag[i] = (u8)ff;
-      if (ff & PIPAMD_F_MINUS) atomicMin(&sc.pivi, i);
+      S.fl[s] = (u8)ff;
+      if (ff & PIPAMD_F_MINUS)
+        atomicMin(&sc.pivi, k);
+      else if (ff == PIPAMD_F_UNKNOWN && bigparm < 0) {
+        const int ec = exam_class(sg);
+        S.nf[s] = (u8)ec;
+        if (ec == PIPAMD_F_MINUS) atomicMin(&sc.pivi2, k);
+      }
     }
     bsync<NW>();
     PROF(7);
@@ -1050,15 +1085,22 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
   // ---- epilogue: publish the row tables, the header and (if any) the solution
   bsync<NW>();
   for (int i = tid; i < nligne; i += NT) {
-    g_den[i] = S.den[i];
-    g_flag[i] = S.flag[i];
-    g_ref[i] = S.ref[i];
+    const int rf = S.ref[i];
+    if (rf & UNITBIT) {
+      g_den[i] = 1;
+      g_flag[i] = S.uflag[i];
+      g_ref[i] = rf & ~UNITBIT;
+    } else {
+      g_den[i] = S.den[rf];
+      g_flag[i] = S.fl[rf];
+      g_ref[i] = rf;
+    }
   }
   if (status == PIPAMD_ST_RUN) {
     // paused (pivot budget of this launch spent, or LDS image full): save the summaries
-    for (int i = tid; i < nligne; i += NT) {
-      g_sig[i] = S.sig[i];
-      g_rbits[i] = S.rbits[i];
+    for (int s = tid; s < ni; s += NT) {
+      g_sig[s] = S.sig[s];
+      g_rcls[s] = S.rcls[s];
     }
     for (int e = tid; e < ni * NM; e += NT) g_nzm[e] = S.nzm[e];
     tflags |= PIPAMD_T_STATE;
@@ -1070,16 +1112,20 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     for (int e = tid; e < nvar * (nparm + 1); e += NT) {
       int i = e / (nparm + 1), jj = e % (nparm + 1);
       int col = jj < nparm ? nvar + 1 + jj : nvar;
+      const int rf = S.ref[i];
       i64 v = 0;
-      if (!(S.flag[i] & PIPAMD_F_UNIT)) v = vals[(size_t)S.ref[i] * W + col];
+      if (!(rf & UNITBIT)) v = vals[(size_t)rf * W + col];
       sol_num[e] = v;
     }
-    for (int i = tid; i < nvar; i += NT) sol_den[i] = S.den[i];
+    for (int i = tid; i < nvar; i += NT) {
+      const int rf = S.ref[i];
+      sol_den[i] = (rf & UNITBIT) ? 1 : S.den[rf];
+    }
   }
   if (tid == 0) {
-    u64 mb = 0;
-    for (int i = 0; i < nligne; i++)
-      if (!(S.flag[i] & PIPAMD_F_UNIT) && S.rbits[i] > mb) mb = S.rbits[i];
+    int mc = 0;
+    for (int s = 0; s < ni; s++)
+      if (S.rcls[s] > mc) mc = S.rcls[s];
     J->ni = ni;
     J->npiv = npiv;
     J->ncut = ncut;
@@ -1087,7 +1133,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     J->ldet = ldet;
     for (int i = 0; i < PIPAMD_MAXDET; i++) J->det[i] = det[i];
     J->tflags = tflags;
-    J->maxabs = mb;  // bit length of the largest entry
+    J->maxabs = (u64)mc;  // magnitude class of the largest entry
     J->aux = sc.aux;
     J->status = status;
   }
@@ -1123,10 +1169,17 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
       g_den[i] = 0;
     }
   }
+  // input rows; spare slots only need their columns beyond ncol cleared (a cut row writes its
+  // first ncol columns itself, a parametric cut relies on the new column being 0 elsewhere)
   const i64 *src = rows + (size_t)b * lay.ni * ncol;
-  for (int e = tid; e < lay.S * lay.W; e += blockDim.x) {
+  for (int e = tid; e < lay.ni * lay.W; e += blockDim.x) {
     int s = e / lay.W, j = e % lay.W;
-    vals[e] = (s < lay.ni && j < ncol) ? src[(size_t)s * ncol + j] : 0;
+    vals[e] = j < ncol ? src[(size_t)s * ncol + j] : 0;
+  }
+  const int pad = lay.W - ncol;
+  for (int e = tid; e < (lay.S - lay.ni) * pad; e += blockDim.x) {
+    int s = lay.ni + e / pad, j = ncol + e % pad;
+    vals[(size_t)s * lay.W + j] = 0;
   }
   if (tid == 0) {
     J->rows_off = base;
@@ -1204,8 +1257,8 @@ extern "C" hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, i
 extern "C" size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax) {
   const size_t WP = Wmax <= 128 ? 128 : (Wmax <= 256 ? 256 : 512);
   const size_t NM = WP / 64;
-  size_t shm = sizeof(i64) * ((size_t)Lmax + WP) + sizeof(u64) * (size_t)Smax * NM + sizeof(float) * (size_t)Lmax +
-               sizeof(u16) * (2 * (size_t)Lmax + 2 * (size_t)Smax + WP) + 2 * (size_t)Lmax;
+  size_t shm = sizeof(i64) * ((size_t)Smax + WP) + sizeof(u64) * (size_t)Smax * NM + sizeof(float) * (size_t)Smax +
+               sizeof(u16) * (3 * (size_t)Smax + (size_t)Lmax + WP) + 3 * (size_t)Smax + (size_t)Lmax;
   return (shm + 15) & ~(size_t)15;
 }
 

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "libpipamd.so")
 
 ST_RUN, ST_SOLUTION, ST_NIL, ST_NEED_COMPA, ST_NEED_PARMCUT, ST_OVERFLOW, ST_CAPACITY, ST_RANGE, ST_INTERNAL, ST_MAXCOL = range(10)
 T_INT, T_DUAL = 1, 2
+T_NOSKIP = 2048
 
 
 class BatchDesc(C.Structure):
