@@ -27,6 +27,7 @@ typedef struct PipJob {
   int32_t ldet, nupd; /* nupd: rows rewritten by pivots so far (excludes skipped zero-multiplier rows) */
   int64_t det[PIPAMD_MAXDET]; /* multi-limb determinant, tab.h:76-81 */
   uint64_t maxabs;
+  int32_t state_nch, pad1; /* row-chunk count (NCH) of the launch that saved the state block */
 } PipJob;
 
 typedef struct PipBatchLayout {

@@ -557,6 +557,53 @@ last_unit_wins:
   return sc->tmp2 & 1023;
 }
 
+// choisir_piv when entries are too large for the tournament's exactness guard: the reference's
+// own fold (traiter.c:312-331), candidate by candidate, with its wrap-around products; only the
+// search for the first row with a non-zero cross product is spread over the lanes.  Slow (two
+// column gathers per candidate) but bit-identical whatever the magnitudes.  Wave 0.
+__device__ int choose_column_slow(const Shared &S, const i64 *vals, int W, int nvar, int nligne) {
+  const int lane = threadIdx.x & 63;
+  int pivj = -1;
+  i64 pivot = 0;
+  for (int j = 0; j < nvar; j++) {
+    const i64 foo = S.prow[j];
+    if (!(foo > 0)) continue;
+    if (pivj < 0) {
+      pivj = j;
+      pivot = foo;
+      continue;
+    }
+    bool less = false;
+    for (int k0 = 0; k0 < nligne; k0 += 64) {
+      const int k = k0 + lane;
+      i64 x = 0;
+      if (k < nligne) {
+        const int rf = S.ref[k];
+        i64 vj, vb;
+        if (rf & UNITBIT) {  // valeur(): the unit row's denominator (1) in its own column
+          vj = ((rf & ~UNITBIT) == j) ? 1 : 0;
+          vb = ((rf & ~UNITBIT) == pivj) ? 1 : 0;
+        } else {
+          vj = vals[(size_t)rf * W + j];
+          vb = vals[(size_t)rf * W + pivj];
+        }
+        x = wsub(wmul(pivot, vj), wmul(vb, foo));
+      }
+      const u64 nz = __ballot(x != 0);
+      if (nz) {
+        const int src = __ffsll((long long)nz) - 1;
+        less = readlane64(x, src) < 0;
+        break;
+      }
+    }
+    if (less) {
+      pivj = j;
+      pivot = foo;
+    }
+  }
+  return pivj;
+}
+
 // ------------------------------------------------------------ tab_sort_rows
 // traiter.c:591-614: selection sort of the real rows nvar..nligne-1 by `size`
 // (first minimum strictly below the running bound, swap into place).  With
@@ -701,7 +748,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     }
   }
   bsync<NW>();
-  if (tflags & PIPAMD_T_STATE) {
+  if ((tflags & PIPAMD_T_STATE) && J->state_nch == NCH) {
     // resumed job: the summaries were saved when it paused
     for (int s = tid; s < ni; s += NT) {
       S.sig[s] = g_sig[s];
@@ -852,7 +899,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
           else if (!any_v)
             verdict = PIPAMD_ST_NIL;  // integrer.c:482-485 case (b)
           else if (tflags & PIPAMD_T_DEEPEST)
-            verdict = PIPAMD_ST_INTERNAL;  // deepest cut is not available on the device path
+            verdict = PIPAMD_ST_NEED_PARMCUT;  // deepest cut (integrer.c:417-438): built by the host
           else if (ni >= Sl || nligne >= L)
             verdict = PIPAMD_ST_CAPACITY;
           else if (ni >= Smax || nligne >= Lmax)
@@ -913,7 +960,8 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
       mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
       const bool safe = abits + cls_bits(mc) <= 62;
       PROF(3);
-      int pj = safe ? choose_column<NCH>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc) : -2;
+      int pj = safe ? choose_column<NCH>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc)
+                    : choose_column_slow(S, vals, W, nvar, nligne);
       PROF(4);
       if (pj >= 0) {
         // slots the elimination has to rewrite: the recycled pivot slot plus every real row
@@ -1096,8 +1144,10 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
       g_ref[i] = rf;
     }
   }
-  if (status == PIPAMD_ST_RUN) {
-    // paused (pivot budget of this launch spent, or LDS image full): save the summaries
+  tflags &= ~PIPAMD_T_STATE;
+  if (status == PIPAMD_ST_RUN || status == PIPAMD_ST_NEED_COMPA) {
+    // paused (pivot budget spent, LDS image full, or waiting for the host's sign tests, which
+    // only touch flags): save the summaries for the launch that resumes the job
     for (int s = tid; s < ni; s += NT) {
       g_sig[s] = S.sig[s];
       g_rcls[s] = S.rcls[s];
@@ -1133,6 +1183,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     J->ldet = ldet;
     for (int i = 0; i < PIPAMD_MAXDET; i++) J->det[i] = det[i];
     J->tflags = tflags;
+    J->state_nch = NCH;
     J->maxabs = (u64)mc;  // magnitude class of the largest entry
     J->aux = sc.aux;
     J->status = status;

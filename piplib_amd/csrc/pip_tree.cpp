@@ -1,11 +1,796 @@
-// piplib_amd/csrc/pip_tree.cpp -- layer 3 (placeholder until the host decision tree lands).
+// piplib_amd/csrc/pip_tree.cpp -- layer 3 of the C ABI: PipLib front-end semantics with the
+// quast decision tree on the host and every pivot on the GPU.
+//
+// The host owns exactly what the reference's traiter() does *between* pivot runs
+// (source/traiter.c:628-791):
+//   * compa_test (traiter.c:162-243): the sign tests of undecided rows are integer
+//     feasibility problems over the context; all of them are built here and solved as one
+//     batch of device jobs, then applied in the reference's order (stop at the first row
+//     proven negative);
+//   * the tree split on a Critic/Unknown row (traiter.c:695-759): device-to-device copy of
+//     the tableau for the "then" branch, context rows kept on the host;
+//   * parametric Gomory cuts (integrer.c:487-520, find_parm/add_parm integrer.c:156-291):
+//     the context and the solution tape live here, the cut row is appended to the device
+//     tableau;
+//   * the solution tape (sol.c:52-226) and its sol_edit text (sol.c:291-422).
+// Everything that pivots -- including the context-emptiness test of the front ends
+// (maind.c:196-203) and every compa_test sub-problem -- runs in pip_advance_kernel.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
 #include "pip_host.h"
+
+namespace {
+
+typedef long long i64;
+typedef unsigned long long u64;
+
+#define HIPTHROW(call)                                                                              \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      pipamd_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      throw (int)PIPAMD_E_HIP;                                                                      \
+    }                                                                                               \
+  } while (0)
+
+// ---- wrap-around integer helpers (piplib.h:128-169, integrer.c:43-74), host side ----
+inline i64 wadd(i64 a, i64 b) { return (i64)((u64)a + (u64)b); }
+inline i64 wsub(i64 a, i64 b) { return (i64)((u64)a - (u64)b); }
+inline i64 wneg(i64 a) { return (i64)(0ull - (u64)a); }
+inline i64 wabs(i64 a) { return a < 0 ? wneg(a) : a; }
+inline i64 crem(i64 a, i64 b) { return (b == 0 || b == -1) ? 0 : a % b; }
+inline i64 cquo(i64 a, i64 b) { return b == 0 ? 0 : (b == -1 ? wneg(a) : a / b); }
+i64 gcd(i64 a, i64 b) {
+  while (b) {
+    i64 t = crem(a, b);
+    a = b;
+    b = t;
+  }
+  return wabs(a);
+}
+inline i64 fmod_(i64 a, i64 b) {
+  i64 m = crem(a, b);
+  if (m < 0) m = wadd(m, wabs(b));
+  return m;
+}
+inline i64 floordiv(i64 a, i64 b) { return cquo(wsub(a, fmod_(a, b)), b); }
+inline i64 wmul(i64 a, i64 b) { return (i64)((u64)a * (u64)b); }
+
+enum { S_FREE = 0, S_NIL, S_IF, S_LIST, S_FORM, S_NEW, S_DIV, S_VAL }; /* sol.c:42-50 */
+struct Cell {
+  int kind;
+  i64 a, b;
+};
+
+// context: rows of (parameters | constant), traiter.c keeps it as a Tableau
+struct Ctx {
+  int nc = 0, width = 0;  // rows in use, columns allocated per row
+  std::vector<i64> v;
+  i64 &at(int r, int c) { return v[(size_t)r * width + c]; }
+  i64 at(int r, int c) const { return v[(size_t)r * width + c]; }
+  void reserve(int rows, int cols) {
+    if (cols > width) {
+      std::vector<i64> nv((size_t)std::max(rows, nc + 4) * cols, 0);
+      for (int r = 0; r < nc; r++)
+        for (int c = 0; c < width; c++) nv[(size_t)r * cols + c] = v[(size_t)r * width + c];
+      v.swap(nv);
+      width = cols;
+    }
+    if ((size_t)rows * width > v.size()) v.resize((size_t)(rows + 8) * width, 0);
+  }
+};
+
+struct HostJob {
+  PipJob pj;
+  i64 block_off = 0;
+  size_t block_words = 0;
+};
+
+struct Snap {  // host copy of a job's row tables and rows
+  int L = 0, S = 0, W = 0;
+  std::vector<i64> den, vals;
+  std::vector<int> flag, ref;
+  const i64 *row(int k) const { return &vals[(size_t)ref[k] * W]; }
+};
+
+class Tree {
+ public:
+  Tree(pipamd_engine *e, int deepest) : deepest_(deepest) { (void)e; }
+  ~Tree() {
+    if (d_arena_) hipFree(d_arena_);
+    if (d_jobs_) hipFree(d_jobs_);
+  }
+  std::vector<Cell> tape;
+  long long pivots = 0;
+  int fail_status = 0;
+
+  // maind.c:196-231: context emptiness test, then traiter
+  bool front(int nvar, int nparm, int ni, int nc, int bigparm, int nq, const i64 *ineq, const i64 *ctxrows) {
+    Ctx ctx;
+    ctx.reserve(nc + 4, nparm + 2);
+    ctx.nc = nc;
+    for (int r = 0; r < nc; r++)
+      for (int c = 0; c <= nparm; c++) ctx.at(r, c) = ctxrows[(size_t)r * (nparm + 1) + c];
+    if (nc) {
+      size_t mark = top_;
+      HostJob cj = make_context_job(ctx, nparm, nc, nullptr);
+      std::vector<HostJob *> js{&cj};
+      run_to_final(js);
+      pivots += cj.pj.npiv;
+      check_final(cj);
+      top_ = mark;
+      if (cj.pj.status == PIPAMD_ST_NIL) return false;  // "void"
+    }
+    HostJob job = make_job(nvar, nparm, ni, bigparm, nq ? PIPAMD_T_INT : 0, ineq);
+    node(job, ctx, nvar, nparm, ni, bigparm, nq ? PIPAMD_T_INT : 0);
+    return true;
+  }
+
+ private:
+  int deepest_;
+  i64 *d_arena_ = nullptr;
+  size_t arena_words_ = 0, top_ = 0;
+  PipJob *d_jobs_ = nullptr;
+  int d_jobs_cap_ = 0;
+
+  void fail(int st) {
+    fail_status = st;
+    throw (int)PIPAMD_E_SOLVER;
+  }
+  void push(int kind, i64 a, i64 b) {
+    tape.push_back(Cell{kind, a, b});
+    if (tape.size() >= 4096) fail(PIPAMD_ST_INTERNAL);  // "The solution is too complex", sol.c:97
+  }
+
+  // ---------------------------------------------------------------- arena
+  void ensure_arena(size_t words) {
+    if (words <= arena_words_) return;
+    size_t nw = std::max(words * 2, (size_t)1 << 20);
+    i64 *n = nullptr;
+    HIPTHROW(hipMalloc((void **)&n, nw * sizeof(i64)));
+    if (d_arena_) {
+      HIPTHROW(hipMemcpy(n, d_arena_, top_ * sizeof(i64), hipMemcpyDeviceToDevice));
+      hipFree(d_arena_);
+    }
+    d_arena_ = n;
+    arena_words_ = nw;
+  }
+  static int even(int x) { return (x + 1) & ~1; }
+
+  HostJob alloc_job(int nvar, int nparm, int ni, int bigparm, int tflags, int S, int W) {
+    HostJob j;
+    memset(&j.pj, 0, sizeof j.pj);
+    S = std::max(S, ni + 1);
+    W = even(std::max(W, nvar + nparm + 1));
+    if (W > PIPAMD_MAXCOL || S > PIPAMD_SMAX || nvar + S > PIPAMD_LMAX) fail(PIPAMD_ST_CAPACITY);
+    const int L = even(nvar + S);
+    const int nm = 8;  // room for the bitmaps of any launch geometry (jobs of mixed widths share launches)
+    const size_t sol = (size_t)even(nvar * (W - nvar) + nvar);
+    const size_t state = (size_t)even(S * nm + (3 * L + 7) / 8);
+    j.block_words = 2 * (size_t)L + (size_t)S * W + sol + state;
+    ensure_arena(top_ + j.block_words);
+    j.block_off = (i64)top_;
+    top_ += j.block_words;
+    j.pj.rows_off = j.block_off;
+    j.pj.vals_off = j.block_off + 2 * (i64)L;
+    j.pj.sol_off = j.pj.vals_off + (i64)S * W;
+    j.pj.state_off = j.pj.sol_off + (i64)sol;
+    j.pj.nvar = nvar;
+    j.pj.nparm = nparm;
+    j.pj.ni = ni;
+    j.pj.bigparm = bigparm;
+    j.pj.tflags = tflags | PIPAMD_T_SORT | (deepest_ ? PIPAMD_T_DEEPEST : 0);
+    j.pj.L = L;
+    j.pj.S = S;
+    j.pj.W = W;
+    j.pj.status = PIPAMD_ST_RUN;
+    j.pj.ldet = 1;
+    j.pj.det[0] = 1;
+    return j;
+  }
+
+  // tab_alloc + tab_get (tab.c:158-248): nvar unit rows, ni Unknown rows with denominator 1
+  void upload_fresh(HostJob &j, const std::vector<i64> &rows /* ni x ncol */) {
+    const int nvar = j.pj.nvar, ni = j.pj.ni, ncol = nvar + j.pj.nparm + 1, L = j.pj.L, S = j.pj.S, W = j.pj.W;
+    std::vector<i64> blk(2 * (size_t)L + (size_t)S * W, 0);
+    i64 *den = blk.data();
+    int *flag = (int *)(den + L), *ref = flag + L;
+    for (int i = 0; i < nvar; i++) {
+      den[i] = 1;
+      flag[i] = PIPAMD_F_UNIT;
+      ref[i] = i;
+    }
+    for (int i = 0; i < ni; i++) {
+      den[nvar + i] = 1;
+      flag[nvar + i] = PIPAMD_F_UNKNOWN;
+      ref[nvar + i] = i;
+      for (int c = 0; c < ncol; c++) blk[2 * (size_t)L + (size_t)i * W + c] = rows[(size_t)i * ncol + c];
+    }
+    HIPTHROW(hipMemcpy(d_arena_ + j.block_off, blk.data(), blk.size() * sizeof(i64), hipMemcpyHostToDevice));
+  }
+
+  HostJob make_job(int nvar, int nparm, int ni, int bigparm, int tflags, const i64 *rows) {
+    const int ncol = nvar + nparm + 1;
+    HostJob j = alloc_job(nvar, nparm, ni, bigparm, tflags, ni + 24, ncol + (nparm ? 6 : 0));
+    std::vector<i64> r(rows, rows + (size_t)ni * ncol);
+    upload_fresh(j, r);
+    return j;
+  }
+  // expanser(context, nparm, nc, nparm+1, nparm, extra?1:0, 0) (traiter.c:191,211,
+  // maind.c:198): the context as a problem in the parameters, optionally one more row
+  HostJob make_context_job(const Ctx &ctx, int nparm, int nc, const std::vector<i64> *extra) {
+    const int ni = nc + (extra ? 1 : 0), ncol = nparm + 1;
+    HostJob j = alloc_job(nparm, 0, ni, -1, PIPAMD_T_INT, ni + 16, ncol);
+    std::vector<i64> r((size_t)ni * ncol);
+    for (int i = 0; i < nc; i++)
+      for (int c = 0; c < ncol; c++) r[(size_t)i * ncol + c] = ctx.at(i, c);
+    if (extra)
+      for (int c = 0; c < ncol; c++) r[(size_t)nc * ncol + c] = (*extra)[c];
+    upload_fresh(j, r);
+    return j;
+  }
+
+  Snap download(const HostJob &j) {
+    Snap s;
+    s.L = j.pj.L;
+    s.S = j.pj.S;
+    s.W = j.pj.W;
+    std::vector<i64> blk(2 * (size_t)s.L + (size_t)s.S * s.W);
+    HIPTHROW(hipMemcpy(blk.data(), d_arena_ + j.block_off, blk.size() * sizeof(i64), hipMemcpyDeviceToHost));
+    s.den.assign(blk.begin(), blk.begin() + s.L);
+    const int *flag = (const int *)(blk.data() + s.L);
+    s.flag.assign(flag, flag + s.L);
+    s.ref.assign(flag + s.L, flag + 2 * s.L);
+    s.vals.assign(blk.begin() + 2 * s.L, blk.end());
+    return s;
+  }
+  void set_flag(const HostJob &j, int row, int f) {
+    int *g_flag = (int *)(d_arena_ + j.pj.rows_off + j.pj.L);
+    HIPTHROW(hipMemcpy(g_flag + row, &f, sizeof(int), hipMemcpyHostToDevice));
+  }
+
+  // run the engine on a set of jobs until none is PIPAMD_ST_RUN
+  void run(std::vector<HostJob *> &js) {
+    const int n = (int)js.size();
+    if (!n) return;
+    if (n > d_jobs_cap_) {
+      if (d_jobs_) hipFree(d_jobs_);
+      d_jobs_cap_ = n + 64;
+      HIPTHROW(hipMalloc((void **)&d_jobs_, sizeof(PipJob) * d_jobs_cap_));
+    }
+    std::vector<PipJob> tab(n);
+    int Lm = 4, Sm = 4, Wm = 2;
+    for (int i = 0; i < n; i++) {
+      tab[i] = js[i]->pj;
+      Lm = std::max(Lm, (int)tab[i].L);
+      Sm = std::max(Sm, (int)tab[i].S);
+      Wm = std::max(Wm, (int)tab[i].W);
+    }
+    for (int pass = 0; pass < 64; pass++) {
+      HIPTHROW(hipMemcpy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice));
+      for (int guard = 0; guard < 4096; guard++) {
+        HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, nullptr, 0));
+        HIPTHROW(hipMemcpy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost));
+        bool again = false;
+        for (int i = 0; i < n; i++)
+          if (tab[i].status == PIPAMD_ST_RUN) again = true;
+        if (!again) break;
+      }
+      // a tableau that ran out of spare rows is re-housed in a larger block (expanser) and resumed
+      bool grown = false;
+      for (int i = 0; i < n; i++) {
+        js[i]->pj = tab[i];
+        if (tab[i].status == PIPAMD_ST_CAPACITY) {
+          grow(*js[i], js[i]->pj.S + 32, js[i]->pj.W);
+          tab[i] = js[i]->pj;
+          Lm = std::max(Lm, (int)tab[i].L);
+          Sm = std::max(Sm, (int)tab[i].S);
+          grown = true;
+        }
+      }
+      if (!grown) break;
+    }
+  }
+  // non-parametric jobs (context test, compa_test sub-problems): run to a final status.  With
+  // the deepest-cut option the kernel hands every cut to the host (integrer.c:417-438).
+  void run_to_final(std::vector<HostJob *> &js) {
+    for (int guard = 0; guard < 100000; guard++) {
+      run(js);
+      bool again = false;
+      for (HostJob *j : js)
+        if (j->pj.status == PIPAMD_ST_NEED_PARMCUT) {
+          Ctx none;
+          int np = 0, ni = j->pj.ni;
+          if (host_cut(*j, none, j->pj.nvar, np, ni, -1)) {
+            j->pj.status = PIPAMD_ST_RUN;
+            again = true;
+          } else
+            j->pj.status = PIPAMD_ST_NIL;
+        }
+      if (!again) return;
+    }
+  }
+  // statuses that end a traiter() call abnormally (the reference exits the process)
+  void check_final(const HostJob &j) {
+    const int s = j.pj.status;
+    if (s == PIPAMD_ST_OVERFLOW || s == PIPAMD_ST_RANGE || s == PIPAMD_ST_INTERNAL || s == PIPAMD_ST_MAXCOL ||
+        s == PIPAMD_ST_RUN)
+      fail(s);
+  }
+
+  // Re-house a job in a larger block (more rows / columns): expanser (traiter.c:55-88)
+  void grow(HostJob &j, int newS, int newW) {
+    Snap s = download(j);
+    HostJob n = alloc_job(j.pj.nvar, j.pj.nparm, j.pj.ni, j.pj.bigparm, 0, newS, newW);
+    const int L = n.pj.L, W = n.pj.W, nl = j.pj.nvar + j.pj.ni;
+    std::vector<i64> blk(2 * (size_t)L + (size_t)n.pj.S * W, 0);
+    i64 *den = blk.data();
+    int *flag = (int *)(den + L), *ref = flag + L;
+    for (int k = 0; k < nl; k++) {
+      den[k] = s.den[k];
+      flag[k] = s.flag[k];
+      ref[k] = s.ref[k];
+      if (!(s.flag[k] & PIPAMD_F_UNIT))
+        for (int c = 0; c < s.W; c++) blk[2 * (size_t)L + (size_t)s.ref[k] * W + c] = s.vals[(size_t)s.ref[k] * s.W + c];
+    }
+    HIPTHROW(hipMemcpy(d_arena_ + n.block_off, blk.data(), blk.size() * sizeof(i64), hipMemcpyHostToDevice));
+    PipJob keep = j.pj;
+    j.block_off = n.block_off;
+    j.block_words = n.block_words;
+    j.pj = n.pj;
+    j.pj.tflags = keep.tflags & ~PIPAMD_T_STATE;  // summaries are rebuilt by the next launch
+    j.pj.npiv = keep.npiv;
+    j.pj.ncut = keep.ncut;
+    j.pj.nupd = keep.nupd;
+    j.pj.ldet = keep.ldet;
+    memcpy(j.pj.det, keep.det, sizeof keep.det);
+    j.pj.status = PIPAMD_ST_RUN;
+  }
+
+  // ------------------------------------------------------------ compa_test
+  void compa(HostJob &job, const Ctx &ctx, int nvar, int nparm, int ni) {
+    if (nparm == 0) return;
+    if (nparm >= PIPAMD_MAXPARM) fail(PIPAMD_ST_INTERNAL);  // "Too much parameters"
+    Snap s = download(job);
+    const int nc = ctx.nc;
+    std::vector<int> rows;
+    for (int i = 0; i < ni + nvar; i++)
+      if (s.flag[i] & (PIPAMD_F_CRITIC | PIPAMD_F_UNKNOWN)) rows.push_back(i);
+    if (rows.empty()) return;
+    const size_t mark = top_;
+    std::vector<HostJob> sub;
+    std::vector<int> critic(rows.size());
+    sub.reserve(2 * rows.size());
+    for (size_t t = 0; t < rows.size(); t++) {
+      const i64 *r = s.row(rows[t]);
+      int cr = 1;
+      for (int j = 0; j < nvar; j++)
+        if (r[j] > 0) {
+          cr = 0;
+          break;
+        }
+      critic[t] = cr;
+      std::vector<i64> ex(nparm + 1);
+      for (int j = 0; j < nparm; j++) ex[j] = r[j + nvar + 1];  // "row >= 1" (>= 0 if critical)
+      ex[nparm] = cr ? r[nvar] : wsub(r[nvar], 1);
+      sub.push_back(make_context_job(ctx, nparm, nc, &ex));
+      for (int j = 0; j < nparm; j++) ex[j] = wneg(r[j + nvar + 1]);  // "-row >= 1"
+      ex[nparm] = wsub(wneg(r[nvar]), 1);
+      sub.push_back(make_context_job(ctx, nparm, nc, &ex));
+    }
+    std::vector<HostJob *> ptr;
+    for (auto &h : sub) ptr.push_back(&h);
+    run_to_final(ptr);
+    // apply in the reference's order; sub-problems behind the first negative row were
+    // speculative and are ignored (their pivots are not counted either)
+    for (size_t t = 0; t < rows.size(); t++) {
+      HostJob &jp = sub[2 * t], &jm = sub[2 * t + 1];
+      pivots += jp.pj.npiv + jm.pj.npiv;
+      check_final(jp);
+      check_final(jm);
+      const bool cp = jp.pj.status != PIPAMD_ST_NIL, cm = jm.pj.status != PIPAMD_ST_NIL;
+      int f;
+      if (cp && cm)
+        f = critic[t] ? PIPAMD_F_CRITIC : PIPAMD_F_UNKNOWN;
+      else if (cm)
+        f = PIPAMD_F_MINUS;
+      else
+        f = cp ? PIPAMD_F_PLUS : PIPAMD_F_ZERO;
+      set_flag(job, rows[t], f);
+      if (f == PIPAMD_F_MINUS) break;
+    }
+    top_ = mark;
+  }
+
+  // --------------------------------------------------- find_parm / add_parm
+  static bool has_cut(const Ctx &cx, int nr, int nparm, int p, const std::vector<i64> &cut) {
+    for (int row = 0; row < nr; row++) {
+      if (cx.at(row, p) != cut[1 + nparm]) continue;
+      if (cx.at(row, nparm) != cut[0]) continue;
+      int col;
+      for (col = p + 1; col < nparm; col++)
+        if (cx.at(row, col) != 0) break;
+      if (col < nparm) continue;
+      for (col = 0; col < p; col++)
+        if (cx.at(row, col) != cut[1 + col]) break;
+      if (col < p) continue;
+      return true;
+    }
+    return false;
+  }
+  static int find_parm(const Ctx &cx, int nr, int nparm, std::vector<i64> &cut) {  // integrer.c:258-291
+    if (cut[1 + nparm - 1] != 0) return -1;
+    cut[0] = wsub(wadd(cut[0], cut[1 + nparm]), 1);
+    for (int p = nparm - 1; p >= 0; --p) {
+      if (cut[1 + p] != 0) break;
+      if (!has_cut(cx, nr, nparm, p, cut)) continue;
+      cut[0] = wsub(wadd(cut[0], 1), cut[1 + nparm]);
+      for (auto &x : cut) x = wneg(x);
+      const bool found = has_cut(cx, nr, nparm, p, cut);
+      for (auto &x : cut) x = wneg(x);
+      if (found) return p;
+      cut[0] = wsub(wadd(cut[0], cut[1 + nparm]), 1);
+    }
+    cut[0] = wsub(wadd(cut[0], 1), cut[1 + nparm]);
+    return -1;
+  }
+  void add_parm(Ctx &cx, int &nparm, const std::vector<i64> &cut) {  // integrer.c:156-227
+    const int nr = cx.nc;
+    push(S_NEW, nparm, 0);
+    push(S_DIV, 0, 0);
+    push(S_FORM, nparm + 1, 0);
+    for (int j = 0; j < nparm; j++) push(S_VAL, wneg(cut[1 + j]), 1);
+    push(S_VAL, wneg(cut[0]), 1);
+    push(S_VAL, cut[1 + nparm], 1);
+    cx.reserve(nr + 2, nparm + 2);
+    for (int k = 0; k < nr; k++) {
+      cx.at(k, nparm + 1) = cx.at(k, nparm);
+      cx.at(k, nparm) = 0;
+    }
+    for (int j = 0; j < nparm; j++) {
+      cx.at(nr, j) = wneg(cut[1 + j]);
+      cx.at(nr + 1, j) = cut[1 + j];
+    }
+    cx.at(nr, nparm) = wneg(cut[1 + nparm]);
+    cx.at(nr + 1, nparm) = cut[1 + nparm];
+    i64 x = cut[0];
+    cx.at(nr, nparm + 1) = wneg(x);
+    x = wsub(x, 1);
+    cx.at(nr + 1, nparm + 1) = wadd(x, cut[1 + nparm]);
+    nparm++;
+    cx.nc += 2;
+  }
+  static i64 bezout(i64 x, i64 y, i64 delta) {  // integrer.c:98-150
+    i64 a = 1, b = 0, c = 0, d = 1, u = y, v = delta;
+    for (;;) {
+      i64 q = floordiv(u, v), r = fmod_(u, v);
+      if (r == 0) break;
+      u = v;
+      v = r;
+      i64 e = wsub(a, wmul(q, c)), f = wsub(b, wmul(q, d));
+      a = c;
+      b = d;
+      c = e;
+      d = f;
+    }
+    if (v != 1) return 0;
+    return fmod_(wmul(c, x), delta);
+  }
+
+  // integrer() for the row the kernel stopped at (integrer.c:342-520): the kernel hands over
+  // parametric cuts, and every cut when the deepest-cut option is on.
+  // Returns false when the row admits no cut (case (b): no solution).
+  bool host_cut(HostJob &job, Ctx &ctx, int nvar, int &nparm, int &ni, int bigparm) {
+    const int ci = job.pj.aux;
+    Snap s = download(job);
+    const int ncol = nvar + nparm + 1, nligne = nvar + ni;
+    if (ncol >= PIPAMD_MAXCOL) fail(PIPAMD_ST_MAXCOL);
+    const i64 *r = s.row(ci);
+    const i64 D = s.den[ci];
+    std::vector<i64> cut(ncol + 1);
+    bool ok_var = false, ok_parm = false;
+    for (int j = 0; j < nvar; j++) {
+      cut[j] = fmod_(r[j], D);
+      if (cut[j] > 0) ok_var = true;
+    }
+    cut[nvar] = wneg(fmod_(wneg(r[nvar]), D));
+    for (int j = nvar + 1; j < ncol; j++) {
+      if (j == bigparm) {
+        cut[j] = 0;
+        continue;
+      }
+      cut[j] = wneg(fmod_(wneg(r[j]), D));
+      if (cut[j] != 0) ok_parm = true;
+    }
+    cut[ncol] = D;
+    int newcol = -1;
+    if (!ok_parm) {
+      if (!ok_var) return false;
+      if (deepest_) {  // integrer.c:417-438
+        i64 t = wneg(cut[nvar]), delta = gcd(t, D), tau = cquo(t, delta), dd = cquo(D, delta);
+        t = wsub(dd, 1);
+        i64 lambda = bezout(t, tau, dd);
+        t = gcd(lambda, D);
+        while (t != 1) {
+          lambda = wadd(lambda, dd);
+          t = gcd(lambda, D);
+        }
+        for (int j = 0; j < nvar; j++) cut[j] = fmod_(wmul(lambda, cut[j]), D);
+        t = fmod_(wmul(cut[nvar], lambda), D);
+        t = wsub(D, t);
+        cut[nvar] = wneg(t);
+      }
+    } else {
+      std::vector<i64> pc(cut.begin() + nvar, cut.end());  // constant | parameters | divisor
+      int parm = find_parm(ctx, ctx.nc, nparm, pc);
+      std::copy(pc.begin(), pc.end(), cut.begin() + nvar);
+      if (parm == -1) {
+        add_parm(ctx, nparm, pc);
+        parm = nparm - 1;
+      }
+      if (!ok_var) fail(PIPAMD_ST_INTERNAL);  // assert(ok_var), integrer.c:499
+      newcol = nvar + 1 + parm;
+    }
+    // append the cut as logical row nligne in slot ni
+    const int need_w = nvar + nparm + 1;
+    if (ni >= job.pj.S || nligne >= job.pj.L || need_w > job.pj.W)
+      grow(job, std::max((int)job.pj.S, ni + 1) + 16, std::max((int)job.pj.W, need_w) + 4);
+    const int W = job.pj.W, L = job.pj.L;
+    std::vector<i64> row(W, 0);
+    for (int j = 0; j < ncol; j++) row[j] = cut[j];
+    if (newcol >= 0) row[newcol] = wadd(row[newcol], cut[ncol]);
+    HIPTHROW(hipMemcpy(d_arena_ + job.pj.vals_off + (size_t)ni * W, row.data(), W * sizeof(i64), hipMemcpyHostToDevice));
+    i64 *g_den = d_arena_ + job.pj.rows_off;
+    int *g_flag = (int *)(g_den + L), *g_ref = g_flag + L;
+    const int fl = PIPAMD_F_MINUS;
+    HIPTHROW(hipMemcpy(g_den + nligne, &D, sizeof(i64), hipMemcpyHostToDevice));
+    HIPTHROW(hipMemcpy(g_flag + nligne, &fl, sizeof(int), hipMemcpyHostToDevice));
+    HIPTHROW(hipMemcpy(g_ref + nligne, &ni, sizeof(int), hipMemcpyHostToDevice));
+    ni++;
+    job.pj.ni = ni;
+    job.pj.nparm = nparm;
+    job.pj.ncut++;
+    job.pj.tflags &= ~PIPAMD_T_STATE;
+    return true;
+  }
+
+  void emit_solution(const HostJob &job, int nvar, int nparm) {  // traiter.c:255-271
+    const size_t n = (size_t)nvar * (nparm + 1);
+    std::vector<i64> buf(n + nvar);
+    if (n + nvar)
+      HIPTHROW(hipMemcpy(buf.data(), d_arena_ + job.pj.sol_off, (n + nvar) * sizeof(i64), hipMemcpyDeviceToHost));
+    push(S_LIST, nvar, 0);
+    for (int i = 0; i < nvar; i++) {
+      push(S_FORM, nparm + 1, 0);
+      for (int j = 0; j <= nparm; j++) push(S_VAL, buf[(size_t)i * (nparm + 1) + j], buf[n + i]);
+    }
+  }
+
+  // ------------------------------------------------------------- traiter()
+  void node(HostJob &job, Ctx ctx /* this call's own copy, traiter.c:654 */, int nvar, int nparm, int ni,
+            int bigparm, int flags) {
+    for (;;) {
+      job.pj.status = PIPAMD_ST_RUN;
+      std::vector<HostJob *> js{&job};
+      const int piv0 = job.pj.npiv;
+      run(js);
+      pivots += job.pj.npiv - piv0;
+      ni = job.pj.ni;
+      switch (job.pj.status) {
+        case PIPAMD_ST_SOLUTION: emit_solution(job, nvar, nparm); return;
+        case PIPAMD_ST_NIL: push(S_NIL, 0, 0); return;
+        case PIPAMD_ST_CAPACITY: grow(job, job.pj.S + 32, job.pj.W); continue;
+        case PIPAMD_ST_NEED_PARMCUT:
+          if (!host_cut(job, ctx, nvar, nparm, ni, bigparm)) {
+            push(S_NIL, 0, 0);
+            return;
+          }
+          continue;
+        case PIPAMD_ST_NEED_COMPA: break;
+        default: fail(job.pj.status);
+      }
+      // compa_test, then chercher(Minus) / Critic / Unknown on the refreshed flags
+      compa(job, ctx, nvar, nparm, ni);
+      Snap s = download(job);
+      const int nligne = nvar + ni;
+      int pivi = nligne;
+      for (int i = 0; i < nligne; i++)
+        if (s.flag[i] & PIPAMD_F_MINUS) {
+          pivi = i;
+          break;
+        }
+      if (pivi < nligne) continue;  // the kernel pivots on it
+      for (int i = 0; i < nligne; i++)
+        if (s.flag[i] & PIPAMD_F_CRITIC) {
+          pivi = i;
+          break;
+        }
+      if (pivi >= nligne)
+        for (int i = 0; i < nligne; i++)
+          if (s.flag[i] & PIPAMD_F_UNKNOWN) {
+            pivi = i;
+            break;
+          }
+      if (pivi >= nligne) continue;  // all signs settled: the kernel goes on to the solution / cuts
+      // ---- the quast forks on the sign of row pivi (traiter.c:695-759)
+      if (nparm >= PIPAMD_MAXPARM) fail(PIPAMD_ST_INTERNAL);
+      const size_t mark = top_;
+      HostJob child = alloc_job(nvar, nparm, ni, bigparm, flags, job.pj.S, job.pj.W);
+      if (child.pj.L != job.pj.L || child.pj.S != job.pj.S || child.pj.W != job.pj.W) fail(PIPAMD_ST_INTERNAL);
+      HIPTHROW(hipMemcpy(d_arena_ + child.block_off, d_arena_ + job.block_off,
+                         (2 * (size_t)job.pj.L + (size_t)job.pj.S * job.pj.W) * sizeof(i64), hipMemcpyDeviceToDevice));
+      child.pj.ldet = job.pj.ldet;
+      memcpy(child.pj.det, job.pj.det, sizeof job.pj.det);
+      push(S_IF, 0, 0);
+      push(S_FORM, nparm + 1, 0);
+      const i64 *r = s.row(pivi);
+      i64 g = 0;
+      for (int j = 0; j < nparm; j++) g = gcd(g, r[j + nvar + 1]);
+      if (!(flags & PIPAMD_T_INT)) g = gcd(g, r[nvar]);
+      const int nc = ctx.nc;
+      ctx.reserve(nc + 1, nparm + 2);
+      for (int j = 0; j < nparm; j++) {
+        ctx.at(nc, j) = cquo(r[j + nvar + 1], g);
+        push(S_VAL, ctx.at(nc, j), 1);
+      }
+      ctx.at(nc, nparm) = (flags & PIPAMD_T_INT) ? floordiv(r[nvar], g) : cquo(r[nvar], g);
+      push(S_VAL, ctx.at(nc, nparm), 1);
+      set_flag(child, pivi, PIPAMD_F_PLUS);
+      {
+        Ctx cc = ctx;
+        cc.nc = nc + 1;
+        node(child, cc, nvar, nparm, ni, bigparm, flags);
+      }
+      top_ = mark;
+      for (int j = 0; j < nparm; j++) ctx.at(nc, j) = wneg(ctx.at(nc, j));
+      ctx.at(nc, nparm) = wneg(wadd(ctx.at(nc, nparm), 1));
+      ctx.nc = nc + 1;
+      set_flag(job, pivi, PIPAMD_F_MINUS);
+    }
+  }
+};
+
+// ------------------------------------------------------------------ sol_edit
+void print_ent(std::string &o, i64 x) {
+  char b[32];
+  snprintf(b, sizeof b, "%lld", x);
+  o += b;
+}
+void print_frac(std::string &o, i64 N, i64 D) {  // sol.c:343-374
+  const i64 d = gcd(N, D);
+  o += ' ';
+  print_ent(o, cquo(N, d));
+  if (d != D) {
+    o += '/';
+    print_ent(o, cquo(D, d));
+  }
+}
+size_t print_tape(const std::vector<Cell> &t, std::string &o, size_t i) {  // sol.c:291-422
+  for (;;) {
+    if (t[i].kind == S_FREE) {
+      i++;
+      continue;
+    }
+    if (t[i].kind == S_NEW) {
+      char b[48];
+      snprintf(b, sizeof b, "(newparm %d ", (int)t[i].a);
+      o += b;
+      i = print_tape(t, o, i + 1);
+      o += ")\n";
+      continue;
+    }
+    break;
+  }
+  switch (t[i].kind) {
+    case S_NIL:
+      o += "()\n";
+      i++;
+      break;
+    case S_IF:
+      o += "(if ";
+      i = print_tape(t, o, i + 1);
+      i = print_tape(t, o, i);
+      i = print_tape(t, o, i);
+      o += ")\n";
+      break;
+    case S_LIST: {
+      o += "(list ";
+      int n = (int)t[i].a;
+      i++;
+      while (n--) i = print_tape(t, o, i);
+      o += ")\n";
+      break;
+    }
+    case S_FORM: {
+      o += "#[";
+      const int n = (int)t[i].a;
+      for (int j = 0; j < n; j++) {
+        i++;
+        print_frac(o, t[i].a, t[i].b);
+      }
+      o += "]\n";
+      i++;
+      break;
+    }
+    case S_DIV:
+      o += "(div ";
+      i = print_tape(t, o, i + 1);
+      i = print_tape(t, o, i);
+      o += ")\n";
+      break;
+    case S_VAL:
+      print_frac(o, t[i].a, t[i].b);
+      i++;
+      break;
+    default: o += "Inconnu : sol\n"; i++;
+  }
+  return i;
+}
+
+// tab_simplify (tab.c:396-427) on a row-major matrix
+void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) {
+  for (int i = 0; i < rows; i++) {
+    i64 *r = &m[(size_t)i * width];
+    i64 g = 0;
+    for (int j = 0; j < width; j++) {
+      if (j == cst) continue;
+      g = gcd(g, r[j]);
+      if (g == 1) break;
+    }
+    if (g == 0 || g == 1) continue;
+    for (int j = 0; j < width; j++) r[j] = (j == cst) ? floordiv(r[j], g) : cquo(r[j], g);
+  }
+}
+
+}  // namespace
 
 extern "C" int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int nq,
                                     const int64_t *ineq, const int64_t *ctx, int simplify, int deepest_cut, char **text,
                                     int *status, int64_t *pivots) {
-  (void)e; (void)nvar; (void)nparm; (void)ni; (void)nc; (void)bigparm; (void)nq; (void)ineq; (void)ctx;
-  (void)simplify; (void)deepest_cut; (void)text; (void)status; (void)pivots;
-  pipamd_set_error("pipamd_solve_tableau: not built yet");
-  return PIPAMD_E_INVALID;
+  if (!e || !text || nvar < 0 || nparm < 0 || ni < 0 || nc < 0 || (ni && !ineq) || (nc && !ctx)) {
+    pipamd_set_error("pipamd_solve_tableau: invalid argument");
+    return PIPAMD_E_INVALID;
+  }
+  const int ncol = nvar + nparm + 1;
+  if (bigparm >= ncol || (bigparm >= 0 && bigparm <= nvar)) {
+    pipamd_set_error("bigparm must be -1 or a parameter column (nvar < bigparm < nvar+nparm+1)");
+    return PIPAMD_E_INVALID;
+  }
+  *text = nullptr;
+  if (status) *status = 0;
+  if (pivots) *pivots = 0;
+  std::vector<i64> a((const i64 *)ineq, (const i64 *)ineq + (size_t)ni * ncol);
+  std::vector<i64> c((const i64 *)ctx, (const i64 *)ctx + (size_t)nc * (nparm + 1));
+  if (nq && simplify) {  // maind.c:190-196
+    simplify_rows(a, ni, ncol, nvar);
+    simplify_rows(c, nc, nparm + 1, nparm);
+  }
+  if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
+  Tree t(e, deepest_cut);
+  std::string out;
+  int rc = PIPAMD_OK;
+  try {
+    if (t.front(nvar, nparm, ni, nc, bigparm, nq, a.data(), c.data())) {
+      size_t i = 0;
+      while (i < t.tape.size()) i = print_tape(t.tape, out, i);
+    } else
+      out = "void\n";
+  } catch (int code) {
+    rc = code;
+    if (status) *status = t.fail_status;
+    if (rc == PIPAMD_E_SOLVER)
+      pipamd_set_error("solver stopped with status %d (5 = the reference's \"Integer overflow\" exit)", t.fail_status);
+  }
+  if (pivots) *pivots = t.pivots;
+  if (rc) return rc;
+  *text = (char *)malloc(out.size() + 1);
+  if (!*text) return PIPAMD_E_NOMEM;
+  memcpy(*text, out.c_str(), out.size() + 1);
+  return PIPAMD_OK;
 }

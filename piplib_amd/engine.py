@@ -147,3 +147,30 @@ class Batch:
 
     def pivot_bytes(self):
         return int(lib().pipamd_pivot_bytes(C.byref(self.desc)))
+
+
+def solve_tableau(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify=True, deepest_cut=False):
+    """Layer 3: one problem in .dat form (host arrays) -> (sol_edit text, pivots).
+    Raises SolverError(status) where the reference would have exit()ed."""
+    import numpy as np
+    a = np.ascontiguousarray(ineq, dtype=np.int64).reshape(ni, nvar + nparm + 1)
+    c = np.ascontiguousarray(ctx, dtype=np.int64).reshape(nc, nparm + 1)
+    text = C.c_void_p()
+    status = C.c_int(0)
+    piv = C.c_int64(0)
+    rc = lib().pipamd_solve_tableau(engine._h, nvar, nparm, ni, nc, bigparm, nq,
+                                    C.c_void_p(a.ctypes.data), C.c_void_p(c.ctypes.data), int(bool(simplify)),
+                                    int(bool(deepest_cut)), C.byref(text), C.byref(status), C.byref(piv))
+    if rc == -5:
+        raise SolverError(status.value, piv.value)
+    _check(rc)
+    out = C.string_at(text).decode()
+    lib().pipamd_free(text)
+    return out, piv.value
+
+
+class SolverError(RuntimeError):
+    def __init__(self, status, pivots=0):
+        super().__init__(f"solver stopped with PIPAMD_ST status {status}")
+        self.status = status
+        self.pivots = pivots
