@@ -149,6 +149,50 @@ int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int ni, int nc, 
                          char **text, int *status, int64_t *pivots);
 void pipamd_free(void *p);
 
+/* pip_solve() (reference source/piplib.c:722-880) with the same argument meaning.  The
+ * structures below have the memory layout of the reference's int64 ("dp" / piplib64) types
+ * PipMatrix, PipVector, PipNewparm, PipList, PipQuast and PipOptions
+ * (include/piplib/piplib.h:194-329), and every node of the returned tree is malloc'ed on its
+ * own, so the reference's pip_quast_print / pip_quast_free can be applied to it directly.
+ * *quast is NULL for the reference's "void" answers.  Compute_dual is not supported. */
+typedef struct pipamd_matrix {
+  unsigned int NbRows, NbColumns;
+  long long **p;
+  long long *p_Init;
+  int p_Init_size;
+} pipamd_matrix;
+typedef struct pipamd_vector {
+  int nb_elements;
+  long long *the_vector;
+  long long *the_deno;
+} pipamd_vector;
+typedef struct pipamd_newparm {
+  int rank;
+  pipamd_vector *vector;
+  long long deno;
+  struct pipamd_newparm *next;
+} pipamd_newparm;
+typedef struct pipamd_list {
+  pipamd_vector *vector;
+  struct pipamd_list *next;
+} pipamd_list;
+typedef struct pipamd_quast {
+  pipamd_newparm *newparm;
+  pipamd_list *list;
+  pipamd_vector *condition;
+  struct pipamd_quast *next_then, *next_else, *father;
+} pipamd_quast;
+typedef struct pipamd_options {
+  int Nq, Verbose, Simplify, Deepest_cut, Maximize, Urs_parms, Urs_unknowns, Compute_dual;
+} pipamd_options;
+
+int pipamd_pip_solve(pipamd_engine *e, const pipamd_matrix *domain, const pipamd_matrix *context,
+                     int bignum, const pipamd_options *options, pipamd_quast **quast, int *status,
+                     int64_t *pivots);
+void pipamd_quast_free(pipamd_quast *q);
+/* pip_quast_print (piplib.c:290-317) into a malloc'ed string (free with pipamd_free) */
+char *pipamd_quast_to_string(const pipamd_quast *q, int indent);
+
 #ifdef __cplusplus
 }
 #endif

@@ -794,3 +794,404 @@ extern "C" int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int n
   memcpy(*text, out.c_str(), out.size() + 1);
   return PIPAMD_OK;
 }
+
+
+// =========================================================================== pip_solve
+// The PolyLib-matrix front end (reference source/piplib.c:722-880) on top of the same tree:
+// tab_Matrix2Tableau (tab.c:292-393) and the tape -> PipQuast conversion (sol.c:435-734) are
+// host-side data conversions; the structures are layout-compatible with the reference's
+// int64 ("dp") PipMatrix / PipVector / PipNewparm / PipList / PipQuast / PipOptions
+// (include/piplib/piplib.h:194-329), every piece malloc'ed separately, so the reference's own
+// pip_quast_free / pip_quast_print work on the result.
+namespace {
+
+enum { SOL_SHIFT = 1, SOL_NEGATE = 2, SOL_REMOVE = 4, SOL_MAX = 3, SOL_DUAL = 8 }; /* sol.h:36-50 */
+
+struct TabArr {
+  int rows = 0, width = 0;
+  std::vector<i64> v;
+};
+
+// tab.c:292-393; returns the real rows only (the n leading unit rows are implicit)
+TabArr matrix_to_tab(const pipamd_matrix *m, int Nineq, int Nv, int n, int Shift, int Bg, int Urs) {
+  const int ctx = (n == -1);
+  unsigned nb_columns = m->NbColumns - 1;
+  const bool bignum_is_new = Shift && (Bg + ctx > 0) && ((unsigned)(Bg + ctx) > (m->NbColumns - 2));
+  if (bignum_is_new) nb_columns++;
+  int cst;
+  if (ctx) {
+    Shift = 0;
+    cst = Nv + Urs;
+  } else
+    cst = Nv;
+  TabArr t;
+  t.rows = Nineq;
+  t.width = (int)nb_columns + Urs;
+  t.v.assign((size_t)t.rows * t.width, 0);
+  unsigned decal = 0;
+  for (unsigned i = 0; i < m->NbRows; i++) {
+    i64 *r = &t.v[(size_t)(i + decal) * t.width];
+    const i64 *src = m->p[i];
+    i64 big = 0;
+    const bool inequality = src[0] != 0;
+    int j, k;
+    for (j = 0; j < Nv; j++) {
+      if (bignum_is_new && j == Bg) continue;
+      if (Shift) big = wadd(big, src[1 + j]);
+      r[j] = Shift > 0 ? wneg(src[1 + j]) : src[1 + j];
+    }
+    for (k = j = Nv + 1; (unsigned)j < nb_columns; j++) {
+      if (bignum_is_new && j == Bg) continue;
+      r[j] = src[k];
+      k++;
+    }
+    for (j = 0; j < Urs; ++j) {
+      int pos_n = (int)nb_columns - ctx + j, pos = pos_n - Urs;
+      if (pos <= Bg) --pos;
+      r[pos_n] = wneg(r[pos]);
+    }
+    r[cst] = src[m->NbColumns - 1];
+    if (Shift) {
+      if (Shift < 0) big = wneg(big);
+      if (bignum_is_new)
+        r[Bg] = big;
+      else
+        r[Bg] = wadd(r[Bg], big);
+    }
+    if (!inequality) {
+      decal++;
+      i64 *r2 = &t.v[(size_t)(i + decal) * t.width];
+      for (j = 0; (unsigned)j < nb_columns + (unsigned)Urs; j++) r2[j] = wneg(r[j]);
+    }
+  }
+  return t;
+}
+
+template <class T>
+T *zalloc() {
+  return (T *)calloc(1, sizeof(T));
+}
+
+// sol.c:435-512 sol_vector_edit
+pipamd_vector *q_vector(const std::vector<Cell> &t, size_t *i, int Bg, int Urs_p, int flags) {
+  const Cell *p = &t[*i];
+  int n = (int)p->a, j, k, unbounded = 0;
+  pipamd_vector *v = zalloc<pipamd_vector>();
+  if (flags & SOL_REMOVE) --n;
+  n -= Urs_p;
+  const int first_urs = Urs_p + (Bg >= 0);
+  v->nb_elements = n;
+  v->the_vector = (long long *)calloc((size_t)(n > 0 ? n : 1), sizeof(long long));
+  v->the_deno = (long long *)calloc((size_t)(n > 0 ? n : 1), sizeof(long long));
+  for (j = 0, k = 0; k < n; j++) {
+    (*i)++;
+    p++;
+    i64 N = p->a, D = p->b;
+    const i64 d = gcd(N, D);
+    if ((flags & SOL_SHIFT) && j == Bg) {
+      N = wsub(N, D);
+      if (N != 0) unbounded = 1;
+    }
+    if ((flags & SOL_REMOVE) && j == Bg) continue;
+    if (first_urs <= j && j < first_urs + Urs_p) continue;
+    v->the_vector[k] = cquo(N, d);
+    if (flags & SOL_NEGATE) v->the_vector[k] = wneg(v->the_vector[k]);
+    v->the_deno[k] = (d == D) ? 1 : cquo(D, d);
+    ++k;
+  }
+  if (unbounded)
+    for (k = 0; k < n; k++) v->the_deno[k] = 0;
+  (*i)++;
+  return v;
+}
+// sol.c:525-577
+pipamd_newparm *q_newparm(const std::vector<Cell> &t, size_t *i, int Bg, int Urs_p, int flags) {
+  const Cell *p = &t[*i];
+  pipamd_newparm *first = nullptr, *last = nullptr;
+  do {
+    pipamd_newparm *np = zalloc<pipamd_newparm>();
+    (*i) += 2;
+    np->vector = q_vector(t, i, Bg, Urs_p, flags);
+    np->rank = (int)p->a;
+    p = &t[*i];
+    np->deno = p->a;
+    if (flags & SOL_REMOVE) np->rank--;
+    np->rank -= Urs_p;
+    if (last)
+      last->next = np;
+    else
+      first = np;
+    last = np;
+    (*i)++;
+    p = &t[*i];
+  } while (*i < t.size() && p->kind == S_NEW);
+  return first;
+}
+// sol.c:591-638
+pipamd_list *q_list(const std::vector<Cell> &t, size_t *i, int n, int Bg, int Urs_p, int flags) {
+  pipamd_list *head = zalloc<pipamd_list>(), *cur = head;
+  if (n == 0) return head;
+  head->vector = q_vector(t, i, Bg, Urs_p, flags);
+  while (--n) {
+    pipamd_list *nx = zalloc<pipamd_list>();
+    nx->vector = q_vector(t, i, Bg, Urs_p, flags);
+    cur->next = nx;
+    cur = nx;
+  }
+  return head;
+}
+// sol.c:664-734
+pipamd_quast *q_quast(const std::vector<Cell> &t, size_t *i, pipamd_quast *father, int Bg, int Urs_p, int flags) {
+  pipamd_quast *q = zalloc<pipamd_quast>();
+  q->father = father;
+  while (t[*i].kind == S_FREE) (*i)++;
+  const Cell *p = &t[*i];
+  if (p->kind == S_NEW) {
+    q->newparm = q_newparm(t, i, Bg, Urs_p, flags & SOL_REMOVE);
+    p = &t[*i];
+  }
+  (*i)++;
+  switch (p->kind) {
+    case S_LIST: q->list = q_list(t, i, (int)p->a, Bg, Urs_p, flags); break;
+    case S_NIL: break;
+    case S_IF:
+      q->condition = q_vector(t, i, Bg, Urs_p, flags & SOL_REMOVE);
+      q->next_then = q_quast(t, i, q, Bg, Urs_p, flags);
+      q->next_else = q_quast(t, i, q, Bg, Urs_p, flags);
+      break;
+    default: break;
+  }
+  return q;
+}
+
+// sol.c:236-288 skip / sol_simplify on our tape
+size_t t_skip(const std::vector<Cell> &t, size_t i);
+size_t t_skip_new(const std::vector<Cell> &t, size_t i) { return t[i].kind != S_NEW ? i : t_skip(t, i + 1); }
+size_t t_skip(const std::vector<Cell> &t, size_t i) {
+  while (t[i].kind == S_FREE) i++;
+  switch (t[i].kind) {
+    case S_NIL:
+    case S_VAL: i++; break;
+    case S_NEW: i = t_skip_new(t, i); break;
+    case S_IF:
+      i = t_skip(t, i + 1);
+      i = t_skip(t, i);
+      i = t_skip(t, i);
+      break;
+    case S_LIST:
+    case S_FORM: {
+      int n = (int)t[i].a;
+      i++;
+      while (n--) i = t_skip(t, i);
+      break;
+    }
+    case S_DIV:
+      i = t_skip(t, i + 1);
+      i = t_skip(t, i);
+      break;
+    default: break;
+  }
+  return i < t.size() ? t_skip_new(t, i) : i;
+}
+void t_simplify(std::vector<Cell> &t, size_t i) {
+  if (t[i].kind != S_IF) return;
+  const size_t j = t_skip(t, i + 1), k = t_skip(t, j);
+  t_simplify(t, k);
+  t_simplify(t, j);
+  if (t[j].kind == S_NIL && t[k].kind == S_NIL) {
+    t[i].kind = S_NIL;
+    if (k + 1 >= t.size())
+      t.resize(i + 1);
+    else
+      for (size_t l = i + 1; l <= k; l++) t[l].kind = S_FREE;
+  }
+}
+
+void pr_vec(std::string &o, const pipamd_vector *v) {  // piplib.c:198-214
+  if (!v) return;
+  o += "#[";
+  for (int i = 0; i < v->nb_elements; i++) {
+    o += ' ';
+    print_ent(o, v->the_vector[i]);
+    if (v->the_deno[i] != 1) {
+      o += '/';
+      print_ent(o, v->the_deno[i]);
+    }
+  }
+  o += ']';
+}
+void pr_quast(std::string &o, const pipamd_quast *q, int indent) {  // piplib.c:225-317
+  const int ni = indent >= 0 ? indent + 1 : indent;
+  auto ind = [&](int n) {
+    for (int i = 0; i < n; i++) o += ' ';
+  };
+  if (!q) {
+    ind(indent);
+    o += "void\n";
+    return;
+  }
+  for (const pipamd_newparm *np = q->newparm; np; np = np->next) {
+    char b[48];
+    ind(indent);
+    snprintf(b, sizeof b, "(newparm %d (div ", np->rank);
+    o += b;
+    pr_vec(o, np->vector);
+    o += ' ';
+    print_ent(o, np->deno);
+    o += "))\n";
+  }
+  if (!q->condition) {
+    ind(indent);
+    if (!q->list)
+      o += "()\n";
+    else {
+      o += "(list\n";
+      for (const pipamd_list *l = q->list; l; l = l->next)
+        if (l->vector) {
+          ind(indent + 1);
+          pr_vec(o, l->vector);
+          o += '\n';
+        }
+      ind(indent);
+      o += ")\n";
+    }
+    if (q->next_then) pr_quast(o, q->next_then, ni);
+  } else {
+    ind(indent);
+    o += "(if ";
+    pr_vec(o, q->condition);
+    o += '\n';
+    pr_quast(o, q->next_then, ni);
+    pr_quast(o, q->next_else, ni);
+    ind(indent);
+    o += ")\n";
+  }
+}
+
+void free_vec(pipamd_vector *v) {
+  if (!v) return;
+  free(v->the_vector);
+  free(v->the_deno);
+  free(v);
+}
+
+}  // namespace
+
+extern "C" void pipamd_quast_free(pipamd_quast *q) {  // piplib.c:435-447
+  if (!q) return;
+  for (pipamd_newparm *np = q->newparm; np;) {
+    pipamd_newparm *nx = np->next;
+    free_vec(np->vector);
+    free(np);
+    np = nx;
+  }
+  for (pipamd_list *l = q->list; l;) {
+    pipamd_list *nx = l->next;
+    free_vec(l->vector);
+    free(l);
+    l = nx;
+  }
+  free_vec(q->condition);
+  pipamd_quast_free(q->next_then);
+  pipamd_quast_free(q->next_else);
+  free(q);
+}
+
+extern "C" char *pipamd_quast_to_string(const pipamd_quast *q, int indent) {
+  std::string o;
+  pr_quast(o, q, indent);
+  char *r = (char *)malloc(o.size() + 1);
+  if (r) memcpy(r, o.c_str(), o.size() + 1);
+  return r;
+}
+
+// piplib.c:722-880 pip_solve.  *quast is NULL for "void" (empty context or no domain).
+extern "C" int pipamd_pip_solve(pipamd_engine *e, const pipamd_matrix *inequnk, const pipamd_matrix *ineqpar, int Bg,
+                                const pipamd_options *opt, pipamd_quast **quast, int *status, int64_t *pivots) {
+  if (!e || !quast || !opt) return PIPAMD_E_INVALID;
+  *quast = nullptr;
+  if (status) *status = 0;
+  if (pivots) *pivots = 0;
+  if (!inequnk) return PIPAMD_OK;
+  if (opt->Compute_dual && !opt->Nq) {
+    pipamd_set_error("pipamd_pip_solve: Compute_dual is not supported by the device path");
+    return PIPAMD_E_INVALID;
+  }
+  int Np = ineqpar ? (int)ineqpar->NbColumns - 2 : 0;
+  const int Nn = (int)inequnk->NbColumns - Np - 2;
+  unsigned Nl = inequnk->NbRows;
+  for (unsigned i = 0; i < inequnk->NbRows; i++)
+    if (inequnk->p[i][0] == 0) ++Nl;
+  int Shift = 0, Urs_parms = 0, sol_flags = 0, Nm = 0;
+  if (opt->Maximize) {
+    sol_flags |= SOL_MAX;
+    Shift = 1;
+  } else if (opt->Urs_unknowns) {
+    sol_flags |= SOL_SHIFT;
+    Shift = -1;
+  }
+  if (opt->Urs_parms) {
+    Urs_parms = Np - (Bg >= 0);
+    Np += Urs_parms;
+  }
+  if (opt->Maximize || opt->Urs_unknowns) {
+    if (Bg < 0) {
+      Bg = (int)inequnk->NbColumns - 1;
+      Np++;
+      sol_flags |= SOL_REMOVE;
+    }
+  }
+  pipamd_matrix empty;
+  memset(&empty, 0, sizeof empty);
+  empty.NbColumns = 2;
+  TabArr ctx;
+  if (ineqpar) {
+    Nm = (int)ineqpar->NbRows;
+    for (unsigned i = 0; i < ineqpar->NbRows; i++)
+      if (ineqpar->p[i][0] == 0) Nm++;
+    ctx = matrix_to_tab(ineqpar, Nm, Np - Urs_parms, -1, Shift, Bg - Nn - 1, Urs_parms);
+  } else
+    ctx = matrix_to_tab(&empty, 0, Np - Urs_parms, -1, Shift, Bg - Nn - 1, Urs_parms);
+  TabArr ineq = matrix_to_tab(inequnk, (int)Nl, Nn, Nn, Shift, Bg, Urs_parms);
+  if (ctx.width < Np + 1 || ineq.width < Nn + Np + 1) {
+    pipamd_set_error("pipamd_pip_solve: inconsistent matrix shapes");
+    return PIPAMD_E_INVALID;
+  }
+  // our tableaux are exactly (Np+1) resp. (Nn+Np+1) wide
+  auto narrow = [](TabArr &t, int w) {
+    if (t.width == w) return;
+    std::vector<i64> nv((size_t)t.rows * w);
+    for (int r = 0; r < t.rows; r++)
+      for (int c = 0; c < w; c++) nv[(size_t)r * w + c] = t.v[(size_t)r * t.width + c];
+    t.v.swap(nv);
+    t.width = w;
+  };
+  narrow(ctx, Np + 1);
+  narrow(ineq, Nn + Np + 1);
+  if (opt->Nq) {
+    simplify_rows(ctx.v, ctx.rows, ctx.width, Np);
+    simplify_rows(ineq.v, ineq.rows, ineq.width, Nn);
+  }
+  if (Bg >= Nn + Np + 1 || (Bg >= 0 && Bg <= Nn)) {
+    pipamd_set_error("pipamd_pip_solve: bignum column out of range");
+    return PIPAMD_E_INVALID;
+  }
+  if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
+  Tree t(e, opt->Deepest_cut);
+  int rc = PIPAMD_OK;
+  bool non_vide = false;
+  try {
+    non_vide = t.front(Nn, Np, (int)Nl, Nm, Bg, opt->Nq, ineq.v.data(), ctx.v.data());
+  } catch (int code) {
+    rc = code;
+    if (status) *status = t.fail_status;
+    if (rc == PIPAMD_E_SOLVER) pipamd_set_error("solver stopped with status %d", t.fail_status);
+  }
+  if (pivots) *pivots = t.pivots;
+  if (rc) return rc;
+  if (!non_vide) return PIPAMD_OK;
+  if (opt->Simplify) t_simplify(t.tape, 0);
+  size_t xq = 0;
+  *quast = q_quast(t.tape, &xq, nullptr, Bg - Nn - 1, Urs_parms, sol_flags);
+  return PIPAMD_OK;
+}

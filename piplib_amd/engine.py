@@ -174,3 +174,57 @@ class SolverError(RuntimeError):
         super().__init__(f"solver stopped with PIPAMD_ST status {status}")
         self.status = status
         self.pivots = pivots
+
+
+# ---------------------------------------------------------------- pip_solve (PolyLib matrices)
+class PipMatrix(C.Structure):
+    _fields_ = [("NbRows", C.c_uint), ("NbColumns", C.c_uint), ("p", C.POINTER(C.POINTER(C.c_longlong))),
+                ("p_Init", C.POINTER(C.c_longlong)), ("p_Init_size", C.c_int)]
+
+
+class PipOptions(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("Nq", "Verbose", "Simplify", "Deepest_cut", "Maximize", "Urs_parms", "Urs_unknowns", "Compute_dual")]
+
+
+def _matrix(a):
+    """numpy (rows, cols) int64 -> (PipMatrix, keep-alive objects); the reference's layout."""
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    rows, cols = a.shape
+    flat = (C.c_longlong * max(1, rows * cols))(*a.reshape(-1).tolist())
+    ptrs = (C.POINTER(C.c_longlong) * max(1, rows))()
+    for i in range(rows):
+        ptrs[i] = C.cast(C.byref(flat, i * cols * 8), C.POINTER(C.c_longlong))
+    m = PipMatrix(rows, cols, ptrs, flat, rows * cols)
+    return m, (flat, ptrs, a)
+
+
+def pip_solve(engine, domain, context, bignum, **options):
+    """pip_solve(domain, context, bignum, options) -> (pip_quast_print text, pivots).
+    `domain`/`context` are PolyLib-format numpy matrices (first column = eq/ineq marker)."""
+    L = lib()
+    L.pipamd_pip_solve.argtypes = [C.c_void_p, C.POINTER(PipMatrix), C.POINTER(PipMatrix), C.c_int,
+                                   C.POINTER(PipOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int64)]
+    L.pipamd_quast_to_string.restype = C.c_void_p
+    L.pipamd_quast_to_string.argtypes = [C.c_void_p, C.c_int]
+    L.pipamd_quast_free.argtypes = [C.c_void_p]
+    opt = PipOptions(1, 0, 0, 0, 0, 0, 0, 0)
+    for k, v in options.items():
+        setattr(opt, k, int(v))
+    md, keep1 = _matrix(domain)
+    mc, keep2 = _matrix(context)
+    q = C.c_void_p()
+    status = C.c_int(0)
+    piv = C.c_int64(0)
+    rc = L.pipamd_pip_solve(engine._h, C.byref(md), C.byref(mc), int(bignum), C.byref(opt), C.byref(q),
+                            C.byref(status), C.byref(piv))
+    if rc == -5:
+        raise SolverError(status.value, piv.value)
+    _check(rc)
+    s = L.pipamd_quast_to_string(q, 0)
+    text = C.string_at(s).decode()
+    L.pipamd_free(s)
+    L.pipamd_quast_free(q)
+    return text, piv.value

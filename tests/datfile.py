@@ -85,3 +85,61 @@ def read_dat(path):
         out.append(dict(comment="".join(com), nvar=nvar, nparm=nparm, ni=ni, nc=nc, bigparm=bigparm, nq=nq,
                         ineq=ineq.astype(np.int64), ctx=ctx.astype(np.int64)))
     return out
+
+
+def read_pip(path):
+    """The stdin protocol of the reference's example/example.c:72-108: context matrix, bignum,
+    domain matrix (PolyLib format, '#' comments), then option keywords."""
+    lines = open(path, encoding="latin-1").read().split("\n")
+    pos = 0
+
+    def matrix():
+        nonlocal pos
+        while True:
+            s = lines[pos]
+            pos += 1
+            t = s.split()
+            if s.startswith("#") or not t:
+                continue
+            if len(t) >= 2 and t[0].isdigit() and t[1].isdigit():
+                nr, nc = int(t[0]), int(t[1])
+                break
+        m = np.zeros((nr, nc), dtype=np.int64)
+        i = 0
+        while i < nr:
+            s = lines[pos].strip()
+            pos += 1
+            if not s or s.startswith("#"):
+                continue
+            m[i] = [int(x) for x in s.split()[:nc]]
+            i += 1
+        return m
+
+    context = matrix()
+    while not lines[pos].strip():
+        pos += 1
+    bignum = int(lines[pos].split()[0])
+    pos += 1
+    domain = matrix()
+    opts = {}
+    for s in lines[pos:]:
+        low = s.lower()
+        if low.startswith("maximize"):
+            opts["Maximize"] = 1
+        if low.startswith("urs_parms"):
+            opts["Urs_parms"] = 1
+        if low.startswith("urs_unknowns"):
+            opts["Urs_unknowns"] = 1
+        if low.startswith("rational"):
+            opts["Nq"] = 0
+        if low.startswith("dual"):
+            opts["Compute_dual"] = 1
+    return context, bignum, domain, opts
+
+
+def matrix_text(m):
+    """pip_matrix_print (piplib.c:176-190)"""
+    out = [f"{m.shape[0]} {m.shape[1]}\n"]
+    for r in m:
+        out.append("".join(f" {int(v)}" for v in r) + "\n")
+    return "".join(out)

@@ -50,3 +50,22 @@ def test_ref_generated_on_gpu(key):
     else:
         assert status is None
     assert pb.squash(got) == pb.squash(want)
+
+
+from test_oracle_golden import PIPTEST_PIP  # noqa: E402
+
+
+@pytest.mark.parametrize("name", PIPTEST_PIP)
+def test_pip_solve_golden_on_gpu(name):
+    """example/*.pip through pipamd_pip_solve (PolyLib matrices in, PipQuast out) vs example/*.ll."""
+    from datfile import read_pip, matrix_text
+    from piplib_amd import engine as eng
+    context, bignum, domain, opts = read_pip(os.path.join(G, "example", name + ".pip"))
+    e = eng.Engine(0)
+    bg = bignum + (domain.shape[1] - context.shape[1]) if bignum > 0 else bignum
+    text, _ = eng.pip_solve(e, domain, context, bg, **opts)
+    got = ("[PIP2-like future input] Please enter:\n- the context matrix,\n" + matrix_text(context) +
+           "- the bignum column (start at 0, -1 if no bignum),\n" + f"{bignum}\n" +
+           "- the constraint matrix.\n" + matrix_text(domain) + "\n" + text)
+    want = open(os.path.join(G, "example", name + ".ll"), encoding="latin-1").read()
+    assert pb.squash(got) == pb.squash(want)

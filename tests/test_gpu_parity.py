@@ -21,3 +21,48 @@ def test_lexmin_batch_vs_oracle(seed, batch, nvar, ni, nq, kw):
     rows = synth.lexmin_batch(seed, batch, nvar, ni, **kw)
     n, piv = compare(rows, nvar, 0, nq)
     assert n == batch and piv > 0
+
+
+@pytest.mark.parametrize("seed,nvar,nparm,ni,nc,nq,deepest", [
+    (21, 5, 2, 7, 2, 1, 0), (22, 5, 2, 7, 2, 0, 0), (23, 4, 3, 6, 3, 1, 0), (24, 3, 1, 5, 1, 1, 0),
+    (25, 6, 0, 8, 0, 1, 1), (26, 5, 2, 7, 2, 1, 1), (27, 8, 2, 10, 1, 1, 0), (28, 6, 4, 8, 2, 1, 0),
+])
+def test_random_parametric_vs_oracle(seed, nvar, nparm, ni, nc, nq, deepest):
+    """Host decision tree + HIP engine (pipamd_solve_tableau) vs the CPU oracle on random
+    parametric problems: same text (splits, newparms, nil leaves), same pivot count, and the
+    same abort verdict where the reference would exit."""
+    import pipbatch as pb
+    from piplib_amd import engine as eng
+    from piplib_amd import synth
+    import subprocess
+    probs, results = [], []
+    for p in synth.random_problems(seed, 40, nvar, nparm, ni, nc, nq):
+        # some random parametric problems make the reference itself cut forever: keep the
+        # ones the CPU oracle finishes promptly
+        try:
+            r = pb.run_batch(pb.ORACLEPIP, [p], pb.F_DEEPEST if deepest else 0, timeout=2).results[0]
+        except subprocess.TimeoutExpired:
+            continue
+        if r.pivots <= 3000:
+            probs.append(p)
+            results.append(r)
+    assert len(probs) >= 20
+
+    class o:  # noqa: N801
+        pass
+    o.results = results
+    e = eng.Engine(0)
+    nontrivial = 0
+    for i, (p, r) in enumerate(zip(probs, o.results)):
+        try:
+            text, piv = eng.solve_tableau(e, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx,
+                                          simplify=True, deepest_cut=bool(deepest))
+        except eng.SolverError as ex:
+            assert r.status == pb.ST_ABORT, (i, ex.status)
+            continue
+        assert r.status != pb.ST_ABORT, i
+        want = "void" if r.status == pb.ST_VOID else pb.squash(r.text)
+        assert pb.squash(text) == want, (i, text[:200], r.text[:200])
+        assert piv == r.pivots, (i, piv, r.pivots)
+        nontrivial += "if" in text or "newparm" in text
+    assert nparm == 0 or nontrivial > 0
