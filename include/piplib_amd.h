@@ -96,6 +96,8 @@ typedef struct pipamd_batch_desc {
   int32_t tflags;      /* PIPAMD_T_INT ... */
   int32_t cap_cuts;    /* spare rows per tableau for Gomory cuts */
   int32_t cap_newparm; /* spare columns per tableau (parametric cuts) */
+  int32_t entier_bits; /* 0 or 64: int64 entries (the reference's long long build);
+                          128: __int128 entries, same algorithm, overflow-safe variant */
 } pipamd_batch_desc;
 
 /* bytes of device workspace the batch needs (tableaux + row tables + job table + results) */
@@ -113,7 +115,8 @@ int pipamd_batch_solve(pipamd_engine *e, void *d_workspace, const pipamd_batch_d
 
 /* Copy out, device to device: status[b], pivots[b], cuts[b] (int32 each, may be NULL),
  * sol_num[b][i][0..nparm] (parameter coefficients then constant, as solution() emits them,
- * traiter.c:255-271) and sol_den[b][i], i < nvar (int64). */
+ * traiter.c:255-271) and sol_den[b][i], i < nvar: int64 each, or little-endian pairs of
+ * int64 (low, high) per value when entier_bits == 128. */
 int pipamd_batch_results(pipamd_engine *e, const void *d_workspace, const pipamd_batch_desc *d,
                          int32_t *d_status, int32_t *d_pivots, int32_t *d_cuts, int64_t *d_sol_num,
                          int64_t *d_sol_den, void *stream);

@@ -64,6 +64,13 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
     return PIPAMD_E_INVALID;
   }
   const int ncol = d->nvar + d->nparm + 1;
+  const int ebits = d->entier_bits == 128 ? 128 : 64;
+  if (d->entier_bits != 0 && d->entier_bits != 64 && d->entier_bits != 128) {
+    pipamd_set_error("entier_bits must be 0 (= 64), 64 or 128");
+    return PIPAMD_E_INVALID;
+  }
+  const int ew = ebits / 64;
+  lay->ebits = ebits;
   lay->batch = d->batch;
   lay->nvar = d->nvar;
   lay->nparm = d->nparm;
@@ -72,7 +79,7 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
   lay->tflags = d->tflags;
   lay->S = d->ni + d->cap_cuts;
   lay->L = round_even(d->nvar + lay->S);
-  lay->W = round_even(ncol + d->cap_newparm);
+  lay->W = ebits == 128 ? ncol + d->cap_newparm : round_even(ncol + d->cap_newparm);
   if (lay->L > PIPAMD_LMAX || lay->S > PIPAMD_SMAX || lay->W > PIPAMD_MAXCOL || lay->S < 1) {
     pipamd_set_error("batch shape exceeds engine limits (L=%d<=%d, S=%d<=%d, W=%d<=%d)", lay->L, PIPAMD_LMAX, lay->S,
                      PIPAMD_SMAX, lay->W, PIPAMD_MAXCOL);
@@ -82,12 +89,15 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
     pipamd_set_error("bigparm must be -1 or a parameter column (nvar < bigparm < ncol)");
     return PIPAMD_E_INVALID;
   }
-  const int64_t sol = round_even(d->nvar * (d->nparm + d->cap_newparm + 1) + d->nvar);
-  const int nm = lay->W <= 128 ? 2 : (lay->W <= 256 ? 4 : 8);
+  const int64_t sol = round_even((d->nvar * (d->nparm + d->cap_newparm + 1) + d->nvar) * ew);
+  const int wp = ebits == 128 ? (lay->W <= 64 ? 64 : (lay->W <= 128 ? 128 : (lay->W <= 256 ? 256 : 512)))
+                              : (lay->W <= 128 ? 128 : (lay->W <= 256 ? 256 : 512));
+  const int nm = wp / 64;
   const int64_t state = round_even(lay->S * nm + (3 * lay->L + 7) / 8);
   lay->sol_words = (int32_t)sol;
   lay->state_words = (int32_t)state;
-  lay->per_job = 2 * (int64_t)lay->L + (int64_t)lay->S * lay->W + sol + state;
+  // rows: den[L] (entry type) | flag[L] | ref[L];  then S x W entries;  solution;  saved summaries
+  lay->per_job = ((int64_t)lay->L * ew + lay->L) + (int64_t)lay->S * lay->W * ew + sol + state;
   lay->arena_off = 0;
   *jobs_bytes = ((size_t)d->batch * sizeof(PipJob) + 255) & ~(size_t)255;
   return PIPAMD_OK;
@@ -102,7 +112,7 @@ extern "C" size_t pipamd_batch_workspace_bytes(const pipamd_batch_desc *d) {
 
 extern "C" size_t pipamd_pivot_bytes(const pipamd_batch_desc *d) {
   // one pivot reads and writes every real row once: 2 * ni * ncol * sizeof(Entier)
-  return 2ull * (size_t)d->ni * (size_t)(d->nvar + d->nparm + 1) * sizeof(int64_t);
+  return 2ull * (size_t)d->ni * (size_t)(d->nvar + d->nparm + 1) * (d->entier_bits == 128 ? 16 : 8);
 }
 
 extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, const int64_t *d_rows,
@@ -158,7 +168,7 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
       e->nev++;
     }
     HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch], st));
-    HIPCHK(pipk_launch_advance(jobs, arena, lay.batch, lmax, smax, lay.W, budget, waves, e->d_prof, st));
+    HIPCHK(pipk_launch_advance(jobs, arena, lay.batch, lmax, smax, lay.W, budget, waves, lay.ebits, e->d_prof, st));
     HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
     e->nlaunch++;
     HIPCHK(pipk_launch_batch_running(jobs, lay.batch, e->d_run, st));
@@ -205,8 +215,8 @@ extern "C" int pipamd_batch_results(pipamd_engine *e, const void *d_ws, const pi
   if (rc) return rc;
   const PipJob *jobs = (const PipJob *)d_ws;
   const long long *arena = (const long long *)((const char *)d_ws + jb);
-  HIPCHK(pipk_launch_batch_results(jobs, arena, lay.batch, lay.nvar, lay.nparm, d_status, d_pivots, d_cuts,
-                                   (long long *)d_sol_num, (long long *)d_sol_den, (hipStream_t)stream));
+  HIPCHK(pipk_launch_batch_results(jobs, arena, lay.batch, lay.nvar, lay.nparm, lay.ebits, d_status, d_pivots, d_cuts,
+                                   (void *)d_sol_num, (void *)d_sol_den, (hipStream_t)stream));
   return PIPAMD_OK;
 }
 

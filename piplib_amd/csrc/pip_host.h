@@ -27,11 +27,11 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
 
 extern "C" {
 hipError_t pipk_launch_advance(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
-                               int waves_per_job, unsigned long long *prof, hipStream_t stream);
+                               int waves_per_job, int ebits, unsigned long long *prof, hipStream_t stream);
 hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long long *rows, PipBatchLayout lay,
                                   hipStream_t stream);
 hipError_t pipk_launch_batch_results(const PipJob *jobs, const long long *arena, int njobs, int nvar, int nparm,
-                                     int *status, int *pivots, int *cuts, long long *sol_num, long long *sol_den,
+                                     int ebits, int *status, int *pivots, int *cuts, void *sol_num, void *sol_den,
                                      hipStream_t stream);
 hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, int *out2, hipStream_t stream);
 hipError_t pipk_launch_batch_counters(const PipJob *jobs, int njobs, unsigned long long *out, hipStream_t stream);

@@ -25,9 +25,10 @@ typedef struct PipJob {
   int32_t L, S, W;
   int32_t status, aux, npiv, ncut;
   int32_t ldet, nupd; /* nupd: rows rewritten by pivots so far (excludes skipped zero-multiplier rows) */
-  int64_t det[PIPAMD_MAXDET]; /* multi-limb determinant, tab.h:76-81 */
+  int64_t det[2 * PIPAMD_MAXDET]; /* multi-limb determinant, tab.h:76-81: det[i] (64-bit entries) or
+                                     det[2i] | det[2i+1] << 64 (128-bit entries) */
   uint64_t maxabs;
-  int32_t state_nch, pad1; /* row-chunk count (NCH) of the launch that saved the state block */
+  int32_t state_nch, ebits; /* ebits: 64 or 128 (0 = 64) */ /* row-chunk count (NCH) of the launch that saved the state block */
 } PipJob;
 
 typedef struct PipBatchLayout {
@@ -36,6 +37,7 @@ typedef struct PipBatchLayout {
   int32_t batch, nvar, nparm, ni, bigparm, tflags;
   int32_t L, S, W;
   int32_t sol_words, state_words;
+  int32_t ebits, pad;
 } PipBatchLayout;
 
 #endif

@@ -35,6 +35,23 @@
 
 typedef long long i64;
 typedef unsigned long long u64;
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+// Entry ("Entier") type traits.  int64: the reference's `long long` build, two columns per
+// lane and chunk (16 B); int128: the overflow-safe variant, one column per lane and chunk.
+template <class T>
+struct ET;
+template <>
+struct ET<i64> {
+  typedef u64 U;
+  static constexpr int BITS = 64, CPL = 2, EW = 1;
+};
+template <>
+struct ET<i128> {
+  typedef u128 U;
+  static constexpr int BITS = 128, CPL = 1, EW = 2;
+};
 typedef unsigned short u16;
 typedef unsigned char u8;
 
@@ -99,6 +116,7 @@ __device__ __forceinline__ i64 readlane64(i64 v, int src) {
   unsigned hi = __builtin_amdgcn_readlane((unsigned)((u64)v >> 32), src);
   return (i64)(((u64)hi << 32) | lo);
 }
+
 // C '/' and '%' made total (the CPU traps on x / 0 and MIN / -1).
 __device__ __forceinline__ i64 cquo(i64 a, i64 b) {
   if (b == 1) return a;
@@ -149,6 +167,102 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
   return v;
 }
 
+// ---------------------------------------------------------------- 128-bit counterparts
+__device__ __forceinline__ u128 uabs64(i128 x) { return x < 0 ? (u128)0 - (u128)x : (u128)x; }
+__device__ __forceinline__ i128 wmul(i128 a, i128 b) { return (i128)((u128)a * (u128)b); }
+__device__ __forceinline__ i128 wsub(i128 a, i128 b) { return (i128)((u128)a - (u128)b); }
+__device__ __forceinline__ i128 wadd(i128 a, i128 b) { return (i128)((u128)a + (u128)b); }
+__device__ __forceinline__ i128 wneg(i128 a) { return (i128)((u128)0 - (u128)a); }
+__device__ __forceinline__ int ctz128(u128 x) {
+  u64 lo = (u64)x;
+  return lo ? __builtin_ctzll(lo) : 64 + __builtin_ctzll((u64)(x >> 64));
+}
+__device__ __forceinline__ int bitlen64(u128 x) {
+  u64 hi = (u64)(x >> 64);
+  return hi ? 128 - __builtin_clzll(hi) : bitlen64((u64)x);
+}
+__device__ __forceinline__ bool fits64(i128 x) { return (i128)(i64)x == x; }
+__device__ __forceinline__ u128 gcd_mag(u128 a, u128 b) {
+  if (((a | b) >> 64) == 0) return gcd_mag((u64)a, (u64)b);
+  if (a == 0) return b;
+  if (b == 0) return a;
+  int sh = ctz128(a | b);
+  a >>= ctz128(a);
+  do {
+    b >>= ctz128(b);
+    if (a > b) {
+      u128 t = a;
+      a = b;
+      b = t;
+    }
+    b -= a;
+  } while (b);
+  return a << sh;
+}
+__device__ __forceinline__ i128 gcd_i64(i128 a, i128 b) { return (i128)gcd_mag(uabs64(a), uabs64(b)); }
+__device__ __forceinline__ u128 inv_odd64(u128 m) {
+  u128 x = m;  // 3 correct bits, doubled by every Newton step
+  for (int i = 0; i < 6; i++) x *= 2 - m * x;
+  return x;
+}
+// every division on the pivot path is exact (piplib_int_div_exact of a gcd): shift + odd inverse
+__device__ __forceinline__ i128 cquo(i128 a, i128 b) {
+  if (b == 1) return a;
+  if (b == 0) return 0;
+  if (fits64(a) && fits64(b)) return (i128)cquo((i64)a, (i64)b);
+  const bool neg = b < 0;
+  u128 ub = uabs64(b);
+  int s = ctz128(ub);
+  i128 q = (i128)((u128)(a >> s) * inv_odd64(ub >> s));
+  return neg ? wneg(q) : q;
+}
+__device__ __forceinline__ u128 umod128(u128 a, u128 g) {
+  if (((a | g) >> 64) == 0) return (u64)a % (u64)g;
+  if (a < g) return a;
+  u128 rem = 0;
+  for (int i = bitlen64(a) - 1; i >= 0; i--) {
+    rem = (rem << 1) | ((a >> i) & 1);
+    if (rem >= g) rem -= g;
+  }
+  return rem;
+}
+__device__ __forceinline__ i128 crem(i128 a, i128 b) {
+  if (b == 0 || b == -1 || b == 1) return 0;
+  if (fits64(a) && fits64(b)) return (i128)crem((i64)a, (i64)b);
+  u128 r = umod128(uabs64(a), uabs64(b));
+  return a < 0 ? wneg((i128)r) : (i128)r;  // C remainder: sign of the dividend
+}
+__device__ __forceinline__ i128 fmod64(i128 a, i128 b) {
+  i128 m = crem(a, b);
+  if (m < 0) m = wadd(m, (i128)uabs64(b));
+  return m;
+}
+__device__ __forceinline__ int log2_64(i128 x) {
+  u128 u = uabs64(x);
+  return u == 0 ? 1 : bitlen64(u);
+}
+__device__ __forceinline__ int sign_code(i128 x) { return x > 0 ? 1 : (x < 0 ? 2 : 0); }
+__device__ __forceinline__ i128 readlane64(i128 v, int src) {
+  u64 lo = (u64)readlane64((i64)(u64)(u128)v, src), hi = (u64)readlane64((i64)(u64)((u128)v >> 64), src);
+  return (i128)(((u128)hi << 64) | lo);
+}
+__device__ __forceinline__ i128 uni64(i128 v) {
+  u64 lo = (u64)uni64((i64)(u64)(u128)v), hi = (u64)uni64((i64)(u64)((u128)v >> 64));
+  return (i128)(((u128)hi << 64) | lo);
+}
+__device__ __forceinline__ u128 umod_small(u128 a, u128 g, bool small32) {
+  (void)small32;
+  return umod128(a, g);
+}
+__device__ __forceinline__ u64 umod_small(u64 a, u64 g, bool small32) {
+  return small32 ? (u64)((unsigned)a % (unsigned)g) : a % g;
+}
+__device__ __forceinline__ double to_double(i64 x) { return (double)x; }
+__device__ __forceinline__ double to_double(i128 x) {
+  const u128 m = uabs64(x);  // via the magnitude: hi*2^64 + lo on a negative value would cancel
+  const double d = (double)(u64)(m >> 64) * 18446744073709551616.0 + (double)(u64)m;
+  return x < 0 ? -d : d;
+}
 // workgroup barrier; a single-wave workgroup only needs the compiler to keep LDS order
 template <int NW>
 __device__ __forceinline__ void bsync() {
@@ -189,14 +303,33 @@ __device__ __forceinline__ void bsync() {
 #define PROF_FLUSH(buf)
 #endif
 
+template <class T>
+__device__ __forceinline__ int colof(int c, int lane, int h) {
+  return c * (64 * ET<T>::CPL) + ET<T>::CPL * lane + h;
+}
+__device__ __forceinline__ int ctzU(u64 x) { return __builtin_ctzll(x); }
+__device__ __forceinline__ int ctzU(u128 x) { return ctz128(x); }
+// magnitude classes: every entry of a class-c row is below 2^cls_bits(c)
+template <class T>
+__device__ __forceinline__ int cls_bits(int c) {
+  return c < 3 ? (ET<T>::BITS / 4) * (c + 1) - 1 : ET<T>::BITS;
+}
+template <class T>
+__device__ __forceinline__ int cls_of(typename ET<T>::U orall) {  // wave-collective: class of the OR of all lanes
+  constexpr int B4 = ET<T>::BITS / 4;
+  return __ballot((orall >> (3 * B4 - 1)) != 0) ? 3
+         : (__ballot((orall >> (2 * B4 - 1)) != 0) ? 2 : (__ballot((orall >> (B4 - 1)) != 0) ? 1 : 0));
+}
+
 // LDS image of one job.  L = logical rows, S = row slots (real rows), WP = NCH*128 columns,
 // NM = 2*NCH mask words per row.  Column j of a row is owned by lane (j%128)/2 of the wave
 // that holds the row, register (c = j/128, h = j&1); a row's non-zero bitmap uses the same
 // geometry: word 2c+h, bit (j%128)/2.  Everything that only real rows have is indexed by
 // slot, so the per-pivot loops run over the real rows only.
+template <class T>
 struct Shared {
-  i64 *den;     // [S]  denominator of the row in slot s
-  i64 *prow;    // [WP] pivot row (zero beyond ncol)
+  T *den;     // [S]  denominator of the row in slot s
+  T *prow;      // [WP] pivot row (zero beyond ncol)
   u64 *nzm;     // [S][NM] non-zero bitmap
   float *size;  // [S]  tab_sort_rows key (entry only)
   u16 *sig;     // [S]  sign summary
@@ -209,8 +342,6 @@ struct Shared {
   u8 *rcls;     // [S]  magnitude class of the row's largest entry (see CLS_BITS)
   u8 *uflag;    // [L]  flag of a unit row (Unit or Unit|Zero)
 };
-// magnitude classes: every entry of a class-c row is below 2^CLS_BITS[c]
-__device__ __forceinline__ int cls_bits(int c) { return c == 0 ? 15 : (c == 1 ? 31 : (c == 2 ? 47 : 64)); }
 
 struct Scalars {
   int pivi, pivi2, pivj, tmp, tmp2, aux;
@@ -218,36 +349,45 @@ struct Scalars {
   u64 smaxbits;
 };
 
-template <int NCH>
+template <class T, int NCH>
 struct RowRegs {
-  i64 v[NCH][2];
+  T v[NCH][ET<T>::CPL];
 };
 
-// ---- coalesced row access: lane l of a wave owns columns c*128 + 2l, +1 ----
-template <int NCH>
-__device__ __forceinline__ void row_load(RowRegs<NCH> &r, const i64 *row, int ncolp, int lane) {
+// ---- coalesced row access, 16 B per lane: lane l of a wave owns columns colof(c, l, h) ----
+template <class T, int NCH>
+__device__ __forceinline__ void row_load(RowRegs<T, NCH> &r, const T *row, int ncolp, int lane) {
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
-    int j0 = c * 128 + 2 * lane;
+    int j0 = colof<T>(c, lane, 0);
     if (j0 < ncolp) {
       const longlong2 t = *reinterpret_cast<const longlong2 *>(row + j0);
-      r.v[c][0] = t.x;
-      r.v[c][1] = t.y;
+      if constexpr (ET<T>::CPL == 2) {
+        r.v[c][0] = t.x;
+        r.v[c][1] = t.y;
+      } else {
+        r.v[c][0] = (T)(((u128)(u64)t.y << 64) | (u64)t.x);
+      }
     } else {
-      r.v[c][0] = 0;
-      r.v[c][1] = 0;
+#pragma unroll
+      for (int h = 0; h < ET<T>::CPL; h++) r.v[c][h] = 0;
     }
   }
 }
-template <int NCH>
-__device__ __forceinline__ void row_store(const RowRegs<NCH> &r, i64 *row, int ncolp, int lane) {
+template <class T, int NCH>
+__device__ __forceinline__ void row_store(const RowRegs<T, NCH> &r, T *row, int ncolp, int lane) {
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
-    int j0 = c * 128 + 2 * lane;
+    int j0 = colof<T>(c, lane, 0);
     if (j0 < ncolp) {
       longlong2 t;
-      t.x = r.v[c][0];
-      t.y = r.v[c][1];
+      if constexpr (ET<T>::CPL == 2) {
+        t.x = r.v[c][0];
+        t.y = r.v[c][1];
+      } else {
+        t.x = (i64)(u64)(u128)r.v[c][0];
+        t.y = (i64)(u64)((u128)r.v[c][0] >> 64);
+      }
       *reinterpret_cast<longlong2 *>(row + j0) = t;
     }
   }
@@ -255,19 +395,19 @@ __device__ __forceinline__ void row_store(const RowRegs<NCH> &r, i64 *row, int n
 
 // Sign summary, non-zero bitmap and magnitude class of a row held in registers
 // (wave-collective).  Lane 0 publishes them for slot s.
-template <int NCH>
-__device__ __forceinline__ void row_publish(const RowRegs<NCH> &r, const Shared &S, int s, int nvar, int ncol,
+template <class T, int NCH>
+__device__ __forceinline__ void row_publish(const RowRegs<T, NCH> &r, const Shared<T> &S, int s, int nvar, int ncol,
                                             int bigparm, int pivj, int extra_sig, bool has_parm, int lane) {
   int cs = 0, bs = 0, ps = 0;
   bool ppos = false, pneg = false;
-  u64 mx = 0;
-  u64 nz[2 * NCH];
+  typename ET<T>::U mx = 0;
+  u64 nz[NCH * ET<T>::CPL];
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      int j = c * 128 + 2 * lane + h;
-      i64 z = r.v[c][h];
+    for (int h = 0; h < ET<T>::CPL; h++) {
+      int j = colof<T>(c, lane, h);
+      T z = r.v[c][h];
       mx |= uabs64(z);
       if (j == nvar) cs = sign_code(z);
       if (j == pivj) ps = sign_code(z);
@@ -278,7 +418,7 @@ __device__ __forceinline__ void row_publish(const RowRegs<NCH> &r, const Shared 
           pneg |= z < 0;
         }
       }
-      nz[2 * c + h] = __ballot(z != 0);
+      nz[ET<T>::CPL * c + h] = __ballot(z != 0);
     }
   int sig = extra_sig;
   sig |= (__ballot(cs == 1) ? 1 : 0) | (__ballot(cs == 2) ? 2 : 0);
@@ -287,12 +427,12 @@ __device__ __forceinline__ void row_publish(const RowRegs<NCH> &r, const Shared 
     sig |= (__ballot(ppos) ? 4 : 0) | (__ballot(pneg) ? 8 : 0);
     sig |= (__ballot(bs == 1) ? 16 : 0) | (__ballot(bs == 2) ? 32 : 0);
   }
-  const int cls = __ballot((mx >> 47) != 0) ? 3 : (__ballot((mx >> 31) != 0) ? 2 : (__ballot((mx >> 15) != 0) ? 1 : 0));
+  const int cls = cls_of<T>(mx);
   if (lane == 0) {
     S.sig[s] = (u16)sig;
     S.rcls[s] = (u8)cls;
 #pragma unroll
-    for (int e = 0; e < 2 * NCH; e++) S.nzm[(size_t)s * (2 * NCH) + e] = nz[e];
+    for (int e = 0; e < NCH * ET<T>::CPL; e++) S.nzm[(size_t)s * (NCH * ET<T>::CPL) + e] = nz[e];
   }
 }
 
@@ -303,59 +443,56 @@ __device__ __forceinline__ void row_publish(const RowRegs<NCH> &r, const Shared 
 // 1; gcd is associative, so any evaluation order gives the same g.  We refine
 // g downwards: reduce every z modulo the current g, fold in one non-zero
 // remainder, repeat until all remainders vanish (typically <= 2 rounds).
-template <int NCH>
-__device__ __forceinline__ bool update_row(RowRegs<NCH> &r, const i64 *prow, int pivj, i64 lpiv, i64 foo, i64 dpiv,
-                                           i64 g0, int lane, i64 &newden) {
-  u64 mx = 0;
+template <class T, int NCH>
+__device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, int pivj, T lpiv, T foo, T dpiv, T g0,
+                                           int lane, T &newden) {
+  typedef typename ET<T>::U U;
+  constexpr int CPL = ET<T>::CPL;
+  (void)CPL;
+  U mx = 0;
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      int j = c * 128 + 2 * lane + h;
-      i64 q = prow[j];
-      i64 z = wsub(wmul(r.v[c][h], lpiv), wmul(q, foo));
+    for (int h = 0; h < ET<T>::CPL; h++) {
+      int j = colof<T>(c, lane, h);
+      T q = prow[j];
+      T z = wsub(wmul(r.v[c][h], lpiv), wmul(q, foo));
       if (j == pivj) z = wmul(dpiv, foo);
       r.v[c][h] = z;
       mx |= uabs64(z);
     }
   newden = g0;
   if (g0 == 1) return true;
-  u64 g = (u64)uni64((i64)uabs64(g0));
+  U g = (U)uni64((T)uabs64(g0));
   // 32-bit remainders when everything fits (the common case): one v_rcp-based
   // division instead of the 64-bit software routine
   const bool small = (__ballot((mx >> 32) != 0) == 0) && (g >> 32) == 0;
   for (;;) {
-    u64 rr = 0;
+    U rr = 0;
 #pragma unroll
     for (int c = 0; c < NCH; c++)
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        u64 a = uabs64(r.v[c][h]);
-        u64 m;
-        if (g == 0)
-          m = a;
-        else if (small)
-          m = (unsigned)a % (unsigned)g;
-        else
-          m = a % g;
+      for (int h = 0; h < ET<T>::CPL; h++) {
+        U a = uabs64(r.v[c][h]);
+        U m = g == 0 ? a : umod_small(a, g, small);
         rr = rr ? rr : m;
       }
     u64 nz = __ballot(rr != 0);
     if (!nz) break;
     int src = __ffsll((long long)nz) - 1;
-    u64 r0 = (u64)readlane64((i64)rr, src);
+    U r0 = (U)readlane64((T)rr, src);
     g = gcd_mag(g, r0);
     if (g == 1) break;
   }
   if (g == 1) return true;
   if (g == 0) return false;  // the reference would divide by zero here
-  int s = __builtin_ctzll(g);
-  u64 inv = inv_odd64(g >> s);
+  int s = ctzU(g);
+  U inv = inv_odd64(g >> s);
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
-    for (int h = 0; h < 2; h++) r.v[c][h] = (i64)((u64)(r.v[c][h] >> s) * inv);
-  newden = (i64)((u64)(g0 >> s) * inv);
+    for (int h = 0; h < ET<T>::CPL; h++) r.v[c][h] = (T)((U)(r.v[c][h] >> s) * inv);
+  newden = (T)((U)(g0 >> s) * inv);
   return true;
 }
 
@@ -373,8 +510,8 @@ __device__ __forceinline__ int exam_class(int sg) {
 // traiter.c:101-159, general form (used when there is a big parameter).  Block-collective;
 // returns the first row proven negative or BIG_I.  Rows are visited in logical order, which
 // for the slot-indexed tables means "compare srow[s]".
-template <int NW>
-__device__ int exam_rows(const Shared &S, Scalars *sc, int ni) {
+template <class T, int NW>
+__device__ int exam_rows(const Shared<T> &S, Scalars *sc, int ni) {
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
   if (tid == 0) sc->tmp = BIG_I;
@@ -424,26 +561,26 @@ __device__ int exam_rows(const Shared &S, Scalars *sc, int ni) {
 // and stop when one column is left.  Executed by wave 0 only; `prow` holds the
 // pivot row in the wave's lane geometry.
 // Exact while (max a_j) * (max |entry|) < 2^62, which the caller guarantees.
-template <int NCH>
-__device__ int choose_column(const Shared &S, const RowRegs<NCH> &prow, const i64 *vals, int W, int nvar, int nligne,
+template <class T, int NCH>
+__device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, const T *vals, int W, int nvar, int nligne,
                              int pivi, int ncolp, Scalars *sc) {
-  constexpr int NM = 2 * NCH;
+  constexpr int NM = NCH * ET<T>::CPL;
   const int lane = threadIdx.x & 63;
-  i64 a[NCH][2];
-  int u[NCH][2];
-  bool cand[NCH][2];
+  T a[NCH][ET<T>::CPL];
+  int u[NCH][ET<T>::CPL];
+  bool cand[NCH][ET<T>::CPL];
   u64 cm[NM];
   int count = 0;
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      int j = c * 128 + 2 * lane + h;
+    for (int h = 0; h < ET<T>::CPL; h++) {
+      int j = colof<T>(c, lane, h);
       a[c][h] = j < nvar ? prow.v[c][h] : 0;
       cand[c][h] = a[c][h] > 0;
       u[c][h] = cand[c][h] ? (int)S.urow[j] : -1;
-      cm[2 * c + h] = __ballot(cand[c][h]);
-      count += __popcll(cm[2 * c + h]);
+      cm[ET<T>::CPL * c + h] = __ballot(cand[c][h]);
+      count += __popcll(cm[ET<T>::CPL * c + h]);
     }
   if (count == 0) return -1;
   for (int k0 = 0; k0 < nligne && count > 1; k0 += 64) {
@@ -469,15 +606,15 @@ __device__ int choose_column(const Shared &S, const RowRegs<NCH> &prow, const i6
 #pragma unroll
       for (int c = 0; c < NCH; c++)
 #pragma unroll
-        for (int h = 0; h < 2; h++) nel += __popcll(__ballot(cand[c][h] && u[c][h] < kk));
+        for (int h = 0; h < ET<T>::CPL; h++) nel += __popcll(__ballot(cand[c][h] && u[c][h] < kk));
       if (nel == count) goto last_unit_wins;
       if (nel) {
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
-          for (int h = 0; h < 2; h++) {
+          for (int h = 0; h < ET<T>::CPL; h++) {
             if (u[c][h] < kk) cand[c][h] = false;
-            cm[2 * c + h] = __ballot(cand[c][h]);
+            cm[ET<T>::CPL * c + h] = __ballot(cand[c][h]);
           }
         count -= nel;
         if (count == 1) break;
@@ -489,17 +626,17 @@ __device__ int choose_column(const Shared &S, const RowRegs<NCH> &prow, const i6
         if (!x) continue;
       }
       // real row kk: keep the minimal ratios
-      RowRegs<NCH> n;
-      row_load<NCH>(n, vals + (size_t)sl * W, ncolp, lane);
+      RowRegs<T, NCH> n;
+      row_load<T, NCH>(n, vals + (size_t)sl * W, ncolp, lane);
       for (;;) {
         // reference column b = first remaining candidate
-        i64 ab = 0, nb = 0;
+        T ab = 0, nb = 0;
         bool got = false;
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
-          for (int h = 0; h < 2; h++) {
-            u64 m = cm[2 * c + h];
+          for (int h = 0; h < ET<T>::CPL; h++) {
+            u64 m = cm[ET<T>::CPL * c + h];
             if (!got && m) {
               int src = __ffsll((long long)m) - 1;
               ab = readlane64(a[c][h], src);
@@ -507,13 +644,13 @@ __device__ int choose_column(const Shared &S, const RowRegs<NCH> &prow, const i6
               got = true;
             }
           }
-        bool neg[NCH][2];
+        bool neg[NCH][ET<T>::CPL];
         int nneg = 0, nzero = 0;
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
-          for (int h = 0; h < 2; h++) {
-            i64 x = wsub(wmul(ab, n.v[c][h]), wmul(nb, a[c][h]));
+          for (int h = 0; h < ET<T>::CPL; h++) {
+            T x = wsub(wmul(ab, n.v[c][h]), wmul(nb, a[c][h]));
             neg[c][h] = cand[c][h] && x < 0;
             bool zero = cand[c][h] && x == 0;
             nneg += __popcll(__ballot(neg[c][h]));
@@ -526,13 +663,13 @@ __device__ int choose_column(const Shared &S, const RowRegs<NCH> &prow, const i6
 #pragma unroll
           for (int c = 0; c < NCH; c++)
 #pragma unroll
-            for (int h = 0; h < 2; h++) cand[c][h] = neg[c][h];
+            for (int h = 0; h < ET<T>::CPL; h++) cand[c][h] = neg[c][h];
           count = nneg;
         }
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
-          for (int h = 0; h < 2; h++) cm[2 * c + h] = __ballot(cand[c][h]);
+          for (int h = 0; h < ET<T>::CPL; h++) cm[ET<T>::CPL * c + h] = __ballot(cand[c][h]);
         if (nneg == 0 || count == 1) break;
       }
     }
@@ -541,7 +678,7 @@ __device__ int choose_column(const Shared &S, const RowRegs<NCH> &prow, const i6
     int res = -1;
 #pragma unroll
     for (int e = 0; e < NM; e++)
-      if (cm[e]) res = (e >> 1) * 128 + 2 * (__ffsll((long long)cm[e]) - 1) + (e & 1);
+      if (cm[e]) res = colof<T>(e / ET<T>::CPL, __ffsll((long long)cm[e]) - 1, e % ET<T>::CPL);
     return res;
   }
 last_unit_wins:
@@ -551,8 +688,8 @@ last_unit_wins:
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
-    for (int h = 0; h < 2; h++)
-      if (cand[c][h]) atomicMax(&sc->tmp2, (u[c][h] << 10) | (c * 128 + 2 * lane + h));
+    for (int h = 0; h < ET<T>::CPL; h++)
+      if (cand[c][h]) atomicMax(&sc->tmp2, (u[c][h] << 10) | colof<T>(c, lane, h));
   __builtin_amdgcn_wave_barrier();
   return sc->tmp2 & 1023;
 }
@@ -561,12 +698,13 @@ last_unit_wins:
 // own fold (traiter.c:312-331), candidate by candidate, with its wrap-around products; only the
 // search for the first row with a non-zero cross product is spread over the lanes.  Slow (two
 // column gathers per candidate) but bit-identical whatever the magnitudes.  Wave 0.
-__device__ int choose_column_slow(const Shared &S, const i64 *vals, int W, int nvar, int nligne) {
+template <class T>
+__device__ int choose_column_slow(const Shared<T> &S, const T *vals, int W, int nvar, int nligne) {
   const int lane = threadIdx.x & 63;
   int pivj = -1;
-  i64 pivot = 0;
+  T pivot = 0;
   for (int j = 0; j < nvar; j++) {
-    const i64 foo = S.prow[j];
+    const T foo = S.prow[j];
     if (!(foo > 0)) continue;
     if (pivj < 0) {
       pivj = j;
@@ -576,10 +714,10 @@ __device__ int choose_column_slow(const Shared &S, const i64 *vals, int W, int n
     bool less = false;
     for (int k0 = 0; k0 < nligne; k0 += 64) {
       const int k = k0 + lane;
-      i64 x = 0;
+      T x = 0;
       if (k < nligne) {
         const int rf = S.ref[k];
-        i64 vj, vb;
+        T vj, vb;
         if (rf & UNITBIT) {  // valeur(): the unit row's denominator (1) in its own column
           vj = ((rf & ~UNITBIT) == j) ? 1 : 0;
           vb = ((rf & ~UNITBIT) == pivj) ? 1 : 0;
@@ -608,7 +746,8 @@ __device__ int choose_column_slow(const Shared &S, const i64 *vals, int W, int n
 // traiter.c:591-614: selection sort of the real rows nvar..nligne-1 by `size`
 // (first minimum strictly below the running bound, swap into place).  With
 // slot-indexed row data a swap of two logical rows is a swap of their slots.  Wave 0.
-__device__ void sort_rows(const Shared &S, int nvar, int nligne, double smax) {
+template <class T>
+__device__ void sort_rows(const Shared<T> &S, int nvar, int nligne, double smax) {
   const int lane = threadIdx.x & 63;
   for (int i = nvar; i < nligne; i++) {
     if (S.ref[i] & UNITBIT) continue;
@@ -649,19 +788,19 @@ __device__ __forceinline__ int trunc_int_x86(double t) {
 }
 
 // select the register that holds column pivj (uniform c,h) and read it from its owner lane
-template <int NCH>
-__device__ __forceinline__ i64 row_entry(const RowRegs<NCH> &r, int pc, int ph, int pl) {
-  i64 mine = 0;
+template <class T, int NCH>
+__device__ __forceinline__ T row_entry(const RowRegs<T, NCH> &r, int pc, int ph, int pl) {
+  T mine = 0;
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+    for (int h = 0; h < ET<T>::CPL; h++)
       if (c == pc && h == ph) mine = r.v[c][h];
   return readlane64(mine, pl);
 }
 
 // ================================================================ main kernel
-template <int NCH, int NW>
+template <class T, int NCH, int NW>
 __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax,
                                                          int Wmax, int iter_limit, u64 *prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -672,16 +811,16 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
   if (J->status != PIPAMD_ST_RUN) return;
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int WP = NCH * 128;  // columns a wave's registers cover; prow/urow are padded to it
-  constexpr int NM = 2 * NCH;
+  constexpr int WP = NCH * 64 * ET<T>::CPL;  // columns a wave's registers cover; prow/urow are padded to it
+  constexpr int NM = NCH * ET<T>::CPL;
   (void)Wmax;
   PROF_DECL;
 
-  Shared S;
+  Shared<T> S;
   {
     unsigned char *p = smem;
-    S.den = (i64 *)p;    p += sizeof(i64) * Smax;
-    S.prow = (i64 *)p;   p += sizeof(i64) * WP;
+    S.den = (T *)p;      p += sizeof(T) * Smax;
+    S.prow = (T *)p;     p += sizeof(T) * WP;
     S.nzm = (u64 *)p;    p += sizeof(u64) * (size_t)Smax * NM;
     S.size = (float *)p; p += sizeof(float) * Smax;
     S.sig = (u16 *)p;    p += sizeof(u16) * Smax;
@@ -701,16 +840,21 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
   int ni = J->ni;
   const int L = J->L, Sl = J->S, W = J->W;
   const int ncol = nvar + nparm + 1;
-  const int ncolp = (ncol + 1) & ~1;
-  i64 *vals = arena + J->vals_off;
-  i64 *g_den = arena + J->rows_off;
+  const int ncolp = ET<T>::CPL == 2 ? ((ncol + 1) & ~1) : ncol;  // rows are whole 16-byte units
+  T *vals = (T *)(arena + J->vals_off);
+  T *g_den = (T *)(arena + J->rows_off);
   int *g_flag = (int *)(g_den + L);
   int *g_ref = g_flag + L;
   int nligne = nvar + ni;
   int npiv = J->npiv, ncut = J->ncut, nupd = J->nupd;
   int ldet = J->ldet;
-  i64 det[PIPAMD_MAXDET];
-  for (int i = 0; i < PIPAMD_MAXDET; i++) det[i] = J->det[i];
+  T det[PIPAMD_MAXDET];
+  for (int i = 0; i < PIPAMD_MAXDET; i++) {
+    if constexpr (ET<T>::EW == 1)
+      det[i] = J->det[i];
+    else
+      det[i] = (T)(((u128)(u64)J->det[2 * i + 1] << 64) | (u64)J->det[2 * i]);
+  }
   if (ni > Smax || nligne > Lmax) return;  // this launch's LDS image is too small: stay RUN for a larger one
   // saved LDS state of a paused job (bitmaps, sign summaries, magnitude classes)
   u64 *g_nzm = (u64 *)(arena + J->state_off);
@@ -758,20 +902,20 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
   } else {
     // one pass over the tableau: sign summaries, bitmaps, magnitudes, sort keys
     for (int s = wave; s < ni; s += NW) {
-      RowRegs<NCH> r;
-      row_load<NCH>(r, vals + (size_t)s * W, ncolp, lane);
+      RowRegs<T, NCH> r;
+      row_load<T, NCH>(r, vals + (size_t)s * W, ncolp, lane);
       // rows with a denominator other than 1 are conservatively treated as not yet reduced
-      row_publish<NCH>(r, S, s, nvar, ncol, bigparm, -1, S.den[s] == 1 ? SIG_RED : 0, has_parm, lane);
+      row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, -1, S.den[s] == 1 ? SIG_RED : 0, has_parm, lane);
       if (tflags & PIPAMD_T_SORT) {
         // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns
-        double d = (double)S.den[s], sz = 0;
+        double d = to_double(S.den[s]), sz = 0;
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
-          for (int h = 0; h < 2; h++) {
-            int j = c * 128 + 2 * lane + h;
+          for (int h = 0; h < ET<T>::CPL; h++) {
+            int j = colof<T>(c, lane, h);
             if (j < nvar) {
-              int q = trunc_int_x86((double)r.v[c][h] / d);
+              int q = trunc_int_x86(to_double(r.v[c][h]) / d);
               double aq = (double)(q < 0 ? (int)(0u - (unsigned)q) : q);
               sz = sz > aq ? sz : aq;
             }
@@ -820,7 +964,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     if (pivi == BIG_I) {
       // -------------- exam_coef, then (if nothing is negative) integrer ---------
       if (bigparm >= 0) {
-        pivi = exam_rows<NW>(S, &sc, ni);
+        pivi = exam_rows<T, NW>(S, &sc, ni);
       } else {
         // the flags exam_coef would assign were computed with the post-pivot hints; they are
         // applied up to the first row it proves negative (traiter.c:154-156)
@@ -854,9 +998,9 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
         for (int i = tid; i < nvar; i += NT) {
           const int rf = S.ref[i];
           if (rf & UNITBIT) continue;
-          const i64 D = S.den[rf];
+          const T D = S.den[rf];
           if (D == 1) continue;
-          const i64 *row = vals + (size_t)rf * W;
+          const T *row = vals + (size_t)rf * W;
           bool ok = wneg(fmod64(wneg(row[nvar]), D)) != 0;
           for (int j = nvar + 1; j < ncol && !ok; j++)
             if (j != bigparm && fmod64(wneg(row[j]), D) != 0) ok = true;
@@ -871,16 +1015,16 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
         // wave 0 builds the cut in its registers (integrer.c:357-386) and appends it
         if (wave == 0) {
           const int cslot = S.ref[ci];
-          const i64 D = uni64(S.den[cslot]);
-          RowRegs<NCH> r;
-          row_load<NCH>(r, vals + (size_t)cslot * W, ncolp, lane);
+          const T D = uni64(S.den[cslot]);
+          RowRegs<T, NCH> r;
+          row_load<T, NCH>(r, vals + (size_t)cslot * W, ncolp, lane);
           bool okv = false, okp = false;
 #pragma unroll
           for (int c = 0; c < NCH; c++)
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-              int j = c * 128 + 2 * lane + h;
-              i64 v = r.v[c][h], x = 0;
+            for (int h = 0; h < ET<T>::CPL; h++) {
+              int j = colof<T>(c, lane, h);
+              T v = r.v[c][h], x = 0;
               if (j < nvar) {
                 x = fmod64(v, D);
                 okv |= x > 0;
@@ -907,8 +1051,8 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
           else {
             verdict = PIPAMD_ST_RUN;
             // append the cut as logical row nligne in slot ni (integrer.c:440-446)
-            row_store<NCH>(r, vals + (size_t)ni * W, ncolp, lane);
-            row_publish<NCH>(r, S, ni, nvar, ncol, bigparm, -1, 0, has_parm, lane);
+            row_store<T, NCH>(r, vals + (size_t)ni * W, ncolp, lane);
+            row_publish<T, NCH>(r, S, ni, nvar, ncol, bigparm, -1, 0, has_parm, lane);
             if (lane == 0) {
               S.fl[ni] = PIPAMD_F_MINUS;
               S.nf[ni] = 0;
@@ -939,34 +1083,34 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     npiv++;
     const int pslot = S.ref[pivi];
     if (wave == 0) {
-      RowRegs<NCH> pr;
-      row_load<NCH>(pr, vals + (size_t)pslot * W, ncolp, lane);
-      u64 amax = 0;
+      RowRegs<T, NCH> pr;
+      row_load<T, NCH>(pr, vals + (size_t)pslot * W, ncolp, lane);
+      typename ET<T>::U amax = 0;
 #pragma unroll
       for (int c = 0; c < NCH; c++)
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          int j = c * 128 + 2 * lane + h;
+        for (int h = 0; h < ET<T>::CPL; h++) {
+          int j = colof<T>(c, lane, h);
           if (j >= ncol) pr.v[c][h] = 0;
           S.prow[j] = pr.v[c][h];
-          if (j < nvar && pr.v[c][h] > 0) amax |= (u64)pr.v[c][h];
+          if (j < nvar && pr.v[c][h] > 0) amax |= (typename ET<T>::U)pr.v[c][h];
         }
       // exactness guard of the tournament: (max candidate a_j) * (max |entry|) < 2^62
-      const int abits = __ballot((amax >> 47) != 0) ? 64
-                        : (__ballot((amax >> 31) != 0) ? 47 : (__ballot((amax >> 15) != 0) ? 31 : 15));
+      const int abits = cls_bits<T>(cls_of<T>(amax));
       int mc = 0;
       for (int s = lane; s < ni; s += 64)
         if (S.rcls[s] > mc) mc = S.rcls[s];
       mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
-      const bool safe = abits + cls_bits(mc) <= 62;
+      const bool safe = abits + cls_bits<T>(mc) <= ET<T>::BITS - 2;
       PROF(3);
-      int pj = safe ? choose_column<NCH>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc)
+      int pj = safe ? choose_column<T, NCH>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc)
                     : choose_column_slow(S, vals, W, nvar, nligne);
       PROF(4);
       if (pj >= 0) {
         // slots the elimination has to rewrite: the recycled pivot slot plus every real row
         // that is non-zero in column pj or not yet reduced
-        const int pe = ((pj >> 7) << 1) | (pj & 1), pl = (pj & 127) >> 1;
+        constexpr int CW = 64 * ET<T>::CPL;
+        const int pe = (pj / CW) * ET<T>::CPL + (pj % ET<T>::CPL), pl = (pj % CW) / ET<T>::CPL;
         int base = 0;
         for (int s0 = 0; s0 < ni; s0 += 64) {
           const int s = s0 + lane;
@@ -1005,11 +1149,11 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
       break;
     }
     // pivot scalars + determinant bookkeeping, traiter.c:394-446 (uniform, every thread)
-    const i64 pivot = uni64(S.prow[pivj]);
-    const i64 dpiv = uni64(S.den[pslot]);
+    const T pivot = uni64(S.prow[pivj]);
+    const T dpiv = uni64(S.den[pslot]);
     {
-      i64 d = gcd_i64(pivot, dpiv);
-      i64 ppivot = cquo(pivot, d), dppiv = cquo(dpiv, d);
+      T d = gcd_i64(pivot, dpiv);
+      T ppivot = cquo(pivot, d), dppiv = cquo(dpiv, d);
       for (int i = 0; i < ldet; i++) {
         d = gcd_i64(det[i], dppiv);
         det[i] = cquo(det[i], d);
@@ -1019,7 +1163,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
       if (!ovf) {
         int i = 0;
         for (; i < ldet; i++)
-          if (log2_64(det[i]) + log2_64(ppivot) < 64) {
+          if (log2_64(det[i]) + log2_64(ppivot) < ET<T>::BITS) {
             det[i] = wmul(det[i], ppivot);
             break;
           }
@@ -1038,7 +1182,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     }
     const int ku = S.urow[pivj];  // unit row of the entering column
     const int pred = S.sig[pslot] & SIG_RED;
-    const int pc = pivj >> 7, ph = pivj & 1, pl = (pivj & 127) >> 1;
+    const int pc = pivj / (64 * ET<T>::CPL), ph = pivj % ET<T>::CPL, pl = (pivj % (64 * ET<T>::CPL)) / ET<T>::CPL;
     PROF(5);
     // ---------------- B: eliminate the pivot column (all waves) ----------------
     {
@@ -1046,37 +1190,37 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
       nupd += nwork - 1;
       // rows are double-buffered in registers: the next row's load is in flight while this one
       // is being reduced
-      RowRegs<NCH> r, rn;
-      if (wave < nwork && S.work[wave] != pslot) row_load<NCH>(r, vals + (size_t)S.work[wave] * W, ncolp, lane);
+      RowRegs<T, NCH> r, rn;
+      if (wave < nwork && S.work[wave] != pslot) row_load<T, NCH>(r, vals + (size_t)S.work[wave] * W, ncolp, lane);
       for (int w = wave; w < nwork; w += NW) {
         const int s = S.work[w];
-        i64 *row = vals + (size_t)s * W;
+        T *row = vals + (size_t)s * W;
         if (w + NW < nwork && S.work[w + NW] != pslot)
-          row_load<NCH>(rn, vals + (size_t)S.work[w + NW] * W, ncolp, lane);
+          row_load<T, NCH>(rn, vals + (size_t)S.work[w + NW] * W, ncolp, lane);
         if (s == pslot) {
           // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
 #pragma unroll
           for (int c = 0; c < NCH; c++)
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-              int j = c * 128 + 2 * lane + h;
+            for (int h = 0; h < ET<T>::CPL; h++) {
+              int j = colof<T>(c, lane, h);
               r.v[c][h] = (j == pivj) ? dpiv : wneg(S.prow[j]);
             }
-          row_store<NCH>(r, row, ncolp, lane);
-          row_publish<NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
+          row_store<T, NCH>(r, row, ncolp, lane);
+          row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
         } else {
-          i64 nd;
+          T nd;
           // multipliers from the row's own pivot-column entry (traiter.c:470-476)
-          i64 foo = row_entry<NCH>(r, pc, ph, pl);
-          const i64 d = gcd_i64(pivot, foo);
-          const i64 lp = cquo(pivot, d);
+          T foo = row_entry<T, NCH>(r, pc, ph, pl);
+          const T d = gcd_i64(pivot, foo);
+          const T lp = cquo(pivot, d);
           foo = cquo(foo, d);
-          const i64 g0 = wmul(lp, uni64(S.den[s]));
-          if (!update_row<NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
+          const T g0 = wmul(lp, uni64(S.den[s]));
+          if (!update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
             if (lane == 0) sc.bad = 1;
           }
-          row_store<NCH>(r, row, ncolp, lane);
-          row_publish<NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane);
+          row_store<T, NCH>(r, row, ncolp, lane);
+          row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane);
           if (lane == 0) S.den[s] = nd;
         }
         r = rn;
@@ -1157,13 +1301,13 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
   }
   if (status == PIPAMD_ST_SOLUTION) {
     // solution(), traiter.c:255-271: rows 0..nvar-1, parameters then constant
-    i64 *sol_num = arena + J->sol_off;
-    i64 *sol_den = sol_num + (size_t)nvar * (nparm + 1);
+    T *sol_num = (T *)(arena + J->sol_off);
+    T *sol_den = sol_num + (size_t)nvar * (nparm + 1);
     for (int e = tid; e < nvar * (nparm + 1); e += NT) {
       int i = e / (nparm + 1), jj = e % (nparm + 1);
       int col = jj < nparm ? nvar + 1 + jj : nvar;
       const int rf = S.ref[i];
-      i64 v = 0;
+      T v = 0;
       if (!(rf & UNITBIT)) v = vals[(size_t)rf * W + col];
       sol_num[e] = v;
     }
@@ -1181,7 +1325,14 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     J->ncut = ncut;
     J->nupd = nupd;
     J->ldet = ldet;
-    for (int i = 0; i < PIPAMD_MAXDET; i++) J->det[i] = det[i];
+    for (int i = 0; i < PIPAMD_MAXDET; i++) {
+      if constexpr (ET<T>::EW == 1)
+        J->det[i] = det[i];
+      else {
+        J->det[2 * i] = (i64)(u64)(u128)det[i];
+        J->det[2 * i + 1] = (i64)(u64)((u128)det[i] >> 64);
+      }
+    }
     J->tflags = tflags;
     J->state_nch = NCH;
     J->maxabs = (u64)mc;  // magnitude class of the largest entry
@@ -1194,17 +1345,21 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
 
 // ---------------------------------------------------------------- batch load
 // tab_alloc + tab_get (tab.c:158-248) for a uniform batch: nvar unit rows, then
-// ni Unknown rows with denominator 1; spare slots and columns zeroed.
+// ni Unknown rows with denominator 1; spare slots and columns zeroed.  Input rows are int64
+// whatever the entry type of the tableau.
+template <class T>
 __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows, PipBatchLayout lay) {
+  constexpr int EW = ET<T>::EW;
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int ncol = lay.nvar + lay.nparm + 1;
   PipJob *J = &jobs[b];
   const int64_t base = lay.arena_off + (int64_t)b * lay.per_job;
-  i64 *g_den = arena + base;
+  T *g_den = (T *)(arena + base);
   int *g_flag = (int *)(g_den + lay.L);
   int *g_ref = g_flag + lay.L;
-  i64 *vals = arena + base + 2 * (int64_t)lay.L;
+  const int64_t rows_words = (int64_t)lay.L * EW + lay.L;
+  T *vals = (T *)(arena + base + rows_words);
   for (int i = tid; i < lay.L; i += blockDim.x) {
     if (i < lay.nvar) {
       g_flag[i] = PIPAMD_F_UNIT;
@@ -1225,7 +1380,7 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
   const i64 *src = rows + (size_t)b * lay.ni * ncol;
   for (int e = tid; e < lay.ni * lay.W; e += blockDim.x) {
     int s = e / lay.W, j = e % lay.W;
-    vals[e] = j < ncol ? src[(size_t)s * ncol + j] : 0;
+    vals[e] = j < ncol ? (T)src[(size_t)s * ncol + j] : (T)0;
   }
   const int pad = lay.W - ncol;
   for (int e = tid; e < (lay.S - lay.ni) * pad; e += blockDim.x) {
@@ -1234,8 +1389,8 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
   }
   if (tid == 0) {
     J->rows_off = base;
-    J->vals_off = base + 2 * (int64_t)lay.L;
-    J->sol_off = base + 2 * (int64_t)lay.L + (int64_t)lay.S * lay.W;
+    J->vals_off = base + rows_words;
+    J->sol_off = J->vals_off + (int64_t)lay.S * lay.W * EW;
     J->state_off = J->sol_off + lay.sol_words;
     J->nvar = lay.nvar;
     J->nparm = lay.nparm;
@@ -1251,14 +1406,17 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
     J->ncut = 0;
     J->nupd = 0;
     J->ldet = 1;
+    for (int i = 0; i < 2 * PIPAMD_MAXDET; i++) J->det[i] = 0;
     J->det[0] = 1;
-    J->det[1] = J->det[2] = J->det[3] = 0;
     J->maxabs = 0;
+    J->state_nch = 0;
+    J->ebits = ET<T>::BITS;
   }
 }
 
+template <class T>
 __global__ void pip_batch_results_kernel(const PipJob *jobs, const i64 *arena, int njobs, int nvar, int nparm,
-                                         int *status, int *pivots, int *cuts, i64 *sol_num, i64 *sol_den) {
+                                         int *status, int *pivots, int *cuts, T *sol_num, T *sol_den) {
   const int b = blockIdx.x;
   const PipJob *J = &jobs[b];
   if (threadIdx.x == 0) {
@@ -1267,12 +1425,12 @@ __global__ void pip_batch_results_kernel(const PipJob *jobs, const i64 *arena, i
     if (cuts) cuts[b] = J->ncut;
   }
   const int nn = nvar * (nparm + 1);
-  const i64 *sn = arena + J->sol_off;
+  const T *sn = (const T *)(arena + J->sol_off);
   const bool ok = J->status == PIPAMD_ST_SOLUTION;
   if (sol_num)
-    for (int e = threadIdx.x; e < nn; e += blockDim.x) sol_num[(size_t)b * nn + e] = ok ? sn[e] : 0;
+    for (int e = threadIdx.x; e < nn; e += blockDim.x) sol_num[(size_t)b * nn + e] = ok ? sn[e] : (T)0;
   if (sol_den)
-    for (int i = threadIdx.x; i < nvar; i += blockDim.x) sol_den[(size_t)b * nvar + i] = ok ? sn[nn + i] : 0;
+    for (int i = threadIdx.x; i < nvar; i += blockDim.x) sol_den[(size_t)b * nvar + i] = ok ? sn[nn + i] : (T)0;
 }
 
 // totals over a batch: [0] pivots [1] cuts [2] rows rewritten [3] jobs finished (solution or nil)
@@ -1298,6 +1456,12 @@ __global__ void pip_batch_running_kernel(const PipJob *jobs, int njobs, int *out
 }
 
 // ------------------------------------------------------------------ launchers
+// columns a wave's registers cover (row chunks x 16 B per lane), by entry width
+static int wp_of(int Wmax, int ebits) {
+  if (ebits == 128) return Wmax <= 64 ? 64 : (Wmax <= 128 ? 128 : (Wmax <= 256 ? 256 : 512));
+  return Wmax <= 128 ? 128 : (Wmax <= 256 ? 256 : 512);
+}
+
 extern "C" hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, int *out2, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(out2, 0, 2 * sizeof(int), stream);
   if (e != hipSuccess) return e;
@@ -1305,10 +1469,10 @@ extern "C" hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, i
   return hipGetLastError();
 }
 
-extern "C" size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax) {
-  const size_t WP = Wmax <= 128 ? 128 : (Wmax <= 256 ? 256 : 512);
-  const size_t NM = WP / 64;
-  size_t shm = sizeof(i64) * ((size_t)Smax + WP) + sizeof(u64) * (size_t)Smax * NM + sizeof(float) * (size_t)Smax +
+extern "C" size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax, int ebits) {
+  const size_t WP = (size_t)wp_of(Wmax, ebits);
+  const size_t NM = WP / 64, EB = ebits == 128 ? 16 : 8;
+  size_t shm = EB * ((size_t)Smax + WP) + sizeof(u64) * (size_t)Smax * NM + sizeof(float) * (size_t)Smax +
                sizeof(u16) * (3 * (size_t)Smax + (size_t)Lmax + WP) + 3 * (size_t)Smax + (size_t)Lmax;
   return (shm + 15) & ~(size_t)15;
 }
@@ -1321,48 +1485,72 @@ extern "C" hipError_t pipk_launch_batch_counters(const PipJob *jobs, int njobs, 
   return hipGetLastError();
 }
 
-template <int NCH, int NW>
+template <class T, int NCH, int NW>
 static void launch_advance_t(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
                              unsigned long long *prof, size_t shm, hipStream_t stream) {
-  hipLaunchKernelGGL((pip_advance_kernel<NCH, NW>), dim3(njobs), dim3(64 * NW), shm, stream, jobs, arena, njobs, Lmax,
+  hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW>), dim3(njobs), dim3(64 * NW), shm, stream, jobs, arena, njobs, Lmax,
                      Smax, Wmax, iter_limit, prof);
+}
+template <class T, int NCH>
+static void launch_advance_w(bool one, PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
+                             int iter_limit, unsigned long long *prof, size_t shm, hipStream_t stream) {
+  if (one)
+    launch_advance_t<T, NCH, 1>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
+  else
+    launch_advance_t<T, NCH, 4>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
 }
 
 // waves_per_job: 1 = one wave64 per tableau (latency-bound sparse batches: more tableaux in
 // flight per CU), 4 = four waves share a tableau's rows (few, large tableaux).
+// ebits: 64 or 128 -- every job of the launch must have that entry width.
 extern "C" hipError_t pipk_launch_advance(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
-                                          int iter_limit, int waves_per_job, unsigned long long *prof,
+                                          int iter_limit, int waves_per_job, int ebits, unsigned long long *prof,
                                           hipStream_t stream) {
   if (njobs <= 0) return hipSuccess;
-  // LDS arrays are carved at 8/4/2/1-byte granularity in that order: keep Lmax, Smax multiples of 4
+  // LDS arrays are carved at 16/8/4/2/1-byte granularity in that order: keep Lmax, Smax multiples of 4
   Lmax = (Lmax + 3) & ~3;
   Smax = (Smax + 3) & ~3;
-  const size_t shm = pipk_advance_lds_bytes(Lmax, Smax, Wmax);
+  if (Wmax > 512) return hipErrorInvalidValue;
+  const size_t shm = pipk_advance_lds_bytes(Lmax, Smax, Wmax, ebits);
   const bool one = waves_per_job == 1;
-  if (Wmax <= 128) {
-    if (one) launch_advance_t<1, 1>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
-    else launch_advance_t<1, 4>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
-  } else if (Wmax <= 256) {
-    if (one) launch_advance_t<2, 1>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
-    else launch_advance_t<2, 4>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
-  } else if (Wmax <= 512) {
-    if (one) launch_advance_t<4, 1>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
-    else launch_advance_t<4, 4>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
-  } else
-    return hipErrorInvalidValue;
+  const int wp = wp_of(Wmax, ebits);
+  if (ebits == 128) {
+    if (shm > 64 * 1024) {
+      hipFuncSetAttribute((const void *)pip_advance_kernel<i128, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    switch (wp) {
+      case 64: launch_advance_w<i128, 1>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
+      case 128: launch_advance_w<i128, 2>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
+      case 256: launch_advance_w<i128, 4>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
+      default: launch_advance_w<i128, 8>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
+    }
+  } else {
+    switch (wp) {
+      case 128: launch_advance_w<i64, 1>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
+      case 256: launch_advance_w<i64, 2>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
+      default: launch_advance_w<i64, 4>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
+    }
+  }
   return hipGetLastError();
 }
 
 extern "C" hipError_t pipk_launch_batch_load(PipJob *jobs, i64 *arena, const i64 *rows, PipBatchLayout lay,
                                              hipStream_t stream) {
-  hipLaunchKernelGGL(pip_batch_load_kernel, dim3(lay.batch), dim3(256), 0, stream, jobs, arena, rows, lay);
+  if (lay.ebits == 128)
+    hipLaunchKernelGGL(pip_batch_load_kernel<i128>, dim3(lay.batch), dim3(256), 0, stream, jobs, arena, rows, lay);
+  else
+    hipLaunchKernelGGL(pip_batch_load_kernel<i64>, dim3(lay.batch), dim3(256), 0, stream, jobs, arena, rows, lay);
   return hipGetLastError();
 }
 
 extern "C" hipError_t pipk_launch_batch_results(const PipJob *jobs, const i64 *arena, int njobs, int nvar, int nparm,
-                                                int *status, int *pivots, int *cuts, i64 *sol_num, i64 *sol_den,
-                                                hipStream_t stream) {
-  hipLaunchKernelGGL(pip_batch_results_kernel, dim3(njobs), dim3(256), 0, stream, jobs, arena, njobs, nvar, nparm,
-                     status, pivots, cuts, sol_num, sol_den);
+                                                int ebits, int *status, int *pivots, int *cuts, void *sol_num,
+                                                void *sol_den, hipStream_t stream) {
+  if (ebits == 128)
+    hipLaunchKernelGGL(pip_batch_results_kernel<i128>, dim3(njobs), dim3(256), 0, stream, jobs, arena, njobs, nvar, nparm,
+                       status, pivots, cuts, (i128 *)sol_num, (i128 *)sol_den);
+  else
+    hipLaunchKernelGGL(pip_batch_results_kernel<i64>, dim3(njobs), dim3(256), 0, stream, jobs, arena, njobs, nvar, nparm,
+                       status, pivots, cuts, (i64 *)sol_num, (i64 *)sol_den);
   return hipGetLastError();
 }

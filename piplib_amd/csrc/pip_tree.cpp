@@ -192,6 +192,7 @@ class Tree {
     j.pj.status = PIPAMD_ST_RUN;
     j.pj.ldet = 1;
     j.pj.det[0] = 1;
+    j.pj.ebits = 64;
     return j;
   }
 
@@ -275,7 +276,7 @@ class Tree {
     for (int pass = 0; pass < 64; pass++) {
       HIPTHROW(hipMemcpy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice));
       for (int guard = 0; guard < 4096; guard++) {
-        HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, nullptr, 0));
+        HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0));
         HIPTHROW(hipMemcpy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost));
         bool again = false;
         for (int i = 0; i < n; i++)

@@ -16,7 +16,7 @@ T_NOSKIP = 2048
 
 class BatchDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("batch", "nvar", "nparm", "ni", "bigparm", "tflags", "cap_cuts", "cap_newparm")]
+                ("batch", "nvar", "nparm", "ni", "bigparm", "tflags", "cap_cuts", "cap_newparm", "entier_bits")]
 
 
 _lib = None
@@ -91,10 +91,19 @@ class Engine:
             pass
 
 
+def wide_to_int(a):
+    """numpy (..., 2) int64 (low, high) pairs -> object array of Python ints (two's complement)."""
+    import numpy as np
+    lo = a[..., 0].astype(object) & ((1 << 64) - 1)
+    hi = a[..., 1].astype(object)
+    return hi * (1 << 64) + lo
+
+
 class Batch:
     """A uniform batch of tableaux resident in HBM (layer 1 of the C ABI)."""
 
-    def __init__(self, engine, rows, nvar, nparm, bigparm=-1, tflags=T_INT, cap_cuts=None, cap_newparm=0):
+    def __init__(self, engine, rows, nvar, nparm, bigparm=-1, tflags=T_INT, cap_cuts=None, cap_newparm=0,
+                 entier_bits=64):
         import torch
         self.torch = torch
         self.e = engine
@@ -102,7 +111,9 @@ class Batch:
         assert ncol == nvar + nparm + 1
         if cap_cuts is None:
             cap_cuts = min(ni + 64, 768 - ni) if (tflags & T_INT) else 0
-        self.desc = BatchDesc(B, nvar, nparm, ni, bigparm, tflags, cap_cuts, cap_newparm)
+        self.desc = BatchDesc(B, nvar, nparm, ni, bigparm, tflags, cap_cuts, cap_newparm, entier_bits)
+        self.entier_bits = entier_bits
+        ew = 2 if entier_bits == 128 else 1
         self.dev = torch.device("cuda", engine.device)
         self.rows = rows if (torch.is_tensor(rows) and rows.is_cuda) else torch.as_tensor(rows, dtype=torch.int64).to(self.dev)
         self.rows = self.rows.contiguous()
@@ -113,8 +124,9 @@ class Batch:
         self.status = torch.empty(B, dtype=torch.int32, device=self.dev)
         self.pivots = torch.empty(B, dtype=torch.int32, device=self.dev)
         self.cuts = torch.empty(B, dtype=torch.int32, device=self.dev)
-        self.sol_num = torch.empty(B, nvar, nparm + 1, dtype=torch.int64, device=self.dev)
-        self.sol_den = torch.empty(B, nvar, dtype=torch.int64, device=self.dev)
+        # 128-bit values come back as (low, high) int64 pairs: see wide_to_int()
+        self.sol_num = torch.empty((B, nvar, nparm + 1) + ((2,) if ew == 2 else ()), dtype=torch.int64, device=self.dev)
+        self.sol_den = torch.empty((B, nvar) + ((2,) if ew == 2 else ()), dtype=torch.int64, device=self.dev)
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)

@@ -77,3 +77,18 @@ def random_problems(seed, count, nvar, nparm, ni, nc, nq, cmax=4, bmax=12):
             C[:, nparm] = rng.integers(0, bmax + 1, size=nc)
         out.append(Problem(nvar, nparm, ni, nc, -1, nq, T, C))
     return out
+
+
+def dense_batch(seed, batch, nvar, ni, cmax=40, x0max=9, pzero=0.3):
+    """(batch, ni, nvar+1) int64: dense lexmin problems with large coefficients.  Their
+    determinants outgrow 64 bits quickly -- the reference's int64 build stops with "Integer
+    overflow" on many of them -- which is what the 128-bit Entier variant is for."""
+    rng = np.random.default_rng(seed)
+    A = rng.integers(-cmax, cmax + 1, size=(batch, ni, nvar)).astype(np.int64)
+    A[rng.random((batch, ni, nvar)) < pzero] = 0
+    x0 = rng.integers(0, x0max + 1, size=(batch, nvar))
+    slack = rng.integers(0, 4, size=(batch, ni))
+    T = np.zeros((batch, ni, nvar + 1), dtype=np.int64)
+    T[:, :, :nvar] = A
+    T[:, :, nvar] = slack - np.einsum("bij,bj->bi", A, x0)
+    return T

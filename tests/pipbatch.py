@@ -17,6 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFPIP = os.path.join(ROOT, "oracle", "_ref", "refpip")
 ORACLEPIP = os.path.join(ROOT, "oracle", "oraclepip")
+ORACLEPIP128 = os.path.join(ROOT, "oracle", "oraclepip128")
 MAGIC = 0x50495042
 
 F_NOTEXT, F_NOSIMPLIFY, F_DEEPEST = 1, 2, 4

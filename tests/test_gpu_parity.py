@@ -135,3 +135,89 @@ def test_full_size_properties(batch, nvar, ni, nq):
         want = pb.squash(r.text)
         got = "()" if st[b] == eng.ST_NIL else pb.squash(solution_text(num[b], den[b]))
         assert got == want, b
+
+
+def _gpu128(rows, nvar, nq, cap_cuts):
+    import torch
+    from piplib_amd import engine as eng
+    e = eng.Engine(0)
+    b = eng.Batch(e, rows, nvar, 0, tflags=eng.T_INT if nq else 0, cap_cuts=cap_cuts, entier_bits=128)
+    b.load()
+    b.solve()
+    b.fetch()
+    torch.cuda.synchronize()
+    return b
+
+
+def test_int128_equals_int64_on_small_entries():
+    """128-bit Entier variant == the int64 oracle when nothing overflows."""
+    import numpy as np
+    from gpu_common import oracle_batch, solution_text
+    import pipbatch as pb
+    from piplib_amd import engine as eng, synth
+    rows = synth.lexmin_batch(31, 48, 40, 24)
+    o = oracle_batch(rows, 40, 0, 1)
+    g = _gpu128(rows, 40, 1, 96)
+    st, pv = g.status.cpu().numpy(), g.pivots.cpu().numpy()
+    num, den = eng.wide_to_int(g.sol_num.cpu().numpy()), eng.wide_to_int(g.sol_den.cpu().numpy())
+    for b, r in enumerate(o.results):
+        assert pv[b] == r.pivots, b
+        got = "()" if st[b] == eng.ST_NIL else pb.squash(solution_text(num[b], den[b]))
+        assert st[b] in (eng.ST_SOLUTION, eng.ST_NIL) and got == pb.squash(r.text), b
+
+
+@pytest.mark.parametrize("seed,nvar,ni,cmax", [(3, 10, 10, 40), (4, 14, 12, 60)])
+def test_int128_overflow_safe_path(seed, nvar, ni, cmax):
+    """Dense large-coefficient tableaux: the int64 reference aborts ("Integer overflow") on many
+    of them; the 128-bit engine must agree with the 128-bit oracle (same algorithm on __int128)
+    in status, pivot count and every numerator/denominator."""
+    import numpy as np
+    from gpu_common import solution_text
+    import pipbatch as pb
+    from piplib_amd import engine as eng, synth
+    rows = synth.dense_batch(seed, 48, nvar, ni, cmax)
+    probs = [synth.Problem(nvar, 0, ni, 0, -1, 1, rows[b], np.zeros((0, 1), np.int64)) for b in range(rows.shape[0])]
+    o64 = pb.run_batch(pb.ORACLEPIP, probs, pb.F_NOSIMPLIFY)
+    o128 = pb.run_batch(pb.ORACLEPIP128, probs, pb.F_NOSIMPLIFY)
+    assert sum(r.status == pb.ST_ABORT for r in o64.results) > 5      # int64 really overflows here
+    g = _gpu128(rows, nvar, 1, 700)
+    st, pv = g.status.cpu().numpy(), g.pivots.cpu().numpy()
+    num, den = eng.wide_to_int(g.sol_num.cpu().numpy()), eng.wide_to_int(g.sol_den.cpu().numpy())
+    checked = 0
+    for b, r in enumerate(o128.results):
+        if st[b] == eng.ST_CAPACITY:
+            continue
+        if r.status == pb.ST_ABORT:
+            assert st[b] == eng.ST_OVERFLOW, b
+            continue
+        assert pv[b] == r.pivots, (b, pv[b], r.pivots)
+        got = "()" if st[b] == eng.ST_NIL else pb.squash(solution_text(num[b], den[b]))
+        assert got == pb.squash(r.text), b
+        checked += 1
+    assert checked >= 30
+
+
+def test_full_size_int128_config():
+    """BASELINE configs[4]: 1k-batch 128x256 tableaux on the 128-bit Entier path.  Entries of the
+    sparse generator stay small, so the int64 oracle is the checker for a sample; all tableaux
+    must finish and be feasible + integral."""
+    import numpy as np
+    from gpu_common import oracle_batch, solution_text
+    import pipbatch as pb
+    from piplib_amd import engine as eng, synth
+    nvar, ni, batch = 255, 128, 1000
+    rows = synth.lexmin_batch(77, batch, nvar, ni)
+    g = _gpu128(rows, nvar, 1, None)
+    st, pv = g.status.cpu().numpy(), g.pivots.cpu().numpy()
+    assert np.isin(st, [eng.ST_SOLUTION, eng.ST_NIL]).all(), np.unique(st, return_counts=True)
+    num = eng.wide_to_int(g.sol_num.cpu().numpy())
+    den = eng.wide_to_int(g.sol_den.cpu().numpy())
+    ok = st == eng.ST_SOLUTION
+    assert all((d > 0).all() and (n[:, 0] >= 0).all() and all(int(a) % int(b) == 0 for a, b in zip(n[:, 0], d))
+               for n, d in zip(num[ok][:100], den[ok][:100]))
+    pick = np.arange(0, batch, 25)
+    o = oracle_batch(rows[pick], nvar, 0, 1)
+    for b, r in zip(pick, o.results):
+        assert pv[b] == r.pivots, b
+        got = "()" if st[b] == eng.ST_NIL else pb.squash(solution_text(num[b], den[b]))
+        assert got == pb.squash(r.text), b
