@@ -26,6 +26,9 @@ def build(force=False, verbose=True, profile=False):
     cycle stamps in the kernel; never used for timing or shipped results)."""
     if profile:
         return _compile(os.path.join(HERE, "libpipamd_prof.so"), ["-DPIP_PROFILE"], verbose)
+    if os.environ.get("PIP_MINWAVES"):  # tuning experiments only
+        return _compile(os.path.join(HERE, "libpipamd_mw%s.so" % os.environ["PIP_MINWAVES"]),
+                        ["-DPIP_MINWAVES=" + os.environ["PIP_MINWAVES"]], verbose)
     if not force and not needs_build():
         return OUT
     return _compile(OUT, [], verbose)

@@ -155,13 +155,15 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
       pipamd_set_error("batch_solve: more than %d rounds", PIPAMD_MAX_ROUNDS);
       return PIPAMD_E_SOLVER;
     }
-    int budget = K;
+    const int waves = e->waves_per_job ? e->waves_per_job : (running >= 2048 ? 1 : 4);
+    // few tableaux left: the GPU is under-filled whatever we do, so let them run to the end in
+    // one launch (LDS image sized for every spare row) instead of paying a launch per round
+    int budget = (waves == 4 && running < 2048) ? e->iter_limit : K;
     if (e->iter_limit < budget) budget = e->iter_limit;
-    int smax = max_ni + budget;  // a cut is always followed by a pivot: at most `budget` new rows
+    int smax = budget >= lay.S ? lay.S : max_ni + budget;  // a cut is always followed by a pivot
     if (smax > lay.S) smax = lay.S;
     if (smax < max_ni) smax = max_ni;
     const int lmax = lay.nvar + smax;
-    const int waves = e->waves_per_job ? e->waves_per_job : (running >= 2048 ? 1 : 4);
     if (e->nlaunch >= e->nev) {
       HIPCHK(hipEventCreate(&e->ev[2 * e->nev]));
       HIPCHK(hipEventCreate(&e->ev[2 * e->nev + 1]));

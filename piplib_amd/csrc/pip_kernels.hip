@@ -55,6 +55,9 @@ struct ET<i128> {
 typedef unsigned short u16;
 typedef unsigned char u8;
 
+#ifndef PIP_MINWAVES
+#define PIP_MINWAVES 1
+#endif
 #define BIG_I 0x7fffffff
 #define NOROW 0xffff
 
@@ -100,6 +103,7 @@ __device__ __forceinline__ unsigned gcd_u32(unsigned a, unsigned b) {
   return a << sh;
 }
 __device__ __forceinline__ u64 gcd_mag(u64 a, u64 b) {
+  if (a == 1 || b == 1) return 1;
   if (((a | b) >> 32) == 0) return gcd_u32((unsigned)a, (unsigned)b);
   return gcd_u64(a, b);
 }
@@ -330,6 +334,7 @@ template <class T>
 struct Shared {
   T *den;     // [S]  denominator of the row in slot s
   T *prow;      // [WP] pivot row (zero beyond ncol)
+  T *cst;       // [S]  constant term (column nvar) of the row in slot s
   u64 *nzm;     // [S][NM] non-zero bitmap
   float *size;  // [S]  tab_sort_rows key (entry only)
   u16 *sig;     // [S]  sign summary
@@ -409,7 +414,10 @@ __device__ __forceinline__ void row_publish(const RowRegs<T, NCH> &r, const Shar
       int j = colof<T>(c, lane, h);
       T z = r.v[c][h];
       mx |= uabs64(z);
-      if (j == nvar) cs = sign_code(z);
+      if (j == nvar) {
+        cs = sign_code(z);
+        S.cst[s] = z;
+      }
       if (j == pivj) ps = sign_code(z);
       if (has_parm) {
         if (j == bigparm) bs = sign_code(z);
@@ -801,7 +809,7 @@ __device__ __forceinline__ T row_entry(const RowRegs<T, NCH> &r, int pc, int ph,
 
 // ================================================================ main kernel
 template <class T, int NCH, int NW>
-__global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax,
+__global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? PIP_MINWAVES : 1) void pip_advance_kernel(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax,
                                                          int Wmax, int iter_limit, u64 *prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Scalars sc;
@@ -821,6 +829,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     unsigned char *p = smem;
     S.den = (T *)p;      p += sizeof(T) * Smax;
     S.prow = (T *)p;     p += sizeof(T) * WP;
+    S.cst = (T *)p;      p += sizeof(T) * Smax;
     S.nzm = (u64 *)p;    p += sizeof(u64) * (size_t)Smax * NM;
     S.size = (float *)p; p += sizeof(float) * Smax;
     S.sig = (u16 *)p;    p += sizeof(u16) * Smax;
@@ -899,6 +908,7 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
       S.rcls[s] = g_rcls[s];
     }
     for (int e = tid; e < ni * NM; e += NT) S.nzm[e] = g_nzm[e];
+    for (int s = tid; s < ni; s += NT) S.cst[s] = vals[(size_t)s * W + nvar];
   } else {
     // one pass over the tableau: sign summaries, bitmaps, magnitudes, sort keys
     for (int s = wave; s < ni; s += NW) {
@@ -1000,10 +1010,12 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
           if (rf & UNITBIT) continue;
           const T D = S.den[rf];
           if (D == 1) continue;
-          const T *row = vals + (size_t)rf * W;
-          bool ok = wneg(fmod64(wneg(row[nvar]), D)) != 0;
-          for (int j = nvar + 1; j < ncol && !ok; j++)
-            if (j != bigparm && fmod64(wneg(row[j]), D) != 0) ok = true;
+          bool ok = wneg(fmod64(wneg(S.cst[rf]), D)) != 0;
+          if (has_parm && !ok) {
+            const T *row = vals + (size_t)rf * W;
+            for (int j = nvar + 1; j < ncol && !ok; j++)
+              if (j != bigparm && fmod64(wneg(row[j]), D) != 0) ok = true;
+          }
           if (ok) atomicMin(&sc.tmp, i);
         }
         bsync<NW>();
@@ -1188,42 +1200,50 @@ __global__ __launch_bounds__(64 * NW) void pip_advance_kernel(PipJob *jobs, i64 
     {
       const int nwork = sc.nwork;
       nupd += nwork - 1;
-      // rows are double-buffered in registers: the next row's load is in flight while this one
-      // is being reduced
-      RowRegs<T, NCH> r, rn;
-      if (wave < nwork && S.work[wave] != pslot) row_load<T, NCH>(r, vals + (size_t)S.work[wave] * W, ncolp, lane);
-      for (int w = wave; w < nwork; w += NW) {
-        const int s = S.work[w];
-        T *row = vals + (size_t)s * W;
-        if (w + NW < nwork && S.work[w + NW] != pslot)
-          row_load<T, NCH>(rn, vals + (size_t)S.work[w + NW] * W, ncolp, lane);
-        if (s == pslot) {
-          // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
+      // up to PF rows per wave are loaded before the first one is reduced, so their HBM
+      // latencies overlap (a wave owns only a few rows per pivot on sparse tableaux)
+      constexpr int PF = NCH <= 2 ? 4 : (NCH == 4 ? 2 : 1);
+      for (int w0 = wave; w0 < nwork; w0 += NW * PF) {
+        RowRegs<T, NCH> rr[PF];
 #pragma unroll
-          for (int c = 0; c < NCH; c++)
-#pragma unroll
-            for (int h = 0; h < ET<T>::CPL; h++) {
-              int j = colof<T>(c, lane, h);
-              r.v[c][h] = (j == pivj) ? dpiv : wneg(S.prow[j]);
-            }
-          row_store<T, NCH>(r, row, ncolp, lane);
-          row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
-        } else {
-          T nd;
-          // multipliers from the row's own pivot-column entry (traiter.c:470-476)
-          T foo = row_entry<T, NCH>(r, pc, ph, pl);
-          const T d = gcd_i64(pivot, foo);
-          const T lp = cquo(pivot, d);
-          foo = cquo(foo, d);
-          const T g0 = wmul(lp, uni64(S.den[s]));
-          if (!update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
-            if (lane == 0) sc.bad = 1;
-          }
-          row_store<T, NCH>(r, row, ncolp, lane);
-          row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane);
-          if (lane == 0) S.den[s] = nd;
+        for (int q = 0; q < PF; q++) {
+          const int w = w0 + q * NW;
+          if (w < nwork && S.work[w] != pslot) row_load<T, NCH>(rr[q], vals + (size_t)S.work[w] * W, ncolp, lane);
         }
-        r = rn;
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          const int w = w0 + q * NW;
+          if (w >= nwork) break;
+          RowRegs<T, NCH> &r = rr[q];
+          const int s = S.work[w];
+          T *row = vals + (size_t)s * W;
+          if (s == pslot) {
+            // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+              for (int h = 0; h < ET<T>::CPL; h++) {
+                int j = colof<T>(c, lane, h);
+                r.v[c][h] = (j == pivj) ? dpiv : wneg(S.prow[j]);
+              }
+            row_store<T, NCH>(r, row, ncolp, lane);
+            row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
+          } else {
+            T nd;
+            // multipliers from the row's own pivot-column entry (traiter.c:470-476)
+            T foo = row_entry<T, NCH>(r, pc, ph, pl);
+            const T d = gcd_i64(pivot, foo);
+            const T lp = cquo(pivot, d);
+            foo = cquo(foo, d);
+            const T g0 = wmul(lp, uni64(S.den[s]));
+            if (!update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
+              if (lane == 0) sc.bad = 1;
+            }
+            row_store<T, NCH>(r, row, ncolp, lane);
+            row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane);
+            if (lane == 0) S.den[s] = nd;
+          }
+        }
       }
     }
     bsync<NW>();
@@ -1472,7 +1492,7 @@ extern "C" hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, i
 extern "C" size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax, int ebits) {
   const size_t WP = (size_t)wp_of(Wmax, ebits);
   const size_t NM = WP / 64, EB = ebits == 128 ? 16 : 8;
-  size_t shm = EB * ((size_t)Smax + WP) + sizeof(u64) * (size_t)Smax * NM + sizeof(float) * (size_t)Smax +
+  size_t shm = EB * (2 * (size_t)Smax + WP) + sizeof(u64) * (size_t)Smax * NM + sizeof(float) * (size_t)Smax +
                sizeof(u16) * (3 * (size_t)Smax + (size_t)Lmax + WP) + 3 * (size_t)Smax + (size_t)Lmax;
   return (shm + 15) & ~(size_t)15;
 }
