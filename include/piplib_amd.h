@@ -152,6 +152,19 @@ int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int ni, int nc, 
                          char **text, int *status, int64_t *pivots);
 void pipamd_free(void *p);
 
+/* The same for `n` independent problems: `nthreads` host threads, each with its own decision
+ * tree, device arena and HIP stream, share the GPU (their launches overlap).  texts[i] / rcs[i] /
+ * statuses[i] / pivots[i] are what pipamd_solve_tableau returns for problem i (statuses and
+ * pivots may be NULL). */
+typedef struct pipamd_problem {
+  int32_t nvar, nparm, ni, nc, bigparm, nq;
+  const int64_t *ineq; /* ni x (nvar+nparm+1) */
+  const int64_t *ctx;  /* nc x (nparm+1) */
+} pipamd_problem;
+int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
+                          int deepest_cut, int nthreads, char **texts, int *rcs, int *statuses,
+                          int64_t *pivots);
+
 /* pip_solve() (reference source/piplib.c:722-880) with the same argument meaning.  The
  * structures below have the memory layout of the reference's int64 ("dp" / piplib64) types
  * PipMatrix, PipVector, PipNewparm, PipList, PipQuast and PipOptions

@@ -20,7 +20,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pip_host.h"
@@ -101,10 +103,22 @@ struct Snap {  // host copy of a job's row tables and rows
 
 class Tree {
  public:
-  Tree(pipamd_engine *e, int deepest) : deepest_(deepest) { (void)e; }
+  Tree(pipamd_engine *e, int deepest) : deepest_(deepest) {
+    (void)e;
+    if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) st_ = 0;
+  }
   ~Tree() {
     if (d_arena_) hipFree(d_arena_);
     if (d_jobs_) hipFree(d_jobs_);
+    if (st_) hipStreamDestroy(st_);
+  }
+  // reuse the device buffers for another problem
+  void reset(int deepest) {
+    deepest_ = deepest;
+    tape.clear();
+    pivots = 0;
+    fail_status = 0;
+    top_ = 0;
   }
   std::vector<Cell> tape;
   long long pivots = 0;
@@ -134,6 +148,7 @@ class Tree {
 
  private:
   int deepest_;
+  hipStream_t st_ = 0;
   i64 *d_arena_ = nullptr;
   size_t arena_words_ = 0, top_ = 0;
   PipJob *d_jobs_ = nullptr;
@@ -142,6 +157,12 @@ class Tree {
   void fail(int st) {
     fail_status = st;
     throw (int)PIPAMD_E_SOLVER;
+  }
+  // every transfer and launch of a tree goes through its own stream, so several trees (one per
+  // host thread) overlap on the GPU
+  void copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    HIPTHROW(hipMemcpyAsync(dst, src, bytes, kind, st_));
+    HIPTHROW(hipStreamSynchronize(st_));
   }
   void push(int kind, i64 a, i64 b) {
     tape.push_back(Cell{kind, a, b});
@@ -155,7 +176,7 @@ class Tree {
     i64 *n = nullptr;
     HIPTHROW(hipMalloc((void **)&n, nw * sizeof(i64)));
     if (d_arena_) {
-      HIPTHROW(hipMemcpy(n, d_arena_, top_ * sizeof(i64), hipMemcpyDeviceToDevice));
+      copy(n, d_arena_, top_ * sizeof(i64), hipMemcpyDeviceToDevice);
       hipFree(d_arena_);
     }
     d_arena_ = n;
@@ -213,7 +234,7 @@ class Tree {
       ref[nvar + i] = i;
       for (int c = 0; c < ncol; c++) blk[2 * (size_t)L + (size_t)i * W + c] = rows[(size_t)i * ncol + c];
     }
-    HIPTHROW(hipMemcpy(d_arena_ + j.block_off, blk.data(), blk.size() * sizeof(i64), hipMemcpyHostToDevice));
+    copy(d_arena_ + j.block_off, blk.data(), blk.size() * sizeof(i64), hipMemcpyHostToDevice);
   }
 
   HostJob make_job(int nvar, int nparm, int ni, int bigparm, int tflags, const i64 *rows) {
@@ -243,7 +264,7 @@ class Tree {
     s.S = j.pj.S;
     s.W = j.pj.W;
     std::vector<i64> blk(2 * (size_t)s.L + (size_t)s.S * s.W);
-    HIPTHROW(hipMemcpy(blk.data(), d_arena_ + j.block_off, blk.size() * sizeof(i64), hipMemcpyDeviceToHost));
+    copy(blk.data(), d_arena_ + j.block_off, blk.size() * sizeof(i64), hipMemcpyDeviceToHost);
     s.den.assign(blk.begin(), blk.begin() + s.L);
     const int *flag = (const int *)(blk.data() + s.L);
     s.flag.assign(flag, flag + s.L);
@@ -253,7 +274,7 @@ class Tree {
   }
   void set_flag(const HostJob &j, int row, int f) {
     int *g_flag = (int *)(d_arena_ + j.pj.rows_off + j.pj.L);
-    HIPTHROW(hipMemcpy(g_flag + row, &f, sizeof(int), hipMemcpyHostToDevice));
+    copy(g_flag + row, &f, sizeof(int), hipMemcpyHostToDevice);
   }
 
   // run the engine on a set of jobs until none is PIPAMD_ST_RUN
@@ -274,10 +295,10 @@ class Tree {
       Wm = std::max(Wm, (int)tab[i].W);
     }
     for (int pass = 0; pass < 64; pass++) {
-      HIPTHROW(hipMemcpy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice));
+      copy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice);
       for (int guard = 0; guard < 4096; guard++) {
-        HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0));
-        HIPTHROW(hipMemcpy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost));
+        HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, st_));
+        copy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost);
         bool again = false;
         for (int i = 0; i < n; i++)
           if (tab[i].status == PIPAMD_ST_RUN) again = true;
@@ -340,7 +361,7 @@ class Tree {
       if (!(s.flag[k] & PIPAMD_F_UNIT))
         for (int c = 0; c < s.W; c++) blk[2 * (size_t)L + (size_t)s.ref[k] * W + c] = s.vals[(size_t)s.ref[k] * s.W + c];
     }
-    HIPTHROW(hipMemcpy(d_arena_ + n.block_off, blk.data(), blk.size() * sizeof(i64), hipMemcpyHostToDevice));
+    copy(d_arena_ + n.block_off, blk.data(), blk.size() * sizeof(i64), hipMemcpyHostToDevice);
     PipJob keep = j.pj;
     j.block_off = n.block_off;
     j.block_words = n.block_words;
@@ -546,13 +567,13 @@ class Tree {
     std::vector<i64> row(W, 0);
     for (int j = 0; j < ncol; j++) row[j] = cut[j];
     if (newcol >= 0) row[newcol] = wadd(row[newcol], cut[ncol]);
-    HIPTHROW(hipMemcpy(d_arena_ + job.pj.vals_off + (size_t)ni * W, row.data(), W * sizeof(i64), hipMemcpyHostToDevice));
+    copy(d_arena_ + job.pj.vals_off + (size_t)ni * W, row.data(), W * sizeof(i64), hipMemcpyHostToDevice);
     i64 *g_den = d_arena_ + job.pj.rows_off;
     int *g_flag = (int *)(g_den + L), *g_ref = g_flag + L;
     const int fl = PIPAMD_F_MINUS;
-    HIPTHROW(hipMemcpy(g_den + nligne, &D, sizeof(i64), hipMemcpyHostToDevice));
-    HIPTHROW(hipMemcpy(g_flag + nligne, &fl, sizeof(int), hipMemcpyHostToDevice));
-    HIPTHROW(hipMemcpy(g_ref + nligne, &ni, sizeof(int), hipMemcpyHostToDevice));
+    copy(g_den + nligne, &D, sizeof(i64), hipMemcpyHostToDevice);
+    copy(g_flag + nligne, &fl, sizeof(int), hipMemcpyHostToDevice);
+    copy(g_ref + nligne, &ni, sizeof(int), hipMemcpyHostToDevice);
     ni++;
     job.pj.ni = ni;
     job.pj.nparm = nparm;
@@ -565,7 +586,7 @@ class Tree {
     const size_t n = (size_t)nvar * (nparm + 1);
     std::vector<i64> buf(n + nvar);
     if (n + nvar)
-      HIPTHROW(hipMemcpy(buf.data(), d_arena_ + job.pj.sol_off, (n + nvar) * sizeof(i64), hipMemcpyDeviceToHost));
+      copy(buf.data(), d_arena_ + job.pj.sol_off, (n + nvar) * sizeof(i64), hipMemcpyDeviceToHost);
     push(S_LIST, nvar, 0);
     for (int i = 0; i < nvar; i++) {
       push(S_FORM, nparm + 1, 0);
@@ -624,8 +645,8 @@ class Tree {
       const size_t mark = top_;
       HostJob child = alloc_job(nvar, nparm, ni, bigparm, flags, job.pj.S, job.pj.W);
       if (child.pj.L != job.pj.L || child.pj.S != job.pj.S || child.pj.W != job.pj.W) fail(PIPAMD_ST_INTERNAL);
-      HIPTHROW(hipMemcpy(d_arena_ + child.block_off, d_arena_ + job.block_off,
-                         (2 * (size_t)job.pj.L + (size_t)job.pj.S * job.pj.W) * sizeof(i64), hipMemcpyDeviceToDevice));
+      copy(d_arena_ + child.block_off, d_arena_ + job.block_off,
+                         (2 * (size_t)job.pj.L + (size_t)job.pj.S * job.pj.W) * sizeof(i64), hipMemcpyDeviceToDevice);
       child.pj.ldet = job.pj.ldet;
       memcpy(child.pj.det, job.pj.det, sizeof job.pj.det);
       push(S_IF, 0, 0);
@@ -751,10 +772,10 @@ void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) {
 
 }  // namespace
 
-extern "C" int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int nq,
-                                    const int64_t *ineq, const int64_t *ctx, int simplify, int deepest_cut, char **text,
-                                    int *status, int64_t *pivots) {
-  if (!e || !text || nvar < 0 || nparm < 0 || ni < 0 || nc < 0 || (ni && !ineq) || (nc && !ctx)) {
+// one problem on an existing tree (device buffers and stream are reused between problems)
+static int solve_one(Tree &t, int nvar, int nparm, int ni, int nc, int bigparm, int nq, const int64_t *ineq,
+                     const int64_t *ctx, int simplify, int deepest_cut, char **text, int *status, int64_t *pivots) {
+  if (!text || nvar < 0 || nparm < 0 || ni < 0 || nc < 0 || (ni && !ineq) || (nc && !ctx)) {
     pipamd_set_error("pipamd_solve_tableau: invalid argument");
     return PIPAMD_E_INVALID;
   }
@@ -772,8 +793,7 @@ extern "C" int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int n
     simplify_rows(a, ni, ncol, nvar);
     simplify_rows(c, nc, nparm + 1, nparm);
   }
-  if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
-  Tree t(e, deepest_cut);
+  t.reset(deepest_cut);
   std::string out;
   int rc = PIPAMD_OK;
   try {
@@ -796,6 +816,45 @@ extern "C" int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int n
   return PIPAMD_OK;
 }
 
+extern "C" int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int nq,
+                                    const int64_t *ineq, const int64_t *ctx, int simplify, int deepest_cut, char **text,
+                                    int *status, int64_t *pivots) {
+  if (!e) return PIPAMD_E_INVALID;
+  if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
+  Tree t(e, deepest_cut);
+  return solve_one(t, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify, deepest_cut, text, status, pivots);
+}
+
+// Many independent problems: `nthreads` host threads, each with its own tree (device arena and
+// HIP stream), pull problems from a shared counter; their launches overlap on the GPU.
+// rc[i] receives what pipamd_solve_tableau would have returned for problem i.
+extern "C" int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
+                                     int nthreads, char **texts, int *rcs, int *statuses, int64_t *pivots) {
+  if (!e || n < 0 || (n && (!probs || !texts || !rcs))) return PIPAMD_E_INVALID;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > n) nthreads = n > 0 ? n : 1;
+  std::atomic<int> next(0);
+  const int device = e->device;
+  auto worker = [&]() {
+    if (hipSetDevice(device) != hipSuccess) return;
+    Tree t(e, deepest_cut);
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) break;
+      const pipamd_problem &p = probs[i];
+      int st = 0;
+      int64_t pv = 0;
+      rcs[i] = solve_one(t, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx, simplify, deepest_cut, &texts[i],
+                         &st, &pv);
+      if (statuses) statuses[i] = st;
+      if (pivots) pivots[i] = pv;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int k = 0; k < nthreads; k++) th.emplace_back(worker);
+  for (auto &x : th) x.join();
+  return PIPAMD_OK;
+}
 
 // =========================================================================== pip_solve
 // The PolyLib-matrix front end (reference source/piplib.c:722-880) on top of the same tree:

@@ -240,3 +240,39 @@ def pip_solve(engine, domain, context, bignum, **options):
     L.pipamd_free(s)
     L.pipamd_quast_free(q)
     return text, piv.value
+
+
+class PipProblem(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nvar", "nparm", "ni", "nc", "bigparm", "nq")] + \
+               [("ineq", C.c_void_p), ("ctx", C.c_void_p)]
+
+
+def solve_tableaux(engine, problems, simplify=True, deepest_cut=False, nthreads=8):
+    """Many problems (objects with nvar, nparm, ni, nc, bigparm, nq, ineq, ctx) through
+    pipamd_solve_tableaux.  Returns a list of (text | None, rc, status, pivots)."""
+    import numpy as np
+    n = len(problems)
+    arr = (PipProblem * max(1, n))()
+    keep = []
+    for i, p in enumerate(problems):
+        a = np.ascontiguousarray(p.ineq, dtype=np.int64).reshape(p.ni, p.nvar + p.nparm + 1)
+        c = np.ascontiguousarray(p.ctx, dtype=np.int64).reshape(p.nc, p.nparm + 1)
+        keep += [a, c]
+        arr[i] = PipProblem(p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, a.ctypes.data, c.ctypes.data)
+    texts = (C.c_void_p * max(1, n))()
+    rcs = (C.c_int * max(1, n))()
+    sts = (C.c_int * max(1, n))()
+    piv = (C.c_int64 * max(1, n))()
+    L = lib()
+    L.pipamd_solve_tableaux.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(L.pipamd_solve_tableaux(engine._h, n, arr, int(bool(simplify)), int(bool(deepest_cut)), int(nthreads),
+                                   texts, rcs, sts, piv))
+    out = []
+    for i in range(n):
+        t = None
+        if rcs[i] == 0 and texts[i]:
+            t = C.string_at(texts[i]).decode()
+            L.pipamd_free(texts[i])
+        out.append((t, rcs[i], sts[i], piv[i]))
+    return out

@@ -221,3 +221,28 @@ def test_full_size_int128_config():
         assert pv[b] == r.pivots, b
         got = "()" if st[b] == eng.ST_NIL else pb.squash(solution_text(num[b], den[b]))
         assert got == pb.squash(r.text), b
+
+
+def test_many_parametric_problems_multithreaded():
+    """pipamd_solve_tableaux: 8 host threads / streams sharing the GPU give exactly the answers
+    of the one-at-a-time entry point (which the other tests pin to the oracle)."""
+    from piplib_amd import engine as eng, synth
+    probs = [p for seed, shape in ((41, (5, 2, 7, 2)), (42, (4, 3, 6, 3)), (43, (6, 1, 8, 1)))
+             for p in synth.random_problems(seed, 30, *shape, 1)]
+    import pipbatch as pb
+    import subprocess
+    keep = []
+    for p in probs:  # drop the few the reference itself never finishes
+        try:
+            if pb.run_batch(pb.ORACLEPIP, [p], timeout=2).results[0].pivots <= 3000:
+                keep.append(p)
+        except subprocess.TimeoutExpired:
+            pass
+    e = eng.Engine(0)
+    many = eng.solve_tableaux(e, keep, nthreads=8)
+    for p, (text, rc, st, piv) in zip(keep, many):
+        try:
+            t1, p1 = eng.solve_tableau(e, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx)
+            assert rc == 0 and text == t1 and piv == p1
+        except eng.SolverError as ex:
+            assert rc == -5 and st == ex.status
