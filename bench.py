@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--batch", type=int, default=10000, help="tableaux per GPU")
     ap.add_argument("--waves", type=int, default=0, help="waves per tableau (0 = engine default)")
     ap.add_argument("--round", type=int, default=0, help="pivots per tableau per launch (0 = engine default)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch tableaux per GPU (default); strong: --batch tableaux in all, sharded over the ranks")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (streams/threads)")
     ap.add_argument("--no-dense", action="store_true", help="skip the row-skipping-off measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -90,7 +92,12 @@ def main():
     dev = torch.device("cuda", local)
     pdist.init("nccl", dev)  # nccl == RCCL on ROCm
 
-    rows_h = synth.lexmin_batch(pdist.shard_seed(1000, rank), args.batch, NVAR, NI)
+    if args.scaling == "strong":  # BASELINE configs[3]: one 10k batch sharded over the GPUs
+        lo, hi = pdist.shard_range(args.batch, rank, world)
+        rows_h = synth.lexmin_batch(1000, args.batch, NVAR, NI)[lo:hi]
+    else:
+        rows_h = synth.lexmin_batch(pdist.shard_seed(1000, rank), args.batch, NVAR, NI)
+    my_batch = rows_h.shape[0]
     rows_d = torch.as_tensor(rows_h, dtype=torch.int64).to(dev)
 
     # `depth` batches in flight, each with its own engine, workspace, HIP stream and host thread:
@@ -152,7 +159,7 @@ def main():
     solved = int(((st == eng.ST_SOLUTION) | (st == eng.ST_NIL)).sum())
 
     rowsw = b.counters()["rows_rewritten"]
-    tot, dt_max = pdist.gather_totals([piv, args.batch, solved, cuts, rowsw], dt, dev)
+    tot, dt_max = pdist.gather_totals([piv, my_batch, solved, cuts, rowsw], dt, dev)
 
     # Same workload once more with row skipping off: every real row is read and written on
     # every pivot, which is the reference's access pattern (traiter.c:467-502) and the regime
@@ -193,7 +200,7 @@ def main():
         if os.path.exists(tp):
             try:
                 t = json.load(open(tp))
-                if t.get("batch_per_gpu") == args.batch:
+                if t.get("batch_per_gpu") == my_batch:
                     traffic = t["hbm_bytes_per_step"]
             except Exception:
                 traffic = None
@@ -206,12 +213,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "int64",
             "data": "synthetic",
             "config": {"workload": "10k-batch synthetic 64x128 tableaux, int64, integer solve with Gomory cuts",
-                       "batch_per_gpu": args.batch, "nvar": NVAR, "nparm": NPARM, "ni": NI,
+                       "batch_per_gpu": my_batch, "nvar": NVAR, "nparm": NPARM, "ni": NI,
                        "parallelism": f"{world} x independent batches (one workgroup per tableau)",
                        "pipeline_depth": depth},
             "problems_per_sec": float(tot[1]) / (ms_step * 1e-3),

@@ -170,7 +170,7 @@ int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *problem
  * PipMatrix, PipVector, PipNewparm, PipList, PipQuast and PipOptions
  * (include/piplib/piplib.h:194-329), and every node of the returned tree is malloc'ed on its
  * own, so the reference's pip_quast_print / pip_quast_free can be applied to it directly.
- * *quast is NULL for the reference's "void" answers.  Compute_dual is not supported. */
+ * *quast is NULL for the reference's "void" answers. */
 typedef struct pipamd_matrix {
   unsigned int NbRows, NbColumns;
   long long **p;

@@ -115,12 +115,14 @@ class Tree {
   // reuse the device buffers for another problem
   void reset(int deepest) {
     deepest_ = deepest;
+    dual_ = false;
     tape.clear();
     pivots = 0;
     fail_status = 0;
     top_ = 0;
   }
   std::vector<Cell> tape;
+  bool dual_ = false;  // Compute_dual (rational solves only, piplib.c:854-857)
   long long pivots = 0;
   int fail_status = 0;
 
@@ -141,8 +143,9 @@ class Tree {
       top_ = mark;
       if (cj.pj.status == PIPAMD_ST_NIL) return false;  // "void"
     }
-    HostJob job = make_job(nvar, nparm, ni, bigparm, nq ? PIPAMD_T_INT : 0, ineq);
-    node(job, ctx, nvar, nparm, ni, bigparm, nq ? PIPAMD_T_INT : 0);
+    const int tfl = nq ? PIPAMD_T_INT : (dual_ ? PIPAMD_T_DUAL : 0);
+    HostJob job = make_job(nvar, nparm, ni, bigparm, tfl, ineq);
+    node(job, ctx, nvar, nparm, ni, bigparm, tfl);
     return true;
   }
 
@@ -594,9 +597,80 @@ class Tree {
     }
   }
 
+  // tab_sort_rows' bookkeeping for the dual (traiter.c:556-623): where each inequality of this
+  // call's tableau ends up after the sort the kernel is about to do.  Replayed on the host from
+  // a snapshot (same keys, same selection sort); rows do not move afterwards.
+  static int trunc_x86(double t) { return (!(t > -2147483649.0 && t < 2147483648.0)) ? (int)0x80000000 : (int)t; }
+  std::vector<int> dual_positions(const HostJob &job, int nvar, int ni) {
+    Snap s = download(job);
+    const int nligne = nvar + ni;
+    std::vector<float> size(nligne, 0.f);
+    std::vector<int> ineq(nligne, 0), order(nligne), pos(std::max(1, ni), 0);
+    for (int i = 0; i < nligne; i++) order[i] = i;
+    double smax = 0;
+    for (int i = nvar; i < nligne; i++) {
+      if (s.flag[i] & PIPAMD_F_UNIT) continue;
+      const i64 *r = s.row(i);
+      double sz = 0, d = (double)s.den[i];
+      for (int j = 0; j < nvar; j++) {
+        int q = trunc_x86((double)r[j] / d);
+        double a = (double)(q < 0 ? (int)(0u - (unsigned)q) : q);
+        sz = sz > a ? sz : a;
+      }
+      size[i] = (float)sz;
+      smax = sz > smax ? sz : smax;
+      ineq[i] = i - nvar;
+    }
+    std::vector<int> isunit(nligne);
+    for (int i = 0; i < nligne; i++) isunit[i] = (s.flag[i] & PIPAMD_F_UNIT) != 0;
+    for (int i = nvar; i < nligne; i++) {
+      if (isunit[i]) continue;
+      double sm = smax;
+      int pv = i;
+      for (int j = i; j < nligne; j++) {
+        if (isunit[j]) continue;
+        if ((double)size[j] < sm) {
+          sm = size[j];
+          pv = j;
+        }
+      }
+      if (pv != i) {
+        std::swap(size[pv], size[i]);
+        std::swap(ineq[pv], ineq[i]);
+      }
+    }
+    // the reference writes pos[ineq[i]] for unit rows too, whose ineq[i] it never set
+    // (traiter.c:577-578 vs 617-618); zero-filled, as our oracle and the reference's fixtures have it
+    for (int i = nvar; i < nligne; i++)
+      if (ineq[i] >= 0 && ineq[i] < ni) pos[ineq[i]] = i;
+    return pos;
+  }
+  // solution_dual, traiter.c:274-294
+  void emit_dual(const HostJob &job, int nvar, int ni, const std::vector<int> &pos) {
+    Snap s = download(job);
+    push(S_LIST, ni, 0);
+    for (int i = 0; i < ni; i++) {
+      push(S_FORM, 1, 0);
+      const int k = pos[i];
+      if (s.flag[k] & PIPAMD_F_UNIT) {
+        const int u = s.ref[k];
+        i64 v;
+        if (s.flag[0] & PIPAMD_F_UNIT)
+          v = (s.ref[0] == u) ? s.den[0] : 0;
+        else
+          v = s.row(0)[u];
+        push(S_VAL, v, s.den[0]);
+      } else
+        push(S_VAL, 0, 1);
+    }
+  }
+
   // ------------------------------------------------------------- traiter()
   void node(HostJob &job, Ctx ctx /* this call's own copy, traiter.c:654 */, int nvar, int nparm, int ni,
             int bigparm, int flags) {
+    std::vector<int> pos;
+    if (flags & PIPAMD_T_DUAL) pos = dual_positions(job, nvar, ni);
+    const int ni0 = ni;
     for (;;) {
       job.pj.status = PIPAMD_ST_RUN;
       std::vector<HostJob *> js{&job};
@@ -605,7 +679,10 @@ class Tree {
       pivots += job.pj.npiv - piv0;
       ni = job.pj.ni;
       switch (job.pj.status) {
-        case PIPAMD_ST_SOLUTION: emit_solution(job, nvar, nparm); return;
+        case PIPAMD_ST_SOLUTION:
+          emit_solution(job, nvar, nparm);
+          if (flags & PIPAMD_T_DUAL) emit_dual(job, nvar, ni0, pos);
+          return;
         case PIPAMD_ST_NIL: push(S_NIL, 0, 0); return;
         case PIPAMD_ST_CAPACITY: grow(job, job.pj.S + 32, job.pj.W); continue;
         case PIPAMD_ST_NEED_PARMCUT:
@@ -1012,7 +1089,10 @@ pipamd_quast *q_quast(const std::vector<Cell> &t, size_t *i, pipamd_quast *fathe
   }
   (*i)++;
   switch (p->kind) {
-    case S_LIST: q->list = q_list(t, i, (int)p->a, Bg, Urs_p, flags); break;
+    case S_LIST:
+      q->list = q_list(t, i, (int)p->a, Bg, Urs_p, flags);
+      if (flags & SOL_DUAL) q->next_then = q_quast(t, i, q, Bg, Urs_p, 0);
+      break;
     case S_NIL: break;
     case S_IF:
       q->condition = q_vector(t, i, Bg, Urs_p, flags & SOL_REMOVE);
@@ -1128,11 +1208,45 @@ void pr_quast(std::string &o, const pipamd_quast *q, int indent) {  // piplib.c:
   }
 }
 
+void free_list_node(pipamd_list *l);
+// piplib.c:651-690 pip_quast_equalities_dual
+void equalities_dual(pipamd_quast *s, const pipamd_matrix *inequnk) {
+  if (!s) return;
+  if (s->condition) {
+    equalities_dual(s->next_then, inequnk);
+    equalities_dual(s->next_else, inequnk);
+  }
+  if (!s->list || !s->next_then || !s->next_then->list) return;
+  pipamd_list **lp = &s->next_then->list, *l;
+  for (unsigned i = 0; i < inequnk->NbRows; ++i) {
+    if (inequnk->p[i][0] == 0) {
+      if ((*lp)->vector->the_vector[0] != 0) {
+        lp = &(*lp)->next;
+        l = *lp;
+        *lp = l->next;
+        free_list_node(l);
+      } else {
+        l = *lp;
+        *lp = l->next;
+        free_list_node(l);
+        (*lp)->vector->the_vector[0] = wneg((*lp)->vector->the_vector[0]);
+        lp = &(*lp)->next;
+      }
+    } else
+      lp = &(*lp)->next;
+  }
+}
+
 void free_vec(pipamd_vector *v) {
   if (!v) return;
   free(v->the_vector);
   free(v->the_deno);
   free(v);
+}
+
+void free_list_node(pipamd_list *l) {
+  free_vec(l->vector);
+  free(l);
 }
 
 }  // namespace
@@ -1173,10 +1287,6 @@ extern "C" int pipamd_pip_solve(pipamd_engine *e, const pipamd_matrix *inequnk, 
   if (status) *status = 0;
   if (pivots) *pivots = 0;
   if (!inequnk) return PIPAMD_OK;
-  if (opt->Compute_dual && !opt->Nq) {
-    pipamd_set_error("pipamd_pip_solve: Compute_dual is not supported by the device path");
-    return PIPAMD_E_INVALID;
-  }
   int Np = ineqpar ? (int)ineqpar->NbColumns - 2 : 0;
   const int Nn = (int)inequnk->NbColumns - Np - 2;
   unsigned Nl = inequnk->NbRows;
@@ -1238,6 +1348,10 @@ extern "C" int pipamd_pip_solve(pipamd_engine *e, const pipamd_matrix *inequnk, 
   }
   if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
   Tree t(e, opt->Deepest_cut);
+  if (!opt->Nq && opt->Compute_dual) {  // piplib.c:854-857
+    t.dual_ = true;
+    sol_flags |= SOL_DUAL;
+  }
   int rc = PIPAMD_OK;
   bool non_vide = false;
   try {
@@ -1253,5 +1367,6 @@ extern "C" int pipamd_pip_solve(pipamd_engine *e, const pipamd_matrix *inequnk, 
   if (opt->Simplify) t_simplify(t.tape, 0);
   size_t xq = 0;
   *quast = q_quast(t.tape, &xq, nullptr, Bg - Nn - 1, Urs_parms, sol_flags);
+  if ((sol_flags & SOL_DUAL) && Nl > inequnk->NbRows) equalities_dual(*quast, inequnk);
   return PIPAMD_OK;
 }

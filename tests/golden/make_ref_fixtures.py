@@ -37,6 +37,18 @@ def main():
         err = p.stderr.decode(errors="replace").strip().splitlines()
         manifest[key] = {"rc": p.returncode, "stderr": err[0] if err else "", "ll": out_name}
         print(key, manifest[key])
+    # Compute_dual (rational solve + dual variables): non-parametric examples only -- with
+    # parameters the reference reads uninitialised memory in tab_sort_rows (traiter.c:576-589
+    # skips unit rows before ineq[i] is set) and crashes or prints garbage.
+    for name in ("small", "square", "max", "big", "cg1", "sven"):
+        src = open(os.path.join(HERE, "example", name + ".pip"), "rb").read() + b"\nRational\nDual\n"
+        with open(os.path.join(out_dir, f"dual__{name}.pip"), "wb") as f:
+            f.write(src)
+        p = subprocess.run([REFPIP, "pip"], input=src, capture_output=True, timeout=60)
+        assert p.returncode == 0, name
+        with open(os.path.join(out_dir, f"dual__{name}.ll"), "wb") as f:
+            f.write(p.stdout)
+        print("dual", name, len(p.stdout))
     with open(os.path.join(out_dir, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 

@@ -69,3 +69,21 @@ def test_pip_solve_golden_on_gpu(name):
            "- the constraint matrix.\n" + matrix_text(domain) + "\n" + text)
     want = open(os.path.join(G, "example", name + ".ll"), encoding="latin-1").read()
     assert pb.squash(got) == pb.squash(want)
+
+
+@pytest.mark.parametrize("name", ["small", "square", "max", "big", "cg1", "sven"])
+def test_compute_dual_on_gpu(name):
+    """pip_solve with Nq = 0 and Compute_dual = 1 vs reference-generated fixtures."""
+    from datfile import read_pip, matrix_text
+    from piplib_amd import engine as eng
+    d = os.path.join(G, "ref_dp")
+    context, bignum, domain, opts = read_pip(os.path.join(d, f"dual__{name}.pip"))
+    assert opts.get("Nq") == 0 and opts.get("Compute_dual") == 1
+    e = eng.Engine(0)
+    bg = bignum + (domain.shape[1] - context.shape[1]) if bignum > 0 else bignum
+    text, _ = eng.pip_solve(e, domain, context, bg, **opts)
+    got = ("[PIP2-like future input] Please enter:\n- the context matrix,\n" + matrix_text(context) +
+           "- the bignum column (start at 0, -1 if no bignum),\n" + f"{bignum}\n" +
+           "- the constraint matrix.\n" + matrix_text(domain) + "\n" + text)
+    want = open(os.path.join(d, f"dual__{name}.ll"), encoding="latin-1").read()
+    assert pb.squash(got) == pb.squash(want)
