@@ -1232,6 +1232,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             T nd;
             // multipliers from the row's own pivot-column entry (traiter.c:470-476)
             T foo = row_entry<T, NCH>(r, pc, ph, pl);
+            if (foo == 0 && (S.sig[s] & SIG_RED)) {
+              // only reached with PIPAMD_T_NOSKIP: multipliers (1, 0) and gcd 1, the reference
+              // rewrites the row with the bits it read -- so do we, without the arithmetic
+              row_store<T, NCH>(r, row, ncolp, lane);
+              if (lane == 0) S.sig[s] &= ~0xC0;
+              continue;
+            }
             const T d = gcd_i64(pivot, foo);
             const T lp = cquo(pivot, d);
             foo = cquo(foo, d);
