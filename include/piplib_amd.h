@@ -165,6 +165,15 @@ int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *problem
                           int deepest_cut, int nthreads, char **texts, int *rcs, int *statuses,
                           int64_t *pivots);
 
+/* The same results from a lock-step scheduler: one explicit traiter() state machine per problem
+ * and, per step, ONE clone / patch / pivot-kernel / gather sequence for the whole batch, so the
+ * host <-> device latency is paid once per step instead of once per problem.  Problems that need
+ * a rare path (tableau growth beyond the reserved block, deepest cuts) are finished by the
+ * per-problem tree of pipamd_solve_tableau. */
+int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
+                                   int deepest_cut, char **texts, int *rcs, int *statuses,
+                                   int64_t *pivots);
+
 /* pip_solve() (reference source/piplib.c:722-880) with the same argument meaning.  The
  * structures below have the memory layout of the reference's int64 ("dp" / piplib64) types
  * PipMatrix, PipVector, PipNewparm, PipList, PipQuast and PipOptions

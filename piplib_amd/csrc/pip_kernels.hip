@@ -1482,6 +1482,100 @@ __global__ void pip_batch_running_kernel(const PipJob *jobs, int njobs, int *out
   }
 }
 
+// ---------------------------------------------------------------- forest helpers
+// Batched host<->device traffic of the lock-step decision-tree scheduler (pip_forest.cpp):
+// one clone pass, one patch pass, one advance launch and one gather pass per step serve every
+// problem of the batch.
+// clone: list of (src word, dst word, n words) int64 triples -- expanser for a tree split
+__global__ void pip_clone_kernel(i64 *arena, const i64 *list, int n) {
+  const int b = blockIdx.x;
+  if (b >= n) return;
+  const i64 *src = arena + list[3 * b];
+  i64 *dst = arena + list[3 * b + 1];
+  const i64 nw = list[3 * b + 2];
+  for (i64 i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+}
+// patch: patch p = { dst (32-bit word index into the arena), n, payload[n] } at buf[index[p]]
+__global__ void pip_patch_kernel(int *arena32, const int *buf, const i64 *index, int n) {
+  const int b = blockIdx.x;
+  if (b >= n) return;
+  const int *p = buf + index[b];
+  const i64 dst = ((i64)(unsigned)p[0]) | ((i64)p[1] << 32);
+  const int nw = p[2];
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) arena32[dst + i] = p[3 + i];
+}
+// gather: what the host needs from each job of the last launch, by status, into out + off[b]:
+//   NEED_COMPA  : n, then per undecided row (ascending): row, critic, constant, nparm parameter coefs
+//   NEED_PARMCUT: row (aux), denominator, ncol entries
+//   SOLUTION    : the solution block (nvar*(nparm+1) numerators, nvar denominators)
+__global__ void pip_gather_kernel(const PipJob *jobs, const i64 *arena, int njobs, i64 *out, const i64 *off) {
+  const int b = blockIdx.x;
+  if (b >= njobs) return;
+  const PipJob *J = &jobs[b];
+  i64 *o = out + off[b];
+  const int nvar = J->nvar, nparm = J->nparm, L = J->L, W = J->W, ncol = nvar + nparm + 1;
+  const i64 *g_den = arena + J->rows_off;
+  const int *g_flag = (const int *)(g_den + L);
+  const int *g_ref = g_flag + L;
+  const i64 *vals = arena + J->vals_off;
+  const int lane = threadIdx.x;  // one wave
+  if (J->status == PIPAMD_ST_NEED_COMPA) {
+    const int nligne = nvar + J->ni;
+    const int rec = 3 + nparm;
+    int base = 0;
+    for (int k0 = 0; k0 < nligne; k0 += 64) {
+      const int k = k0 + lane;
+      const bool und = k < nligne && (g_flag[k] & (PIPAMD_F_CRITIC | PIPAMD_F_UNKNOWN));
+      const u64 m = __ballot(und);
+      if (und) {
+        const i64 *r = vals + (size_t)g_ref[k] * W;
+        i64 *q = o + 1 + (size_t)(base + __popcll(m & ((1ull << lane) - 1))) * rec;
+        int critic = 1;
+        for (int j = 0; j < nvar; j++)
+          if (r[j] > 0) {
+            critic = 0;
+            break;
+          }
+        q[0] = k;
+        q[1] = critic;
+        q[2] = r[nvar];
+        for (int j = 0; j < nparm; j++) q[3 + j] = r[nvar + 1 + j];
+      }
+      base += __popcll(m);
+    }
+    if (lane == 0) o[0] = base;
+  } else if (J->status == PIPAMD_ST_NEED_PARMCUT) {
+    const int ci = J->aux;
+    const i64 *r = vals + (size_t)g_ref[ci] * W;
+    if (lane == 0) {
+      o[0] = ci;
+      o[1] = g_den[ci];
+    }
+    for (int j = lane; j < ncol; j += 64) o[2 + j] = r[j];
+  } else if (J->status == PIPAMD_ST_SOLUTION) {
+    const i64 *sn = arena + J->sol_off;
+    const int n = nvar * (nparm + 1) + nvar;
+    for (int e = lane; e < n; e += 64) o[e] = sn[e];
+  }
+}
+
+extern "C" hipError_t pipk_launch_clone(i64 *arena, const i64 *list, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pip_clone_kernel, dim3(n), dim3(256), 0, stream, arena, list, n);
+  return hipGetLastError();
+}
+extern "C" hipError_t pipk_launch_patch(i64 *arena, const int *buf, const i64 *index, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pip_patch_kernel, dim3(n), dim3(128), 0, stream, (int *)arena, buf, index, n);
+  return hipGetLastError();
+}
+extern "C" hipError_t pipk_launch_gather(const PipJob *jobs, const i64 *arena, int njobs, i64 *out, const i64 *off,
+                                         hipStream_t stream) {
+  if (njobs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pip_gather_kernel, dim3(njobs), dim3(64), 0, stream, jobs, arena, njobs, out, off);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ launchers
 // columns a wave's registers cover (row chunks x 16 B per lane), by entry width
 static int wp_of(int Wmax, int ebits) {

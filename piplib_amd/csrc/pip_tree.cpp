@@ -149,7 +149,7 @@ class Tree {
     return true;
   }
 
- private:
+ public:  // (internal class; the lock-step Forest below reuses its helpers)
   int deepest_;
   hipStream_t st_ = 0;
   i64 *d_arena_ = nullptr;
@@ -930,6 +930,693 @@ extern "C" int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_probl
   std::vector<std::thread> th;
   for (int k = 0; k < nthreads; k++) th.emplace_back(worker);
   for (auto &x : th) x.join();
+  return PIPAMD_OK;
+}
+
+// =========================================================================== Forest
+// Lock-step scheduler for MANY parametric problems.  The per-problem Tree above pays a few host
+// <-> device round trips per decision; on tiny problems that latency dominates.  The Forest
+// keeps one explicit frame stack per problem (the same traiter() state machine, no recursion)
+// and serves every problem of the batch with ONE sequence per step:
+//   clone pass (tree splits) -> patch pass (new tableaux, flags, cut rows) -> advance launch
+//   (all runnable jobs of all problems) -> gather pass (undecided rows / cut rows / solutions).
+// Problems that hit a rare path (capacity growth, deepest cuts, dual) are handed to the Tree.
+namespace {
+
+struct FResult {
+  int rc = PIPAMD_OK, status = 0;
+  long long pivots = 0;
+  bool is_void = false;
+  std::vector<Cell> tape;
+};
+
+class Forest {
+ public:
+  explicit Forest(int device) {
+    (void)device;
+    if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) st_ = 0;
+  }
+  ~Forest() {
+    void *bufs[] = {d_arena_, d_jobs_, d_off_, d_out_, d_patch_, d_pidx_, d_clone_};
+    for (void *b : bufs)
+      if (b) hipFree(b);
+    if (st_) hipStreamDestroy(st_);
+  }
+
+  // returns per-problem results; results[i].rc == PIPAMD_E_TOOLARGE marks "use the Tree path"
+  void solve(int n, const pipamd_problem *probs, int simplify, std::vector<FResult> &res) {
+    res.assign(n, FResult());
+    P_.assign(n, Prob());
+    jobs_.clear();
+    // ---- regions
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+      const pipamd_problem &p = probs[i];
+      Prob &q = P_[i];
+      q.nvar = p.nvar;
+      q.nparm0 = p.nparm;
+      const size_t mainb = block_words(p.nvar, p.ni + 24, p.nvar + p.nparm + 1 + 6);
+      const size_t subb = block_words(p.nparm + 8, p.nc + 48, p.nparm + 8 + 1);
+      q.region_words = 24 * mainb + (size_t)(2 * (p.nvar + p.ni + 24) + 4) * subb;
+      q.region_off = total;
+      q.top = 0;
+      total += q.region_words;
+    }
+    ensure(d_arena_, arena_cap_, total * sizeof(i64));
+    // ---- start every problem
+    for (int i = 0; i < n; i++) {
+      try {
+        start(i, probs[i], simplify);
+      } catch (int code) {
+        finish_error(i, code);
+      }
+    }
+    // ---- lock-step loop
+    for (int step = 0; step < 200000; step++) {
+      std::vector<int> lj;
+      for (int i = 0; i < n; i++) {
+        Prob &q = P_[i];
+        if (q.done) continue;
+        Frame &f = q.stack.back();
+        if (f.phase == PH_RUN)
+          lj.push_back(f.job);
+        else
+          for (int k = 0; k < f.sub_count; k++)
+            if (jobs_[f.sub_begin + k].status == PIPAMD_ST_RUN) lj.push_back(f.sub_begin + k);
+      }
+      if (lj.empty()) break;
+      step_device(lj);
+      for (int i = 0; i < n; i++) {
+        if (P_[i].done) continue;
+        try {
+          advance(i);
+        } catch (int code) {
+          finish_error(i, code);
+        }
+      }
+    }
+    for (int i = 0; i < n; i++) {
+      Prob &q = P_[i];
+      if (!q.done) {
+        q.rc = PIPAMD_E_SOLVER;
+        q.status = PIPAMD_ST_INTERNAL;
+      }
+      res[i].rc = q.rc;
+      res[i].status = q.status;
+      res[i].pivots = q.pivots;
+      res[i].is_void = q.is_void;
+      res[i].tape.swap(q.tape);
+    }
+  }
+
+ private:
+  enum { PH_RUN = 0, PH_COMPA = 1 };
+  enum { K_CTX = 0, K_NODE = 1 };
+  struct Frame {
+    int kind = K_NODE, phase = PH_RUN;
+    int job = -1;
+    Ctx ctx;
+    int nparm = 0, ni = 0, bigparm = -1, flags = 0;
+    int last_npiv = 0;
+    size_t mark = 0;  // region top when the frame was pushed (released when it pops)
+    // compa_test in flight
+    std::vector<int> rows, critic;
+    std::vector<std::vector<i64>> rowvals;  // constant | parameters of each undecided row
+    int sub_begin = 0, sub_count = 0;
+    // split in flight (this frame is the parent waiting for its "then" child)
+    int split_row = -1;
+  };
+  struct Prob {
+    int nvar = 0, nparm0 = 0;
+    size_t region_off = 0, region_words = 0, top = 0;
+    std::vector<Frame> stack;
+    std::vector<Cell> tape;
+    long long pivots = 0;
+    int rc = PIPAMD_OK, status = 0;
+    bool done = false, is_void = false;
+    // pending main problem (started after the context test)
+    std::vector<i64> ineq;
+    int ni = 0, bigparm = -1, nq = 1;
+  };
+
+  hipStream_t st_ = 0;
+  std::vector<Prob> P_;
+  std::vector<PipJob> jobs_;  // master copies, index = job id
+  std::vector<int> lpos_;     // job id -> position in the last launch (or -1)
+  std::vector<i64> gout_, goff_;
+  // device buffers
+  i64 *d_arena_ = nullptr, *d_off_ = nullptr, *d_out_ = nullptr, *d_pidx_ = nullptr, *d_clone_ = nullptr;
+  PipJob *d_jobs_ = nullptr;
+  int *d_patch_ = nullptr;
+  size_t arena_cap_ = 0, jobs_cap_ = 0, off_cap_ = 0, out_cap_ = 0, patch_cap_ = 0, pidx_cap_ = 0, clone_cap_ = 0;
+  // staging of the current step
+  std::vector<int> patch_;
+  std::vector<i64> pidx_, clones_;
+
+  static int even(int x) { return (x + 1) & ~1; }
+  static size_t block_words(int nvar, int S, int W) {
+    W = even(W);
+    const int L = even(nvar + S);
+    return 2 * (size_t)L + (size_t)S * W + (size_t)even(nvar * (W - nvar) + nvar) + (size_t)even(S * 8 + (3 * L + 7) / 8);
+  }
+  template <class T>
+  void ensure(T *&buf, size_t &cap, size_t bytes) {
+    if (bytes <= cap) return;
+    if (buf) hipFree(buf);
+    cap = bytes * 2 + 4096;
+    HIPTHROW(hipMalloc((void **)&buf, cap));
+  }
+  void fail(int i, int st) {
+    P_[i].status = st;
+    throw (int)PIPAMD_E_SOLVER;
+  }
+  void finish_error(int i, int code) {
+    Prob &q = P_[i];
+    q.done = true;
+    q.rc = code;
+  }
+  void tape_push(int i, int kind, i64 a, i64 b) {
+    P_[i].tape.push_back(Cell{kind, a, b});
+    if (P_[i].tape.size() >= 4096) fail(i, PIPAMD_ST_INTERNAL);
+  }
+
+  // ---- patches ------------------------------------------------------------
+  void patch32(size_t dst32, const int *data, int n32) {
+    pidx_.push_back((i64)patch_.size());
+    patch_.push_back((int)(unsigned)(dst32 & 0xffffffffu));
+    patch_.push_back((int)(dst32 >> 32));
+    patch_.push_back(n32);
+    patch_.insert(patch_.end(), data, data + n32);
+  }
+  void patch64(size_t dst64, const i64 *data, size_t n64) { patch32(dst64 * 2, (const int *)data, (int)(n64 * 2)); }
+  void patch_flag(const PipJob &pj, int row, int f) { patch32(((size_t)pj.rows_off + pj.L) * 2 + row, &f, 1); }
+
+  // ---- jobs ---------------------------------------------------------------
+  // allocate a job block in problem i's region; throws TOOLARGE (-> Tree path) when it is full
+  int new_job(int i, int nvar, int nparm, int ni, int bigparm, int tflags, int S, int W) {
+    Prob &q = P_[i];
+    PipJob pj;
+    memset(&pj, 0, sizeof pj);
+    S = std::max(S, ni + 1);
+    W = even(std::max(W, nvar + nparm + 1));
+    if (W > PIPAMD_MAXCOL || S > PIPAMD_SMAX || nvar + S > PIPAMD_LMAX) throw (int)PIPAMD_E_TOOLARGE;
+    const int L = even(nvar + S);
+    const size_t words = block_words(nvar, S, W);
+    if (q.top + words > q.region_words) throw (int)PIPAMD_E_TOOLARGE;
+    const i64 off = (i64)(q.region_off + q.top);
+    q.top += words;
+    pj.rows_off = off;
+    pj.vals_off = off + 2 * (i64)L;
+    pj.sol_off = pj.vals_off + (i64)S * W;
+    pj.state_off = pj.sol_off + even(nvar * (W - nvar) + nvar);
+    pj.nvar = nvar;
+    pj.nparm = nparm;
+    pj.ni = ni;
+    pj.bigparm = bigparm;
+    pj.tflags = tflags | PIPAMD_T_SORT;
+    pj.L = L;
+    pj.S = S;
+    pj.W = W;
+    pj.status = PIPAMD_ST_RUN;
+    pj.ldet = 1;
+    pj.det[0] = 1;
+    pj.ebits = 64;
+    jobs_.push_back(pj);
+    return (int)jobs_.size() - 1;
+  }
+  // tab_alloc + tab_get (tab.c:158-248) as one patch
+  void fresh_block(int job, const std::vector<i64> &rows) {
+    const PipJob &pj = jobs_[job];
+    const int nvar = pj.nvar, ni = pj.ni, ncol = nvar + pj.nparm + 1, L = pj.L, S = pj.S, W = pj.W;
+    std::vector<i64> blk(2 * (size_t)L + (size_t)S * W, 0);
+    i64 *den = blk.data();
+    int *flag = (int *)(den + L), *ref = flag + L;
+    for (int k = 0; k < nvar; k++) {
+      den[k] = 1;
+      flag[k] = PIPAMD_F_UNIT;
+      ref[k] = k;
+    }
+    for (int k = 0; k < ni; k++) {
+      den[nvar + k] = 1;
+      flag[nvar + k] = PIPAMD_F_UNKNOWN;
+      ref[nvar + k] = k;
+      for (int c = 0; c < ncol; c++) blk[2 * (size_t)L + (size_t)k * W + c] = rows[(size_t)k * ncol + c];
+    }
+    patch64((size_t)pj.rows_off, blk.data(), blk.size());
+  }
+  int context_job(int i, const Ctx &ctx, int nparm, int nc, const std::vector<i64> *extra) {
+    const int ni = nc + (extra ? 1 : 0), ncol = nparm + 1;
+    const int job = new_job(i, nparm, 0, ni, -1, PIPAMD_T_INT, ni + 16, ncol);
+    std::vector<i64> r((size_t)ni * ncol);
+    for (int k = 0; k < nc; k++)
+      for (int c = 0; c < ncol; c++) r[(size_t)k * ncol + c] = ctx.at(k, c);
+    if (extra)
+      for (int c = 0; c < ncol; c++) r[(size_t)nc * ncol + c] = (*extra)[c];
+    fresh_block(job, r);
+    return job;
+  }
+
+  void start(int i, const pipamd_problem &p, int simplify) {
+    Prob &q = P_[i];
+    const int ncol = p.nvar + p.nparm + 1;
+    if (p.nvar < 0 || p.nparm < 0 || p.ni < 0 || p.nc < 0 || (p.ni && !p.ineq) || (p.nc && !p.ctx) || p.bigparm >= ncol ||
+        (p.bigparm >= 0 && p.bigparm <= p.nvar)) {
+      q.done = true;
+      q.rc = PIPAMD_E_INVALID;
+      return;
+    }
+    q.ineq.assign((const i64 *)p.ineq, (const i64 *)p.ineq + (size_t)p.ni * ncol);
+    std::vector<i64> c((const i64 *)p.ctx, (const i64 *)p.ctx + (size_t)p.nc * (p.nparm + 1));
+    if (p.nq && simplify) {
+      simplify_rows(q.ineq, p.ni, ncol, p.nvar);
+      simplify_rows(c, p.nc, p.nparm + 1, p.nparm);
+    }
+    q.ni = p.ni;
+    q.bigparm = p.bigparm;
+    q.nq = p.nq;
+    Frame f;
+    f.ctx.reserve(p.nc + 4, p.nparm + 2);
+    f.ctx.nc = p.nc;
+    for (int r = 0; r < p.nc; r++)
+      for (int k = 0; k <= p.nparm; k++) f.ctx.at(r, k) = c[(size_t)r * (p.nparm + 1) + k];
+    f.nparm = p.nparm;
+    f.mark = 0;
+    if (p.nc) {  // context emptiness test first (maind.c:196-203)
+      f.kind = K_CTX;
+      f.job = context_job(i, f.ctx, p.nparm, p.nc, nullptr);
+      q.stack.push_back(f);
+    } else {
+      q.stack.push_back(f);
+      begin_main(i);
+    }
+  }
+  // replace the (finished) context frame by the main traiter() frame
+  void begin_main(int i) {
+    Prob &q = P_[i];
+    Frame &f = q.stack.back();
+    const int tfl = q.nq ? PIPAMD_T_INT : 0;
+    q.top = f.mark;
+    f.kind = K_NODE;
+    f.phase = PH_RUN;
+    f.ni = q.ni;
+    f.bigparm = q.bigparm;
+    f.flags = tfl;
+    f.job = new_job(i, q.nvar, f.nparm, q.ni, q.bigparm, tfl, q.ni + 24, q.nvar + f.nparm + 1 + (f.nparm ? 6 : 0));
+    f.mark = 0;
+    f.last_npiv = 0;
+    fresh_block(f.job, q.ineq);
+  }
+
+  // ---- one device step ---------------------------------------------------------------
+  void step_device(const std::vector<int> &lj) {
+    const int n = (int)lj.size();
+    std::vector<PipJob> tab(n);
+    lpos_.assign(jobs_.size(), -1);
+    goff_.assign(n + 1, 0);
+    int Lm = 4, Sm = 4, Wm = 2;
+    for (int k = 0; k < n; k++) {
+      tab[k] = jobs_[lj[k]];
+      lpos_[lj[k]] = k;
+      Lm = std::max(Lm, (int)tab[k].L);
+      Sm = std::max(Sm, (int)tab[k].S);
+      Wm = std::max(Wm, (int)tab[k].W);
+      const size_t a = 1 + (size_t)tab[k].L * (3 + tab[k].nparm), b = 2 + (size_t)tab[k].W,
+                   c = (size_t)tab[k].nvar * (tab[k].W - tab[k].nvar) + tab[k].nvar;
+      goff_[k + 1] = goff_[k] + (i64)std::max(a, std::max(b, c));
+    }
+    ensure(d_jobs_, jobs_cap_, sizeof(PipJob) * n);
+    ensure(d_off_, off_cap_, sizeof(i64) * (n + 1));
+    ensure(d_out_, out_cap_, sizeof(i64) * (size_t)goff_[n]);
+    if (!clones_.empty()) {
+      ensure(d_clone_, clone_cap_, sizeof(i64) * clones_.size());
+      HIPTHROW(hipMemcpyAsync(d_clone_, clones_.data(), sizeof(i64) * clones_.size(), hipMemcpyHostToDevice, st_));
+      HIPTHROW(pipk_launch_clone(d_arena_, d_clone_, (int)(clones_.size() / 3), st_));
+    }
+    if (!pidx_.empty()) {
+      ensure(d_patch_, patch_cap_, sizeof(int) * patch_.size());
+      ensure(d_pidx_, pidx_cap_, sizeof(i64) * pidx_.size());
+      HIPTHROW(hipMemcpyAsync(d_patch_, patch_.data(), sizeof(int) * patch_.size(), hipMemcpyHostToDevice, st_));
+      HIPTHROW(hipMemcpyAsync(d_pidx_, pidx_.data(), sizeof(i64) * pidx_.size(), hipMemcpyHostToDevice, st_));
+      HIPTHROW(pipk_launch_patch(d_arena_, d_patch_, d_pidx_, (int)pidx_.size(), st_));
+    }
+    HIPTHROW(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice, st_));
+    HIPTHROW(hipMemcpyAsync(d_off_, goff_.data(), sizeof(i64) * (n + 1), hipMemcpyHostToDevice, st_));
+    // the staging vectors must stay alive until the copies are done: sync once before reuse
+    for (int guard = 0; guard < 64; guard++) {
+      HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, st_));
+      HIPTHROW(hipMemcpyAsync(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost, st_));
+      HIPTHROW(hipStreamSynchronize(st_));
+      bool again = false;
+      for (int k = 0; k < n; k++)
+        if (tab[k].status == PIPAMD_ST_RUN) again = true;
+      if (!again) break;
+    }
+    clones_.clear();
+    patch_.clear();
+    pidx_.clear();
+    HIPTHROW(pipk_launch_gather(d_jobs_, d_arena_, n, d_out_, d_off_, st_));
+    gout_.resize((size_t)goff_[n]);
+    if (goff_[n])
+      HIPTHROW(hipMemcpyAsync(gout_.data(), d_out_, sizeof(i64) * (size_t)goff_[n], hipMemcpyDeviceToHost, st_));
+    HIPTHROW(hipStreamSynchronize(st_));
+    for (int k = 0; k < n; k++) jobs_[lj[k]] = tab[k];
+  }
+  const i64 *gathered(int job) const { return gout_.data() + goff_[lpos_[job]]; }
+
+  // ---- host side of one problem after a step ----------------------------------------
+  void pop_frame(int i) {
+    Prob &q = P_[i];
+    q.top = q.stack.back().mark;
+    q.stack.pop_back();
+    if (q.stack.empty()) {
+      q.done = true;
+      return;
+    }
+    // the parent was waiting for its "then" branch: now the "else" branch (traiter.c:751-758)
+    Frame &f = q.stack.back();
+    const int nc = f.ctx.nc;
+    for (int j = 0; j < f.nparm; j++) f.ctx.at(nc, j) = wneg(f.ctx.at(nc, j));
+    f.ctx.at(nc, f.nparm) = wneg(wadd(f.ctx.at(nc, f.nparm), 1));
+    f.ctx.nc = nc + 1;
+    patch_flag(jobs_[f.job], f.split_row, PIPAMD_F_MINUS);
+    jobs_[f.job].status = PIPAMD_ST_RUN;
+    f.split_row = -1;
+    f.phase = PH_RUN;
+  }
+
+  void advance(int i) {
+    Prob &q = P_[i];
+    Frame &f = q.stack.back();
+    if (f.phase == PH_COMPA) {
+      finish_compa(i);
+      return;
+    }
+    PipJob &pj = jobs_[f.job];
+    q.pivots += pj.npiv - f.last_npiv;
+    f.last_npiv = pj.npiv;
+    f.ni = pj.ni;
+    const int st = pj.status;
+    if (f.kind == K_CTX) {
+      if (st == PIPAMD_ST_NIL) {
+        q.is_void = true;
+        q.done = true;
+        return;
+      }
+      if (st != PIPAMD_ST_SOLUTION) {
+        if (st == PIPAMD_ST_CAPACITY || st == PIPAMD_ST_NEED_PARMCUT) throw (int)PIPAMD_E_TOOLARGE;
+        fail(i, st);
+      }
+      begin_main(i);
+      return;
+    }
+    switch (st) {
+      case PIPAMD_ST_SOLUTION: {
+        const i64 *g = gathered(f.job);
+        const int nvar = q.nvar, np = f.nparm;
+        const size_t nn = (size_t)nvar * (np + 1);
+        tape_push(i, S_LIST, nvar, 0);
+        for (int r = 0; r < nvar; r++) {
+          tape_push(i, S_FORM, np + 1, 0);
+          for (int j = 0; j <= np; j++) tape_push(i, S_VAL, g[(size_t)r * (np + 1) + j], g[nn + r]);
+        }
+        pop_frame(i);
+        return;
+      }
+      case PIPAMD_ST_NIL:
+        tape_push(i, S_NIL, 0, 0);
+        pop_frame(i);
+        return;
+      case PIPAMD_ST_NEED_PARMCUT: parm_cut(i); return;
+      case PIPAMD_ST_NEED_COMPA: start_compa(i); return;
+      case PIPAMD_ST_CAPACITY: throw (int)PIPAMD_E_TOOLARGE;
+      default: fail(i, st);
+    }
+  }
+
+  // compa_test (traiter.c:162-243): sub-problems of every undecided row, solved next step
+  void start_compa(int i) {
+    Prob &q = P_[i];
+    Frame &f = q.stack.back();
+    if (f.nparm >= PIPAMD_MAXPARM) fail(i, PIPAMD_ST_INTERNAL);
+    const i64 *g = gathered(f.job);
+    const int nrec = (int)g[0], rec = 3 + f.nparm, np = f.nparm;
+    f.rows.clear();
+    f.critic.clear();
+    f.rowvals.clear();
+    f.sub_begin = (int)jobs_.size();
+    f.sub_count = 0;
+    for (int t = 0; t < nrec; t++) {
+      const i64 *r = g + 1 + (size_t)t * rec;
+      f.rows.push_back((int)r[0]);
+      f.critic.push_back((int)r[1]);
+      std::vector<i64> rv(r + 2, r + 3 + np);  // constant | parameters
+      f.rowvals.push_back(rv);
+      std::vector<i64> ex(np + 1);
+      for (int j = 0; j < np; j++) ex[j] = rv[1 + j];
+      ex[np] = r[1] ? rv[0] : wsub(rv[0], 1);
+      context_job(i, f.ctx, np, f.ctx.nc, &ex);
+      for (int j = 0; j < np; j++) ex[j] = wneg(rv[1 + j]);
+      ex[np] = wsub(wneg(rv[0]), 1);
+      context_job(i, f.ctx, np, f.ctx.nc, &ex);
+      f.sub_count += 2;
+    }
+    f.phase = PH_COMPA;
+    if (nrec == 0) finish_compa(i);
+  }
+
+  void finish_compa(int i) {
+    Prob &q = P_[i];
+    Frame &f = q.stack.back();
+    for (int k = 0; k < f.sub_count; k++) {
+      const int st = jobs_[f.sub_begin + k].status;
+      if (st == PIPAMD_ST_RUN) return;  // not all there yet
+    }
+    const PipJob &pj = jobs_[f.job];
+    const int nrows = (int)f.rows.size();
+    std::vector<int> newflag(nrows, -1);
+    for (int t = 0; t < nrows; t++) {
+      const PipJob &jp = jobs_[f.sub_begin + 2 * t], &jm = jobs_[f.sub_begin + 2 * t + 1];
+        q.pivots += jp.npiv + jm.npiv;
+      for (const PipJob *s : {&jp, &jm}) {
+        if (s->status == PIPAMD_ST_CAPACITY || s->status == PIPAMD_ST_NEED_PARMCUT) throw (int)PIPAMD_E_TOOLARGE;
+        if (s->status != PIPAMD_ST_SOLUTION && s->status != PIPAMD_ST_NIL) fail(i, s->status);
+      }
+      const bool cp = jp.status != PIPAMD_ST_NIL, cm = jm.status != PIPAMD_ST_NIL;
+      int fl;
+      if (cp && cm)
+        fl = f.critic[t] ? PIPAMD_F_CRITIC : PIPAMD_F_UNKNOWN;
+      else if (cm)
+        fl = PIPAMD_F_MINUS;
+      else
+        fl = cp ? PIPAMD_F_PLUS : PIPAMD_F_ZERO;
+      newflag[t] = fl;
+      patch_flag(pj, f.rows[t], fl);
+      if (fl == PIPAMD_F_MINUS) break;
+    }
+    // release the sub-problems (they sit above everything this frame still needs)
+    // rows behind the first negative one keep their old flag (Critic or Unknown)
+    int pick = -1;
+    for (int t = 0; t < nrows && pick < 0; t++)
+      if (newflag[t] == PIPAMD_F_MINUS) pick = -2;  // the kernel pivots on it
+    if (pick != -2) {
+      // chercher(Critic) then chercher(Unknown), traiter.c:692-693 (flags of the other rows are +/0)
+      std::vector<int> cur(nrows);
+      for (int t = 0; t < nrows; t++) cur[t] = newflag[t];
+      for (int t = 0; t < nrows && pick < 0; t++)
+        if (cur[t] == PIPAMD_F_CRITIC) pick = t;
+      for (int t = 0; t < nrows && pick < 0; t++)
+        if (cur[t] == PIPAMD_F_UNKNOWN) pick = t;
+    }
+    // drop the sub-jobs' blocks: nothing was allocated in this region after them
+    if (f.sub_count) q.top = (size_t)jobs_[f.sub_begin].rows_off - q.region_off;
+    f.sub_count = 0;
+    jobs_[f.job].status = PIPAMD_ST_RUN;
+    f.phase = PH_RUN;
+    if (pick < 0) return;  // a negative row to pivot on, or every sign settled
+    split(i, pick, newflag);
+  }
+
+  // the quast forks on the sign of an undecided row (traiter.c:695-759)
+  void split(int i, int t, const std::vector<int> &newflag) {
+    Prob &q = P_[i];
+    Frame &f = q.stack.back();
+    if (f.nparm >= PIPAMD_MAXPARM) fail(i, PIPAMD_ST_INTERNAL);
+    const int np = f.nparm, pivi = f.rows[t];
+    const std::vector<i64> &rv = f.rowvals[t];
+    Frame c;
+    c.kind = K_NODE;
+    c.phase = PH_RUN;
+    c.nparm = np;
+    c.ni = f.ni;
+    c.bigparm = f.bigparm;
+    c.flags = f.flags;
+    c.mark = q.top;
+    c.job = new_job(i, q.nvar, np, f.ni, f.bigparm, f.flags, jobs_[f.job].S, jobs_[f.job].W);
+    const PipJob &pj = jobs_[f.job];  // (taken after new_job: the job table may have moved)
+    PipJob &cj = jobs_[c.job];
+    if (cj.L != pj.L || cj.S != pj.S || cj.W != pj.W) fail(i, PIPAMD_ST_INTERNAL);
+    cj.ldet = pj.ldet;
+    memcpy(cj.det, pj.det, sizeof pj.det);
+    clones_.push_back(pj.rows_off);
+    clones_.push_back(cj.rows_off);
+    clones_.push_back(2 * (i64)pj.L + (i64)pj.S * pj.W);
+    tape_push(i, S_IF, 0, 0);
+    tape_push(i, S_FORM, np + 1, 0);
+    i64 g = 0;
+    for (int j = 0; j < np; j++) g = gcd(g, rv[1 + j]);
+    if (!(f.flags & PIPAMD_T_INT)) g = gcd(g, rv[0]);
+    const int nc = f.ctx.nc;
+    f.ctx.reserve(nc + 1, np + 2);
+    for (int j = 0; j < np; j++) {
+      f.ctx.at(nc, j) = cquo(rv[1 + j], g);
+      tape_push(i, S_VAL, f.ctx.at(nc, j), 1);
+    }
+    f.ctx.at(nc, np) = (f.flags & PIPAMD_T_INT) ? floordiv(rv[0], g) : cquo(rv[0], g);
+    tape_push(i, S_VAL, f.ctx.at(nc, np), 1);
+    // the clone pass runs before the patch pass, so the copy still has the flags from before this
+    // compa_test: give it the refreshed ones (expanser copies them, traiter.c:717), then Plus
+    for (size_t k = 0; k < f.rows.size(); k++)
+      if ((int)k != t && newflag[k] >= 0) patch_flag(cj, f.rows[k], newflag[k]);
+    patch_flag(cj, pivi, PIPAMD_F_PLUS);
+    c.ctx = f.ctx;
+    c.ctx.nc = nc + 1;
+    f.split_row = pivi;
+    q.stack.push_back(c);  // (f is invalid from here on)
+  }
+
+  // parametric Gomory cut (integrer.c:487-520): context and tape on the host, row appended by patch
+  void parm_cut(int i) {
+    Prob &q = P_[i];
+    Frame &f = q.stack.back();
+    PipJob &pj = jobs_[f.job];
+    if (pj.tflags & PIPAMD_T_DEEPEST) throw (int)PIPAMD_E_TOOLARGE;
+    const i64 *g = gathered(f.job);
+    const int nvar = q.nvar, ni = f.ni;
+    int nparm = f.nparm;
+    const int ncol = nvar + nparm + 1, nligne = nvar + ni;
+    if (ncol >= PIPAMD_MAXCOL) fail(i, PIPAMD_ST_MAXCOL);
+    const i64 D = g[1];
+    const i64 *r = g + 2;
+    std::vector<i64> cut(ncol + 1);
+    bool ok_var = false, ok_parm = false;
+    for (int j = 0; j < nvar; j++) {
+      cut[j] = fmod_(r[j], D);
+      if (cut[j] > 0) ok_var = true;
+    }
+    cut[nvar] = wneg(fmod_(wneg(r[nvar]), D));
+    for (int j = nvar + 1; j < ncol; j++) {
+      if (j == f.bigparm) {
+        cut[j] = 0;
+        continue;
+      }
+      cut[j] = wneg(fmod_(wneg(r[j]), D));
+      if (cut[j] != 0) ok_parm = true;
+    }
+    cut[ncol] = D;
+    if (!ok_parm) throw (int)PIPAMD_E_TOOLARGE;  // only reached with options the Tree handles
+    std::vector<i64> pc(cut.begin() + nvar, cut.end());
+    int parm = Tree::find_parm(f.ctx, f.ctx.nc, nparm, pc);
+    std::copy(pc.begin(), pc.end(), cut.begin() + nvar);
+    if (parm == -1) {
+      // add_parm (integrer.c:156-227) on this problem's tape and context
+      const int nr = f.ctx.nc;
+      tape_push(i, S_NEW, nparm, 0);
+      tape_push(i, S_DIV, 0, 0);
+      tape_push(i, S_FORM, nparm + 1, 0);
+      for (int j = 0; j < nparm; j++) tape_push(i, S_VAL, wneg(pc[1 + j]), 1);
+      tape_push(i, S_VAL, wneg(pc[0]), 1);
+      tape_push(i, S_VAL, pc[1 + nparm], 1);
+      f.ctx.reserve(nr + 2, nparm + 2);
+      for (int k = 0; k < nr; k++) {
+        f.ctx.at(k, nparm + 1) = f.ctx.at(k, nparm);
+        f.ctx.at(k, nparm) = 0;
+      }
+      for (int j = 0; j < nparm; j++) {
+        f.ctx.at(nr, j) = wneg(pc[1 + j]);
+        f.ctx.at(nr + 1, j) = pc[1 + j];
+      }
+      f.ctx.at(nr, nparm) = wneg(pc[1 + nparm]);
+      f.ctx.at(nr + 1, nparm) = pc[1 + nparm];
+      i64 x = pc[0];
+      f.ctx.at(nr, nparm + 1) = wneg(x);
+      x = wsub(x, 1);
+      f.ctx.at(nr + 1, nparm + 1) = wadd(x, pc[1 + nparm]);
+      nparm++;
+      f.ctx.nc += 2;
+      parm = nparm - 1;
+    }
+    if (!ok_var) fail(i, PIPAMD_ST_INTERNAL);  // assert(ok_var), integrer.c:499
+    const int newcol = nvar + 1 + parm;
+    if (ni >= pj.S || nligne >= pj.L || nvar + nparm + 1 > pj.W) throw (int)PIPAMD_E_TOOLARGE;
+    std::vector<i64> row(pj.W, 0);
+    for (int j = 0; j < ncol; j++) row[j] = cut[j];
+    row[newcol] = wadd(row[newcol], cut[ncol]);
+    patch64((size_t)pj.vals_off + (size_t)ni * pj.W, row.data(), row.size());
+    patch64((size_t)pj.rows_off + nligne, &D, 1);
+    patch_flag(pj, nligne, PIPAMD_F_MINUS);
+    const int slot = ni;
+    patch32(((size_t)pj.rows_off + pj.L) * 2 + pj.L + nligne, &slot, 1);
+    f.ni = ni + 1;
+    f.nparm = nparm;
+    pj.ni = f.ni;
+    pj.nparm = nparm;
+    pj.ncut++;
+    pj.tflags &= ~PIPAMD_T_STATE;
+    pj.status = PIPAMD_ST_RUN;
+  }
+};
+
+}  // namespace
+
+// Many problems in lock step (Forest); the few that need a rare path are finished by the Tree.
+extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify,
+                                              int deepest_cut, char **texts, int *rcs, int *statuses, int64_t *pivots) {
+  if (!e || n < 0 || (n && (!probs || !texts || !rcs))) return PIPAMD_E_INVALID;
+  if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
+  std::vector<FResult> res(n);
+  if (!deepest_cut) {
+    try {
+      Forest f(e->device);
+      f.solve(n, probs, simplify, res);
+    } catch (int code) {
+      if (code == PIPAMD_E_HIP) return code;
+      for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;
+    }
+  } else
+    for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;
+  Tree *fallback = nullptr;
+  for (int i = 0; i < n; i++) {
+    texts[i] = nullptr;
+    if (res[i].rc == PIPAMD_E_TOOLARGE) {
+      if (!fallback) fallback = new Tree(e, deepest_cut);
+      int st = 0;
+      int64_t pv = 0;
+      const pipamd_problem &p = probs[i];
+      rcs[i] = solve_one(*fallback, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx, simplify, deepest_cut,
+                         &texts[i], &st, &pv);
+      if (statuses) statuses[i] = st;
+      if (pivots) pivots[i] = pv;
+      continue;
+    }
+    rcs[i] = res[i].rc;
+    if (statuses) statuses[i] = res[i].status;
+    if (pivots) pivots[i] = res[i].pivots;
+    if (res[i].rc) continue;
+    std::string out;
+    if (res[i].is_void)
+      out = "void\n";
+    else {
+      size_t k = 0;
+      while (k < res[i].tape.size()) k = print_tape(res[i].tape, out, k);
+    }
+    texts[i] = (char *)malloc(out.size() + 1);
+    if (!texts[i]) {
+      rcs[i] = PIPAMD_E_NOMEM;
+      continue;
+    }
+    memcpy(texts[i], out.c_str(), out.size() + 1);
+  }
+  delete fallback;
   return PIPAMD_OK;
 }
 

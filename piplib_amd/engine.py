@@ -247,7 +247,7 @@ class PipProblem(C.Structure):
                [("ineq", C.c_void_p), ("ctx", C.c_void_p)]
 
 
-def solve_tableaux(engine, problems, simplify=True, deepest_cut=False, nthreads=8):
+def solve_tableaux(engine, problems, simplify=True, deepest_cut=False, nthreads=8, lockstep=False):
     """Many problems (objects with nvar, nparm, ni, nc, bigparm, nq, ineq, ctx) through
     pipamd_solve_tableaux.  Returns a list of (text | None, rc, status, pivots)."""
     import numpy as np
@@ -266,8 +266,14 @@ def solve_tableaux(engine, problems, simplify=True, deepest_cut=False, nthreads=
     L = lib()
     L.pipamd_solve_tableaux.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    _check(L.pipamd_solve_tableaux(engine._h, n, arr, int(bool(simplify)), int(bool(deepest_cut)), int(nthreads),
-                                   texts, rcs, sts, piv))
+    if lockstep:
+        L.pipamd_solve_tableaux_lockstep.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.pipamd_solve_tableaux_lockstep(engine._h, n, arr, int(bool(simplify)), int(bool(deepest_cut)),
+                                                texts, rcs, sts, piv))
+    else:
+        _check(L.pipamd_solve_tableaux(engine._h, n, arr, int(bool(simplify)), int(bool(deepest_cut)), int(nthreads),
+                                       texts, rcs, sts, piv))
     out = []
     for i in range(n):
         t = None

@@ -224,8 +224,9 @@ def test_full_size_int128_config():
 
 
 def test_many_parametric_problems_multithreaded():
-    """pipamd_solve_tableaux: 8 host threads / streams sharing the GPU give exactly the answers
-    of the one-at-a-time entry point (which the other tests pin to the oracle)."""
+    """pipamd_solve_tableaux (8 host threads / streams) and pipamd_solve_tableaux_lockstep (one
+    clone/patch/launch/gather sequence per step for the whole batch) give exactly the answers of
+    the one-at-a-time entry point (which the other tests pin to the oracle)."""
     from piplib_amd import engine as eng, synth
     probs = [p for seed, shape in ((41, (5, 2, 7, 2)), (42, (4, 3, 6, 3)), (43, (6, 1, 8, 1)))
              for p in synth.random_problems(seed, 30, *shape, 1)]
@@ -240,6 +241,8 @@ def test_many_parametric_problems_multithreaded():
             pass
     e = eng.Engine(0)
     many = eng.solve_tableaux(e, keep, nthreads=8)
+    # the lock-step scheduler (one launch per step for all problems) must agree entry by entry
+    assert eng.solve_tableaux(e, keep, lockstep=True) == many
     for p, (text, rc, st, piv) in zip(keep, many):
         try:
             t1, p1 = eng.solve_tableau(e, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx)
