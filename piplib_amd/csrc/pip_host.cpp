@@ -117,6 +117,7 @@ extern "C" size_t pipamd_pivot_bytes(const pipamd_batch_desc *d) {
 
 extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, const int64_t *d_rows,
                                  void *stream) {
+  if (e && hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;  // HIP's current device is per host thread
   PipBatchLayout lay;
   size_t jb;
   if (!e || !d_ws || !d_rows) return PIPAMD_E_INVALID;
@@ -135,6 +136,7 @@ extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batc
 // pivots, and let each launch size its LDS image to the rows the running tableaux have *now*
 // (Gomory cuts add rows as the solve goes on).
 extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, void *stream) {
+  if (e && hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;  // HIP's current device is per host thread
   PipBatchLayout lay;
   size_t jb;
   if (!e || !d_ws) return PIPAMD_E_INVALID;
@@ -210,6 +212,7 @@ extern "C" int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots) {
 extern "C" int pipamd_batch_results(pipamd_engine *e, const void *d_ws, const pipamd_batch_desc *d, int32_t *d_status,
                                     int32_t *d_pivots, int32_t *d_cuts, int64_t *d_sol_num, int64_t *d_sol_den,
                                     void *stream) {
+  if (e && hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;  // HIP's current device is per host thread
   PipBatchLayout lay;
   size_t jb;
   if (!e || !d_ws) return PIPAMD_E_INVALID;
@@ -224,6 +227,7 @@ extern "C" int pipamd_batch_results(pipamd_engine *e, const void *d_ws, const pi
 
 extern "C" int pipamd_batch_counters(pipamd_engine *e, const void *d_ws, const pipamd_batch_desc *d, uint64_t *d_out4,
                                      void *stream) {
+  if (e && hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;  // HIP's current device is per host thread
   PipBatchLayout lay;
   size_t jb;
   if (!e || !d_ws || !d_out4) return PIPAMD_E_INVALID;

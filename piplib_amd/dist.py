@@ -12,7 +12,7 @@ def env_rank():
 def init(backend, device=None):
     """Initialise the default process group when WORLD_SIZE > 1; returns (rank, world, local)."""
     rank, world, local = env_rank()
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torchrun also for a single rank: same code path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -38,24 +38,26 @@ def gather_totals(counts, seconds, device="cpu"):
     import torch
     tot = torch.tensor([float(c) for c in counts], dtype=torch.float64, device=device)
     tmax = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
-    rank, world, _ = env_rank()
-    if world > 1:
+    if _active():
         import torch.distributed as dist
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return tot.cpu().tolist(), float(tmax.item())
 
 
+def _active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def barrier():
-    rank, world, _ = env_rank()
-    if world > 1:
+    if _active():
         import torch.distributed as dist
         dist.barrier()
 
 
 def finish():
-    rank, world, _ = env_rank()
-    if world > 1:
+    if _active():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

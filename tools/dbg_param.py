@@ -1,6 +1,6 @@
 """Manual GPU debug: random parametric problems one by one with progress output."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pipbatch as pb
 from piplib_amd import engine as eng, synth
