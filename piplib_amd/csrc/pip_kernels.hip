@@ -910,35 +910,47 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     for (int e = tid; e < ni * NM; e += NT) S.nzm[e] = g_nzm[e];
     for (int s = tid; s < ni; s += NT) S.cst[s] = vals[(size_t)s * W + nvar];
   } else {
-    // one pass over the tableau: sign summaries, bitmaps, magnitudes, sort keys
-    for (int s = wave; s < ni; s += NW) {
-      RowRegs<T, NCH> r;
-      row_load<T, NCH>(r, vals + (size_t)s * W, ncolp, lane);
-      // rows with a denominator other than 1 are conservatively treated as not yet reduced
-      row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, -1, S.den[s] == 1 ? SIG_RED : 0, has_parm, lane);
-      if (tflags & PIPAMD_T_SORT) {
-        // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns
-        double d = to_double(S.den[s]), sz = 0;
+    // one pass over the tableau: sign summaries, bitmaps, magnitudes, sort keys (PF rows of a
+    // wave in flight at a time)
+    constexpr int PF0 = NCH <= 2 ? 4 : (NCH == 4 ? 2 : 1);
+    for (int s0 = wave; s0 < ni; s0 += NW * PF0) {
+      RowRegs<T, NCH> rr[PF0];
 #pragma unroll
-        for (int c = 0; c < NCH; c++)
+      for (int q = 0; q < PF0; q++)
+        if (s0 + q * NW < ni) row_load<T, NCH>(rr[q], vals + (size_t)(s0 + q * NW) * W, ncolp, lane);
 #pragma unroll
-          for (int h = 0; h < ET<T>::CPL; h++) {
-            int j = colof<T>(c, lane, h);
-            if (j < nvar) {
-              int q = trunc_int_x86(to_double(r.v[c][h]) / d);
-              double aq = (double)(q < 0 ? (int)(0u - (unsigned)q) : q);
-              sz = sz > aq ? sz : aq;
+      for (int q = 0; q < PF0; q++) {
+        const int s = s0 + q * NW;
+        if (s >= ni) break;
+        RowRegs<T, NCH> &r = rr[q];
+        // rows with a denominator other than 1 are conservatively treated as not yet reduced
+        const bool den1 = S.den[s] == 1;
+        row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, -1, den1 ? SIG_RED : 0, has_parm, lane);
+        if (tflags & PIPAMD_T_SORT) {
+          // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns
+          double d = to_double(S.den[s]), sz = 0;
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int h = 0; h < ET<T>::CPL; h++) {
+              int j = colof<T>(c, lane, h);
+              if (j < nvar) {
+                const double tv = to_double(r.v[c][h]);
+                int q2 = trunc_int_x86(den1 ? tv : tv / d);  // x / 1.0 == x exactly
+                double aq = (double)(q2 < 0 ? (int)(0u - (unsigned)q2) : q2);
+                sz = sz > aq ? sz : aq;
+              }
             }
+          for (int o = 32; o; o >>= 1) {
+            double t = __shfl(sz, lane ^ o);
+            sz = sz > t ? sz : t;
           }
-        for (int o = 32; o; o >>= 1) {
-          double t = __shfl(sz, lane ^ o);
-          sz = sz > t ? sz : t;
-        }
-        if (lane == 0) {
-          S.size[s] = (float)sz;
-          // smax is taken over rows nvar..nligne-1 only (traiter.c:576-586); sizes are >= 0,
-          // so their bit patterns order like the doubles
-          if ((int)S.srow[s] >= nvar) atomicMax(&sc.smaxbits, (u64)__double_as_longlong(sz));
+          if (lane == 0) {
+            S.size[s] = (float)sz;
+            // smax is taken over rows nvar..nligne-1 only (traiter.c:576-586); sizes are >= 0,
+            // so their bit patterns order like the doubles
+            if ((int)S.srow[s] >= nvar) atomicMax(&sc.smaxbits, (u64)__double_as_longlong(sz));
+          }
         }
       }
     }
