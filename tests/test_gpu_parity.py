@@ -249,3 +249,99 @@ def test_many_parametric_problems_multithreaded():
             assert rc == 0 and text == t1 and piv == p1
         except eng.SolverError as ex:
             assert rc == -5 and st == ex.status
+
+
+@pytest.mark.parametrize("seed", [51, 52, 53])
+def test_engine_variants_agree(seed):
+    """One batch through every engine configuration -- 1 or 4 waves per tableau, short rounds,
+    row skipping off, 128-bit entries -- must give bit-identical statuses, pivot counts and
+    solutions (and match the oracle, checked on the first configuration)."""
+    import numpy as np
+    import torch
+    from gpu_common import oracle_batch, solution_text
+    import pipbatch as pb
+    from piplib_amd import engine as eng, synth
+    rng = np.random.default_rng(seed)
+    nvar, ni = int(rng.integers(5, 90)), int(rng.integers(4, 48))
+    rows = synth.lexmin_batch(seed, 40, nvar, ni, nnz=int(rng.integers(2, 6)), cmax=int(rng.integers(2, 9)))
+    nq = int(seed % 2 == 1)
+    outs = []
+    for waves, rnd, extra, bits in [(4, 0, 0, 64), (1, 0, 0, 64), (1, 5, 0, 64), (4, 3, eng.T_NOSKIP, 64), (4, 0, 0, 128)]:
+        e = eng.Engine(0)
+        e.set_waves_per_job(waves)
+        if rnd:
+            e.set_round_pivots(rnd)
+        b = eng.Batch(e, rows, nvar, 0, tflags=(eng.T_INT if nq else 0) | extra, cap_cuts=200, entier_bits=bits)
+        b.load()
+        b.solve()
+        b.fetch()
+        torch.cuda.synchronize()
+        num, den = b.sol_num.cpu().numpy(), b.sol_den.cpu().numpy()
+        if bits == 128:
+            num, den = eng.wide_to_int(num), eng.wide_to_int(den)
+        outs.append((b.status.cpu().numpy(), b.pivots.cpu().numpy(), num.astype(object), den.astype(object)))
+    for o in outs[1:]:
+        assert (o[0] == outs[0][0]).all() and (o[1] == outs[0][1]).all()
+        assert (o[2] == outs[0][2]).all() and (o[3] == outs[0][3]).all()
+    ora = oracle_batch(rows, nvar, 0, nq)
+    st, pv, num, den = outs[0]
+    for b_, r in enumerate(ora.results):
+        if st[b_] == eng.ST_CAPACITY:
+            continue
+        assert pv[b_] == r.pivots
+        got = "()" if st[b_] == eng.ST_NIL else pb.squash(solution_text(num[b_], den[b_]))
+        assert got == pb.squash(r.text)
+
+
+def test_pip_solve_options_fuzz():
+    """pipamd_pip_solve with Maximize / Urs_unknowns / Urs_parms / rational on random small
+    PolyLib matrices vs the oracle's pip front end (same text, incl. 'void')."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    import pipbatch as pb
+    from datfile import matrix_text
+    from piplib_amd import engine as eng
+    rng = np.random.default_rng(9)
+    e = eng.Engine(0)
+    checked = 0
+    for trial in range(60):
+        nn, npar = int(rng.integers(1, 4)), int(rng.integers(0, 3))
+        nrow, ncrow = int(rng.integers(1, 6)), int(rng.integers(0, 3))
+        dom = rng.integers(-3, 4, size=(nrow, nn + npar + 2)).astype(np.int64)
+        dom[:, 0] = rng.random(nrow) < 0.85          # mostly inequalities, some equalities
+        dom[:, -1] = rng.integers(-6, 9, size=nrow)
+        ctx = rng.integers(-2, 3, size=(ncrow, npar + 2)).astype(np.int64)
+        if ncrow:
+            ctx[:, 0] = 1
+            ctx[:, -1] = rng.integers(0, 9, size=ncrow)
+        opts = {}
+        k = trial % 5
+        if k == 1:
+            opts["Maximize"] = 1
+        elif k == 2:
+            opts["Urs_unknowns"] = 1
+        elif k == 3 and npar:
+            opts["Urs_parms"] = 1
+        elif k == 4:
+            opts["Nq"] = 0
+        words = {"Maximize": "Maximize", "Urs_unknowns": "Urs_unknowns", "Urs_parms": "Urs_parms"}
+        txt = matrix_text(ctx) + "\n-1\n\n" + matrix_text(dom) + "\n" + \
+            "".join(words[o] + "\n" for o in opts if o in words) + ("Rational\n" if opts.get("Nq") == 0 else "")
+        try:
+            p = subprocess.run([pb.ORACLEPIP, "pip"], input=txt.encode(), capture_output=True, timeout=3)
+        except subprocess.TimeoutExpired:
+            continue
+        if p.returncode != 0:
+            continue
+        want = pb.squash(p.stdout.decode())
+        try:
+            text, _ = eng.pip_solve(e, dom, ctx, -1, **opts)
+        except eng.SolverError:
+            continue
+        head = ("[PIP2-like future input] Please enter:\n- the context matrix,\n" + matrix_text(ctx) +
+                "- the bignum column (start at 0, -1 if no bignum),\n-1\n- the constraint matrix.\n" +
+                matrix_text(dom) + "\n")
+        assert pb.squash(head + text) == want, (trial, opts, text[:200])
+        checked += 1
+    assert checked >= 40
