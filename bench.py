@@ -235,6 +235,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pip_advance_kernel", "kernel_ms": k_ms,
                          "launches_per_step": e.last_solve_launches(),
+                         "avg_launch_ms": k_ms / max(1, e.last_solve_launches()),
+                         "measured": "HIP events around each launch, 2 un-pipelined steps after the timed "
+                                     "region (= `bench.py --pipeline 1`, the command of profiles/r01_kernel_stats.csv)",
                          "algorithmic_bytes_per_step": algo_bytes,
                          "dense_equivalent_GBps": b.pivot_bytes() * piv_rank / (k_ms * 1e-3) / 1e9,
                          "note": "sparse workload: ~2.7 of ~80 rows change per pivot, so the pivot loop is "
