@@ -1621,6 +1621,14 @@ extern "C" hipError_t pipk_launch_batch_counters(const PipJob *jobs, int njobs, 
 template <class T, int NCH, int NW>
 static void launch_advance_t(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
                              unsigned long long *prof, size_t shm, hipStream_t stream) {
+  if (shm > 48 * 1024) {  // large tableaux: opt in to more than the default dynamic LDS (160 KiB per CU)
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute((const void *)pip_advance_kernel<T, NCH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024 - 1024);
+      raised = true;
+    }
+  }
   hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW>), dim3(njobs), dim3(64 * NW), shm, stream, jobs, arena, njobs, Lmax,
                      Smax, Wmax, iter_limit, prof);
 }
@@ -1648,9 +1656,6 @@ extern "C" hipError_t pipk_launch_advance(PipJob *jobs, i64 *arena, int njobs, i
   const bool one = waves_per_job == 1;
   const int wp = wp_of(Wmax, ebits);
   if (ebits == 128) {
-    if (shm > 64 * 1024) {
-      hipFuncSetAttribute((const void *)pip_advance_kernel<i128, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
     switch (wp) {
       case 64: launch_advance_w<i128, 1>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
       case 128: launch_advance_w<i128, 2>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;

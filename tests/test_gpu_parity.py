@@ -345,3 +345,16 @@ def test_pip_solve_options_fuzz():
         assert pb.squash(head + text) == want, (trial, opts, text[:200])
         checked += 1
     assert checked >= 40
+
+
+def test_largest_supported_shape():
+    """Engine limits (the reference's MAXCOL: fewer than 512 columns; 1024 logical rows): a
+    510-unknown tableau with hundreds of rows must run (large dynamic LDS image) and agree with
+    the oracle; with 512 columns both stop with "Too many variables" (integrer.c:324)."""
+    from gpu_common import compare
+    from piplib_amd import synth
+    rows = synth.lexmin_batch(61, 6, 510, 300, nnz=3, cmax=3, x0max=4)
+    n, piv = compare(rows, 510, 0, 1, cap_cuts=200)
+    assert n == 6 and piv > 0
+    rows = synth.lexmin_batch(62, 4, 511, 40, nnz=3, cmax=3, x0max=4)
+    compare(rows, 511, 0, 1, cap_cuts=60)
