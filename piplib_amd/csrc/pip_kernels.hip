@@ -504,6 +504,27 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
   return true;
 }
 
+// integrer.c:98-150 bezout: z with z*y == x (mod delta) when gcd(y, delta) == 1, else 0.
+// Wave-uniform scalar work (deepest-cut option only).
+template <class T>
+__device__ T bezout_dev(T x, T y, T delta) {
+  T a = 1, b = 0, c = 0, d = 1, u = y, v = delta;
+  for (int guard = 0; guard < 4 * ET<T>::BITS; guard++) {
+    const T r = fmod64(u, v);
+    const T q = cquo(wsub(u, r), v);  // floor division: (u - (u mod v)) / v is exact
+    if (r == 0) break;
+    u = v;
+    v = r;
+    const T e = wsub(a, wmul(q, c)), f = wsub(b, wmul(q, d));
+    a = c;
+    b = d;
+    c = e;
+    d = f;
+  }
+  if (v != 1) return 0;
+  return fmod64(wmul(c, x), delta);
+}
+
 // flag exam_coef (traiter.c:121-154) gives an Unknown row, from its sign summary
 __device__ __forceinline__ int exam_class(int sg) {
   const int fc = SIG_CONST(sg) == 1 ? PIPAMD_F_PLUS : (SIG_CONST(sg) == 2 ? PIPAMD_F_MINUS : PIPAMD_F_ZERO);
@@ -1066,14 +1087,37 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             verdict = PIPAMD_ST_NEED_PARMCUT;  // the host owns the context (find_parm/add_parm)
           else if (!any_v)
             verdict = PIPAMD_ST_NIL;  // integrer.c:482-485 case (b)
-          else if (tflags & PIPAMD_T_DEEPEST)
-            verdict = PIPAMD_ST_NEED_PARMCUT;  // deepest cut (integrer.c:417-438): built by the host
           else if (ni >= Sl || nligne >= L)
             verdict = PIPAMD_ST_CAPACITY;
           else if (ni >= Smax || nligne >= Lmax)
             verdict = -1;  // no room in this launch's LDS image: pause, the host relaunches with more
           else {
             verdict = PIPAMD_ST_RUN;
+            if (tflags & PIPAMD_T_DEEPEST) {
+              // deepest cut, integrer.c:417-438: scale the cut by the multiplier lambda that
+              // makes its constant term -1/D-tight
+              constexpr int CW = 64 * ET<T>::CPL;
+              const T cn = row_entry<T, NCH>(r, nvar / CW, nvar % ET<T>::CPL, (nvar % CW) / ET<T>::CPL);
+              T t = wneg(cn);
+              const T delta = gcd_i64(t, D), tau = cquo(t, delta), dd = cquo(D, delta);
+              t = wsub(dd, (T)1);
+              T lambda = bezout_dev<T>(t, tau, dd);
+              t = gcd_i64(lambda, D);
+              for (int guard = 0; t != 1 && guard < (1 << 20); guard++) {
+                lambda = wadd(lambda, dd);
+                t = gcd_i64(lambda, D);
+              }
+#pragma unroll
+              for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int h = 0; h < ET<T>::CPL; h++) {
+                  int j = colof<T>(c, lane, h);
+                  if (j < nvar)
+                    r.v[c][h] = fmod64(wmul(lambda, r.v[c][h]), D);
+                  else if (j == nvar)
+                    r.v[c][h] = wneg(wsub(D, fmod64(wmul(r.v[c][h], lambda), D)));
+                }
+            }
             // append the cut as logical row nligne in slot ni (integrer.c:440-446)
             row_store<T, NCH>(r, vals + (size_t)ni * W, ncolp, lane);
             row_publish<T, NCH>(r, S, ni, nvar, ncol, bigparm, -1, 0, has_parm, lane);

@@ -358,3 +358,35 @@ def test_largest_supported_shape():
     assert n == 6 and piv > 0
     rows = synth.lexmin_batch(62, 4, 511, 40, nnz=3, cmax=3, x0max=4)
     compare(rows, 511, 0, 1, cap_cuts=60)
+
+
+@pytest.mark.parametrize("seed,nvar,ni", [(71, 10, 12), (72, 30, 20), (73, 127, 64)])
+def test_deepest_cut_on_device(seed, nvar, ni):
+    """PIPAMD_T_DEEPEST (the reference's -d / Deepest_cut option, integrer.c:417-438) entirely in
+    the kernel, batch API, vs the oracle run with the same option."""
+    import numpy as np
+    import torch
+    from gpu_common import solution_text
+    import pipbatch as pb
+    from piplib_amd import engine as eng, synth
+    rows = synth.lexmin_batch(seed, 32, nvar, ni)
+    probs = [synth.Problem(nvar, 0, ni, 0, -1, 1, rows[b], np.zeros((0, 1), np.int64)) for b in range(32)]
+    o = pb.run_batch(pb.ORACLEPIP, probs, pb.F_NOSIMPLIFY | pb.F_DEEPEST)
+    plain = pb.run_batch(pb.ORACLEPIP, probs, pb.F_NOSIMPLIFY)
+    e = eng.Engine(0)
+    b = eng.Batch(e, rows, nvar, 0, tflags=eng.T_INT | 512, cap_cuts=250)
+    b.load()
+    b.solve()
+    b.fetch()
+    torch.cuda.synchronize()
+    st, pv = b.status.cpu().numpy(), b.pivots.cpu().numpy()
+    num, den = b.sol_num.cpu().numpy(), b.sol_den.cpu().numpy()
+    for k, r in enumerate(o.results):
+        if st[k] == eng.ST_CAPACITY:
+            continue
+        assert r.status == pb.ST_OK and st[k] in (eng.ST_SOLUTION, eng.ST_NIL)
+        assert pv[k] == r.pivots, (k, pv[k], r.pivots)
+        got = "()" if st[k] == eng.ST_NIL else pb.squash(solution_text(num[k], den[k]))
+        assert got == pb.squash(r.text), k
+    # the option really changes the pivot sequence on this workload
+    assert sum(a.pivots != c.pivots for a, c in zip(o.results, plain.results)) > 0
