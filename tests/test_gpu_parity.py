@@ -390,3 +390,18 @@ def test_deepest_cut_on_device(seed, nvar, ni):
         assert got == pb.squash(r.text), k
     # the option really changes the pivot sequence on this workload
     assert sum(a.pivots != c.pivots for a, c in zip(o.results, plain.results)) > 0
+
+
+@pytest.mark.parametrize("nvar,ni", [(1, 1), (2, 1), (1, 5), (3, 2), (64, 1), (129, 3)])
+def test_degenerate_shapes(nvar, ni):
+    """Tiny and lopsided tableaux (incl. all-zero rows, infeasible and unbounded-looking ones)."""
+    import numpy as np
+    from gpu_common import compare
+    rng = np.random.default_rng(nvar * 100 + ni)
+    rows = rng.integers(-3, 4, size=(24, ni, nvar + 1)).astype(np.int64)
+    rows[0] = 0                      # all-zero tableau
+    rows[1, :, :nvar] = 0            # constants only
+    rows[1, :, nvar] = -1            # ... and infeasible
+    for nq in (0, 1):
+        n, _ = compare(rows, nvar, 0, nq, cap_cuts=64)
+        assert n == 24
