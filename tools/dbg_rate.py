@@ -34,3 +34,8 @@ print(f"32x64 x40k nq=1: {r:.1f} Mpiv/s  {ms:.2f} ms/step  pivots {c['pivots']}"
 rows = synth.lexmin_batch(1000, 1000, 63, 32)
 r, c, ms = rate(rows, 63, 0)
 print(f"32x64 x1k nq=0 (BASELINE configs[1]): {r:.1f} Mpiv/s  {ms:.3f} ms/step  pivots {c['pivots']}", flush=True)
+rows = synth.lexmin_batch(77, 1000, 255, 128)
+r, c, ms = rate(rows, 255, 1, entier_bits=128)
+print(f"128x256 x1k nq=1 int128 (BASELINE configs[4]): {r:.1f} Mpiv/s  {ms:.3f} ms/step  pivots {c['pivots']} cuts {c['cuts']}", flush=True)
+r, c, ms = rate(rows, 255, 1, entier_bits=64)
+print(f"128x256 x1k nq=1 int64: {r:.1f} Mpiv/s  {ms:.3f} ms/step  pivots {c['pivots']}", flush=True)
