@@ -36,6 +36,7 @@ hipError_t pipk_launch_batch_results(const PipJob *jobs, const long long *arena,
 hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, int *out2, hipStream_t stream);
 hipError_t pipk_launch_clone(long long *arena, const long long *list, int n, hipStream_t stream);
 hipError_t pipk_launch_patch(long long *arena, const int *buf, const long long *index, int n, hipStream_t stream);
+hipError_t pipk_launch_fresh(long long *arena, const long long *buf, const long long *index, int n, hipStream_t stream);
 hipError_t pipk_launch_gather(const PipJob *jobs, const long long *arena, int njobs, long long *out,
                               const long long *off, hipStream_t stream);
 hipError_t pipk_launch_batch_counters(const PipJob *jobs, int njobs, unsigned long long *out, hipStream_t stream);

@@ -1560,6 +1560,35 @@ __global__ void pip_patch_kernel(int *arena32, const int *buf, const i64 *index,
   const int nw = p[2];
   for (int i = threadIdx.x; i < nw; i += blockDim.x) arena32[dst + i] = p[3 + i];
 }
+// fresh: build new tableaux (tab_alloc + tab_get, tab.c:158-248) from their rows alone.
+// Record r at buf[index[r]] (int64 words): rows_off, nvar, ni, ncol, L, S, W, then ni*ncol values.
+__global__ void pip_fresh_kernel(i64 *arena, const i64 *buf, const i64 *index, int n) {
+  const int b = blockIdx.x;
+  if (b >= n) return;
+  const i64 *p = buf + index[b];
+  const i64 rows_off = p[0];
+  const int nvar = (int)p[1], ni = (int)p[2], ncol = (int)p[3], L = (int)p[4], S = (int)p[5], W = (int)p[6];
+  const i64 *src = p + 7;
+  i64 *g_den = arena + rows_off;
+  int *g_flag = (int *)(g_den + L);
+  int *g_ref = g_flag + L;
+  i64 *vals = arena + rows_off + 2 * (i64)L;
+  for (int i = threadIdx.x; i < nvar + ni; i += blockDim.x) {
+    g_den[i] = 1;
+    g_flag[i] = i < nvar ? PIPAMD_F_UNIT : PIPAMD_F_UNKNOWN;
+    g_ref[i] = i < nvar ? i : i - nvar;
+  }
+  for (int e = threadIdx.x; e < ni * W; e += blockDim.x) {
+    const int s = e / W, j = e % W;
+    vals[e] = j < ncol ? src[(size_t)s * ncol + j] : 0;
+  }
+  const int pad = W - ncol;
+  for (int e = threadIdx.x; e < (S - ni) * pad; e += blockDim.x) {
+    const int s = ni + e / pad, j = ncol + e % pad;
+    vals[(size_t)s * W + j] = 0;
+  }
+}
+
 // gather: what the host needs from each job of the last launch, by status, into out + off[b]:
 //   NEED_COMPA  : n, then per undecided row (ascending): row, critic, constant, nparm parameter coefs
 //   NEED_PARMCUT: row (aux), denominator, ncol entries
@@ -1568,6 +1597,7 @@ __global__ void pip_gather_kernel(const PipJob *jobs, const i64 *arena, int njob
   const int b = blockIdx.x;
   if (b >= njobs) return;
   const PipJob *J = &jobs[b];
+  if (off[b + 1] == off[b]) return;  // the host does not want anything from this job
   i64 *o = out + off[b];
   const int nvar = J->nvar, nparm = J->nparm, L = J->L, W = J->W, ncol = nvar + nparm + 1;
   const i64 *g_den = arena + J->rows_off;
@@ -1623,6 +1653,11 @@ extern "C" hipError_t pipk_launch_clone(i64 *arena, const i64 *list, int n, hipS
 extern "C" hipError_t pipk_launch_patch(i64 *arena, const int *buf, const i64 *index, int n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(pip_patch_kernel, dim3(n), dim3(128), 0, stream, (int *)arena, buf, index, n);
+  return hipGetLastError();
+}
+extern "C" hipError_t pipk_launch_fresh(i64 *arena, const i64 *buf, const i64 *index, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pip_fresh_kernel, dim3(n), dim3(128), 0, stream, arena, buf, index, n);
   return hipGetLastError();
 }
 extern "C" hipError_t pipk_launch_gather(const PipJob *jobs, const i64 *arena, int njobs, i64 *out, const i64 *off,

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -957,7 +958,7 @@ class Forest {
     if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) st_ = 0;
   }
   ~Forest() {
-    void *bufs[] = {d_arena_, d_jobs_, d_off_, d_out_, d_patch_, d_pidx_, d_clone_};
+    void *bufs[] = {d_arena_, d_jobs_, d_off_, d_out_, d_patch_, d_pidx_, d_clone_, d_fresh_, d_fidx_};
     for (void *b : bufs)
       if (b) hipFree(b);
     if (st_) hipStreamDestroy(st_);
@@ -968,6 +969,7 @@ class Forest {
     res.assign(n, FResult());
     P_.assign(n, Prob());
     jobs_.clear();
+    is_sub_.clear();
     // ---- regions
     size_t total = 0;
     for (int i = 0; i < n; i++) {
@@ -992,6 +994,11 @@ class Forest {
       }
     }
     // ---- lock-step loop
+    const bool stats = getenv("PIPAMD_FOREST_STATS") != nullptr;
+    double t_dev = 0, t_host = 0;
+    long long n_launched = 0, n_patchwords = 0;
+    int nsteps = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int step = 0; step < 200000; step++) {
       std::vector<int> lj;
       for (int i = 0; i < n; i++) {
@@ -1005,7 +1012,11 @@ class Forest {
             if (jobs_[f.sub_begin + k].status == PIPAMD_ST_RUN) lj.push_back(f.sub_begin + k);
       }
       if (lj.empty()) break;
+      const double t0 = now();
+      n_launched += (long long)lj.size();
+      n_patchwords += (long long)patch_.size() + 2 * (long long)fresh_.size();
       step_device(lj);
+      const double t1 = now();
       for (int i = 0; i < n; i++) {
         if (P_[i].done) continue;
         try {
@@ -1014,7 +1025,13 @@ class Forest {
           finish_error(i, code);
         }
       }
+      t_dev += t1 - t0;
+      t_host += now() - t1;
+      nsteps++;
     }
+    if (stats)
+      fprintf(stderr, "[forest] %d problems, %d steps, %lld job launches, %.1f MB patches; device steps %.1f ms, host %.1f ms\n",
+              n, nsteps, n_launched, n_patchwords * 4e-6, t_dev * 1e3, t_host * 1e3);
     for (int i = 0; i < n; i++) {
       Prob &q = P_[i];
       if (!q.done) {
@@ -1062,16 +1079,19 @@ class Forest {
   hipStream_t st_ = 0;
   std::vector<Prob> P_;
   std::vector<PipJob> jobs_;  // master copies, index = job id
+  std::vector<char> is_sub_;  // job id -> compa_test / context sub-problem (only its status matters)
   std::vector<int> lpos_;     // job id -> position in the last launch (or -1)
   std::vector<i64> gout_, goff_;
   // device buffers
   i64 *d_arena_ = nullptr, *d_off_ = nullptr, *d_out_ = nullptr, *d_pidx_ = nullptr, *d_clone_ = nullptr;
+  i64 *d_fresh_ = nullptr, *d_fidx_ = nullptr;
+  size_t fresh_cap_ = 0, fidx_cap_ = 0;
   PipJob *d_jobs_ = nullptr;
   int *d_patch_ = nullptr;
   size_t arena_cap_ = 0, jobs_cap_ = 0, off_cap_ = 0, out_cap_ = 0, patch_cap_ = 0, pidx_cap_ = 0, clone_cap_ = 0;
   // staging of the current step
   std::vector<int> patch_;
-  std::vector<i64> pidx_, clones_;
+  std::vector<i64> pidx_, clones_, fresh_, fidx_;
 
   static int even(int x) { return (x + 1) & ~1; }
   static size_t block_words(int nvar, int S, int W) {
@@ -1142,37 +1162,27 @@ class Forest {
     pj.det[0] = 1;
     pj.ebits = 64;
     jobs_.push_back(pj);
+    is_sub_.push_back(0);
     return (int)jobs_.size() - 1;
   }
-  // tab_alloc + tab_get (tab.c:158-248) as one patch
-  void fresh_block(int job, const std::vector<i64> &rows) {
+  // tab_alloc + tab_get (tab.c:158-248): only the rows travel, a kernel builds the block
+  void fresh_begin(int job) {
     const PipJob &pj = jobs_[job];
-    const int nvar = pj.nvar, ni = pj.ni, ncol = nvar + pj.nparm + 1, L = pj.L, S = pj.S, W = pj.W;
-    std::vector<i64> blk(2 * (size_t)L + (size_t)S * W, 0);
-    i64 *den = blk.data();
-    int *flag = (int *)(den + L), *ref = flag + L;
-    for (int k = 0; k < nvar; k++) {
-      den[k] = 1;
-      flag[k] = PIPAMD_F_UNIT;
-      ref[k] = k;
-    }
-    for (int k = 0; k < ni; k++) {
-      den[nvar + k] = 1;
-      flag[nvar + k] = PIPAMD_F_UNKNOWN;
-      ref[nvar + k] = k;
-      for (int c = 0; c < ncol; c++) blk[2 * (size_t)L + (size_t)k * W + c] = rows[(size_t)k * ncol + c];
-    }
-    patch64((size_t)pj.rows_off, blk.data(), blk.size());
+    fidx_.push_back((i64)fresh_.size());
+    const i64 hdr[7] = {pj.rows_off, pj.nvar, pj.ni, pj.nvar + pj.nparm + 1, pj.L, pj.S, pj.W};
+    fresh_.insert(fresh_.end(), hdr, hdr + 7);
+  }
+  void fresh_block(int job, const std::vector<i64> &rows) {
+    fresh_begin(job);
+    fresh_.insert(fresh_.end(), rows.begin(), rows.end());
   }
   int context_job(int i, const Ctx &ctx, int nparm, int nc, const std::vector<i64> *extra) {
     const int ni = nc + (extra ? 1 : 0), ncol = nparm + 1;
     const int job = new_job(i, nparm, 0, ni, -1, PIPAMD_T_INT, ni + 16, ncol);
-    std::vector<i64> r((size_t)ni * ncol);
-    for (int k = 0; k < nc; k++)
-      for (int c = 0; c < ncol; c++) r[(size_t)k * ncol + c] = ctx.at(k, c);
-    if (extra)
-      for (int c = 0; c < ncol; c++) r[(size_t)nc * ncol + c] = (*extra)[c];
-    fresh_block(job, r);
+    fresh_begin(job);
+    for (int k = 0; k < nc; k++) fresh_.insert(fresh_.end(), &ctx.v[(size_t)k * ctx.width], &ctx.v[(size_t)k * ctx.width] + ncol);
+    if (extra) fresh_.insert(fresh_.end(), extra->begin(), extra->begin() + ncol);
+    is_sub_[job] = 1;
     return job;
   }
 
@@ -1240,17 +1250,20 @@ class Forest {
       Lm = std::max(Lm, (int)tab[k].L);
       Sm = std::max(Sm, (int)tab[k].S);
       Wm = std::max(Wm, (int)tab[k].W);
-      const size_t a = 1 + (size_t)tab[k].L * (3 + tab[k].nparm), b = 2 + (size_t)tab[k].W,
-                   c = (size_t)tab[k].nvar * (tab[k].W - tab[k].nvar) + tab[k].nvar;
-      goff_[k + 1] = goff_[k] + (i64)std::max(a, std::max(b, c));
     }
     ensure(d_jobs_, jobs_cap_, sizeof(PipJob) * n);
     ensure(d_off_, off_cap_, sizeof(i64) * (n + 1));
-    ensure(d_out_, out_cap_, sizeof(i64) * (size_t)goff_[n]);
     if (!clones_.empty()) {
       ensure(d_clone_, clone_cap_, sizeof(i64) * clones_.size());
       HIPTHROW(hipMemcpyAsync(d_clone_, clones_.data(), sizeof(i64) * clones_.size(), hipMemcpyHostToDevice, st_));
       HIPTHROW(pipk_launch_clone(d_arena_, d_clone_, (int)(clones_.size() / 3), st_));
+    }
+    if (!fidx_.empty()) {  // new tableaux first: patches (flags of a fresh clone, ...) come after
+      ensure(d_fresh_, fresh_cap_, sizeof(i64) * fresh_.size());
+      ensure(d_fidx_, fidx_cap_, sizeof(i64) * fidx_.size());
+      HIPTHROW(hipMemcpyAsync(d_fresh_, fresh_.data(), sizeof(i64) * fresh_.size(), hipMemcpyHostToDevice, st_));
+      HIPTHROW(hipMemcpyAsync(d_fidx_, fidx_.data(), sizeof(i64) * fidx_.size(), hipMemcpyHostToDevice, st_));
+      HIPTHROW(pipk_launch_fresh(d_arena_, d_fresh_, d_fidx_, (int)fidx_.size(), st_));
     }
     if (!pidx_.empty()) {
       ensure(d_patch_, patch_cap_, sizeof(int) * patch_.size());
@@ -1260,7 +1273,6 @@ class Forest {
       HIPTHROW(pipk_launch_patch(d_arena_, d_patch_, d_pidx_, (int)pidx_.size(), st_));
     }
     HIPTHROW(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice, st_));
-    HIPTHROW(hipMemcpyAsync(d_off_, goff_.data(), sizeof(i64) * (n + 1), hipMemcpyHostToDevice, st_));
     // the staging vectors must stay alive until the copies are done: sync once before reuse
     for (int guard = 0; guard < 64; guard++) {
       HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, st_));
@@ -1274,6 +1286,23 @@ class Forest {
     clones_.clear();
     patch_.clear();
     pidx_.clear();
+    fresh_.clear();
+    fidx_.clear();
+    // gather only what the host will read: nothing for sub-problems (their status is the answer)
+    for (int k = 0; k < n; k++) {
+      size_t need = 0;
+      if (!is_sub_[lj[k]]) {
+        if (tab[k].status == PIPAMD_ST_NEED_COMPA)
+          need = 1 + (size_t)(tab[k].nvar + tab[k].ni) * (3 + tab[k].nparm);
+        else if (tab[k].status == PIPAMD_ST_NEED_PARMCUT)
+          need = 2 + (size_t)tab[k].W;
+        else if (tab[k].status == PIPAMD_ST_SOLUTION)
+          need = (size_t)tab[k].nvar * (tab[k].nparm + 2);
+      }
+      goff_[k + 1] = goff_[k] + (i64)need;
+    }
+    ensure(d_out_, out_cap_, sizeof(i64) * (size_t)goff_[n] + 8);
+    HIPTHROW(hipMemcpyAsync(d_off_, goff_.data(), sizeof(i64) * (n + 1), hipMemcpyHostToDevice, st_));
     HIPTHROW(pipk_launch_gather(d_jobs_, d_arena_, n, d_out_, d_off_, st_));
     gout_.resize((size_t)goff_[n]);
     if (goff_[n])
