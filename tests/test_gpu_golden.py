@@ -87,3 +87,25 @@ def test_compute_dual_on_gpu(name):
            "- the constraint matrix.\n" + matrix_text(domain) + "\n" + text)
     want = open(os.path.join(d, f"dual__{name}.ll"), encoding="latin-1").read()
     assert pb.squash(got) == pb.squash(want)
+
+
+def test_plain_c_example():
+    """examples/solve_small.c (built by __graft_entry__.build()): the C ABI from plain C --
+    pip_solve drop-in output equals the reference's example/small.ll quast, the tableau-form
+    call equals the oracle."""
+    import subprocess
+    import numpy as np
+    from piplib_amd import synth
+    exe = os.path.join(pb.ROOT, "examples", "solve_small")
+    if not os.access(exe, os.X_OK):
+        import __graft_entry__
+        __graft_entry__.build()
+    p = subprocess.run([exe], capture_output=True, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    out = pb.squash(p.stdout.decode())
+    want_quast = pb.squash(open(os.path.join(G, "example", "small.ll")).read()).split("3")[-1]  # "(list#[0]#[0])"
+    assert out.startswith(want_quast) or want_quast in out
+    prob = synth.Problem(2, 1, 3, 1, -1, 1, np.array([[1, 1, 0, -1], [-1, 0, 5, 0], [0, -1, 7, 0]], dtype=np.int64),
+                         np.array([[-1, 12]], dtype=np.int64))
+    o = pb.run_batch(pb.ORACLEPIP, [prob])
+    assert out.endswith(pb.squash(o.results[0].text))
