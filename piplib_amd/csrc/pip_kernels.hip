@@ -289,7 +289,7 @@ __device__ __forceinline__ void bsync() {
 
 // Optional phase profile (diagnostic build only: -DPIP_PROFILE; never shipped/timed).
 #ifdef PIP_PROFILE
-#define PROF_DECL u64 pf_t = __builtin_readcyclecounter(), pf_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_DECL u64 pf_t = __builtin_readcyclecounter(), pf_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF(i)                                \
   do {                                         \
     u64 pf_n = __builtin_readcyclecounter();   \
@@ -299,7 +299,7 @@ __device__ __forceinline__ void bsync() {
 #define PROF_FLUSH(buf)                                                \
   do {                                                                 \
     if (threadIdx.x == 0 && buf)                                       \
-      for (int q_ = 0; q_ < 10; q_++) atomicAdd(&buf[q_], pf_acc[q_]); \
+      for (int q_ = 0; q_ < 16; q_++) atomicAdd(&buf[q_], pf_acc[q_]); \
   } while (0)
 #else
 #define PROF_DECL
@@ -1288,6 +1288,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             T nd;
             // multipliers from the row's own pivot-column entry (traiter.c:470-476)
             T foo = row_entry<T, NCH>(r, pc, ph, pl);
+            PROF(9);
             if (foo == 0 && (S.sig[s] & SIG_RED)) {
               // only reached with PIPAMD_T_NOSKIP: multipliers (1, 0) and gcd 1, the reference
               // rewrites the row with the bits it read -- so do we, without the arithmetic
@@ -1299,12 +1300,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             const T lp = cquo(pivot, d);
             foo = cquo(foo, d);
             const T g0 = wmul(lp, uni64(S.den[s]));
+            PROF(10);
             if (!update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
               if (lane == 0) sc.bad = 1;
             }
+            PROF(11);
             row_store<T, NCH>(r, row, ncolp, lane);
             row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane);
             if (lane == 0) S.den[s] = nd;
+            PROF(12);
           }
         }
       }

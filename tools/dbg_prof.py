@@ -14,12 +14,12 @@ b = eng.Batch(e, rows, 127, 0, tflags=eng.T_INT)
 L.pipamd_debug_profile(e._h, 1, None)
 for it in range(2):
     b.load(); b.solve()
-    out = (C.c_uint64 * 10)()
+    out = (C.c_uint64 * 16)()
     L.pipamd_debug_profile(e._h, 1, out)
     ms = b.last_solve_ms()
     v = np.array(list(out), dtype=np.float64)
     c = b.counters()
-    names = ["entry", "exam", "integrer", "A prow+guard", "A column", "A worklist+det", "B update", "C flags", "epilogue", "-"]
+    names = ["entry", "exam", "integrer", "A prow+guard", "A column", "A worklist+det", "B rest", "C flags", "epilogue", "B load wait", "B multipliers", "B update_row", "B store+publish", "-", "-", "-"]
     print(f"kernel {ms:.2f} ms pivots {c['pivots']} rows_rewritten {c['rows_rewritten']} cuts {c['cuts']}")
     for n, x in zip(names, v):
         print(f"  {n:10s} {100*x/v.sum():5.1f}%  {x/c['pivots']:9.0f} cycles/pivot")
