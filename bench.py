@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch tableaux per GPU (default); strong: --batch tableaux in all, sharded over the ranks")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (streams/threads)")
+    ap.add_argument("--stagger", type=float, default=-1.0,
+                    help="ms between the lanes' starts (0 = none, <0 = step latency / lanes, measured in warm-up)")
     ap.add_argument("--no-dense", action="store_true", help="skip the row-skipping-off measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
@@ -119,8 +121,14 @@ def main():
         pdist.barrier()
         torch.cuda.synchronize(dev)
 
+    stagger = [0.0]
+
     def run_lane(i, nsteps):
         _, bi, st = lanes[i]
+        # lanes start a fraction of a step apart, so that one batch's under-filled last rounds
+        # coincide with another batch's bulk rounds instead of with its last rounds
+        if stagger[0] > 0 and i:
+            time.sleep(i * stagger[0])
         with torch.cuda.stream(st):
             for _ in range(nsteps):
                 bi.load()
@@ -138,6 +146,15 @@ def main():
 
     run_steps(max(args.warmup, depth))
     barrier()
+    if depth > 1 and args.stagger != 0:
+        if args.stagger > 0:
+            stagger[0] = args.stagger * 1e-3
+        else:  # one lane's own step latency with every lane busy, spread evenly over the lanes
+            tw = time.perf_counter()
+            run_steps(depth)
+            torch.cuda.synchronize(dev)
+            stagger[0] = (time.perf_counter() - tw) / depth
+        barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()

@@ -771,6 +771,31 @@ __device__ int choose_column_slow(const Shared<T> &S, const T *vals, int W, int 
   return pivj;
 }
 
+// Wave-wide unsigned min / max without LDS traffic: a DPP butterfly inside each row of 16
+// lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row results
+// through the scalar unit.  Call with all 64 lanes active; the result is wave-uniform.
+template <bool MAX>
+__device__ __forceinline__ unsigned wave_minmax_u32(unsigned v) {
+#define PIP_DPP_STEP(ctrl)                                                                         \
+  {                                                                                                \
+    unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, 0xf, 0xf, false);     \
+    v = MAX ? (o > v ? o : v) : (o < v ? o : v);                                                   \
+  }
+  PIP_DPP_STEP(0xB1)   // quad_perm [1,0,3,2]
+  PIP_DPP_STEP(0x4E)   // quad_perm [2,3,0,1]
+  PIP_DPP_STEP(0x141)  // row_half_mirror
+  PIP_DPP_STEP(0x140)  // row_mirror
+#undef PIP_DPP_STEP
+  const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  if (MAX) {
+    const unsigned a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
+  }
+  const unsigned a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+  return a < b ? a : b;
+}
+
 // ------------------------------------------------------------ tab_sort_rows
 // traiter.c:591-614: selection sort of the real rows nvar..nligne-1 by `size`
 // (first minimum strictly below the running bound, swap into place).  With
@@ -778,6 +803,42 @@ __device__ int choose_column_slow(const Shared<T> &S, const T *vals, int W, int 
 template <class T>
 __device__ void sort_rows(const Shared<T> &S, int nvar, int nligne, double smax) {
   const int lane = threadIdx.x & 63;
+  if (nligne - nvar <= 64) {
+    // at most 64 candidate rows: lane l keeps logical row nvar+l (its slot, its key and whether
+    // the selection may pick it) in registers.  Sizes are non-negative floats, so their bit
+    // patterns order like the values.  Same selection and swaps as below.
+    const int n = nligne - nvar;
+    unsigned rf = lane < n ? S.ref[nvar + lane] : UNITBIT;
+    const bool unit = (rf & UNITBIT) != 0;
+    unsigned key = 0xFFFFFFFFu;  // rows the selection never picks (Unit, or size >= smax)
+    if (!unit) {
+      const float sj = S.size[rf];
+      if ((double)sj < smax) key = __float_as_uint(sj);
+    }
+    const u64 units = __ballot(unit);
+    for (int i = 0; i < n; i++) {
+      if ((units >> i) & 1) continue;
+      const unsigned m = wave_minmax_u32<false>(lane >= i ? key : 0xFFFFFFFFu);
+      if (m == 0xFFFFFFFFu) continue;  // nothing below smax is left: row i stays
+      const u64 hit = __ballot(lane >= i && key == m);
+      const int pv = __builtin_ctzll(hit);
+      if (pv != i) {
+        const unsigned ki = __builtin_amdgcn_readlane(key, i), ri = __builtin_amdgcn_readlane(rf, i);
+        const unsigned rp = __builtin_amdgcn_readlane(rf, pv);
+        if (lane == pv) {
+          key = ki;
+          rf = ri;
+        }
+        if (lane == i) {
+          key = m;
+          rf = rp;
+        }
+      }
+    }
+    if (lane < n && !unit) S.ref[nvar + lane] = (u16)rf;
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
   for (int i = nvar; i < nligne; i++) {
     if (S.ref[i] & UNITBIT) continue;
     float best = 0;
@@ -922,6 +983,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     }
   }
   bsync<NW>();
+  PROF(13);
   if ((tflags & PIPAMD_T_STATE) && J->state_nch == NCH) {
     // resumed job: the summaries were saved when it paused
     for (int s = tid; s < ni; s += NT) {
@@ -948,43 +1010,59 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         const bool den1 = S.den[s] == 1;
         row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, -1, den1 ? SIG_RED : 0, has_parm, lane);
         if (tflags & PIPAMD_T_SORT) {
-          // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns
-          double d = to_double(S.den[s]), sz = 0;
+          // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns.  The per-entry
+          // terms are ints (x86 cvttsd2si: INT_MIN when out of range, and abs(INT_MIN) stays
+          // negative, so it never wins the max): the row maximum is in [0, 2^31).
+          int sz = 0;
+          if (den1) {
+            // x / 1.0 == x exactly, and (int)x is x itself when it fits an int
 #pragma unroll
-          for (int c = 0; c < NCH; c++)
+            for (int c = 0; c < NCH; c++)
 #pragma unroll
-            for (int h = 0; h < ET<T>::CPL; h++) {
-              int j = colof<T>(c, lane, h);
-              if (j < nvar) {
-                const double tv = to_double(r.v[c][h]);
-                int q2 = trunc_int_x86(den1 ? tv : tv / d);  // x / 1.0 == x exactly
-                double aq = (double)(q2 < 0 ? (int)(0u - (unsigned)q2) : q2);
-                sz = sz > aq ? sz : aq;
+              for (int h = 0; h < ET<T>::CPL; h++) {
+                int j = colof<T>(c, lane, h);
+                if (j < nvar) {
+                  const T v = r.v[c][h];
+                  const int q2 = (v == (T)(int)v) ? (int)v : (int)0x80000000;
+                  const int aq = q2 < 0 ? (int)(0u - (unsigned)q2) : q2;
+                  sz = sz > aq ? sz : aq;
+                }
               }
-            }
-          for (int o = 32; o; o >>= 1) {
-            double t = __shfl(sz, lane ^ o);
-            sz = sz > t ? sz : t;
+          } else {
+            const double d = to_double(S.den[s]);
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+              for (int h = 0; h < ET<T>::CPL; h++) {
+                int j = colof<T>(c, lane, h);
+                if (j < nvar) {
+                  const int q2 = trunc_int_x86(to_double(r.v[c][h]) / d);
+                  const int aq = q2 < 0 ? (int)(0u - (unsigned)q2) : q2;
+                  sz = sz > aq ? sz : aq;
+                }
+              }
           }
+          const unsigned szw = wave_minmax_u32<true>((unsigned)sz);
           if (lane == 0) {
-            S.size[s] = (float)sz;
-            // smax is taken over rows nvar..nligne-1 only (traiter.c:576-586); sizes are >= 0,
-            // so their bit patterns order like the doubles
-            if ((int)S.srow[s] >= nvar) atomicMax(&sc.smaxbits, (u64)__double_as_longlong(sz));
+            S.size[s] = (float)szw;
+            // smax is taken over rows nvar..nligne-1 only (traiter.c:576-586)
+            if ((int)S.srow[s] >= nvar) atomicMax(&sc.smaxbits, (u64)szw);
           }
         }
       }
     }
   }
   bsync<NW>();
+  PROF(14);
   if (tflags & PIPAMD_T_SORT) {
-    if (wave == 0) sort_rows(S, nvar, nligne, __longlong_as_double((i64)sc.smaxbits));
+    if (wave == 0) sort_rows(S, nvar, nligne, (double)sc.smaxbits);
     bsync<NW>();
     for (int i = tid; i < nligne; i += NT)
       if (!(S.ref[i] & UNITBIT)) S.srow[S.ref[i]] = (u16)i;
     tflags &= ~PIPAMD_T_SORT;
     bsync<NW>();
   }
+  PROF(15);
   // chercher(Minus) and the tentative exam_coef flags for the first iteration; later
   // iterations get both from phase C
   for (int s = tid; s < ni; s += NT) {

@@ -7,7 +7,8 @@ eng.LIB_PATH = os.path.join(eng.HERE, "libpipamd_prof.so")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 rows = synth.lexmin_batch(1000, B, 127, 64)
 e = eng.Engine(0)
-if len(sys.argv) > 2: e.set_waves_per_job(int(sys.argv[2]))
+if len(sys.argv) > 2 and int(sys.argv[2]): e.set_waves_per_job(int(sys.argv[2]))
+if len(sys.argv) > 3: e.set_round_pivots(int(sys.argv[3]))
 L = eng.lib()
 L.pipamd_debug_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 b = eng.Batch(e, rows, 127, 0, tflags=eng.T_INT)
@@ -19,7 +20,7 @@ for it in range(2):
     ms = b.last_solve_ms()
     v = np.array(list(out), dtype=np.float64)
     c = b.counters()
-    names = ["entry", "exam", "integrer", "A prow+guard", "A column", "A worklist+det", "B rest", "C flags", "epilogue", "B load wait", "B multipliers", "B update_row", "B store+publish", "-", "-", "-"]
-    print(f"kernel {ms:.2f} ms pivots {c['pivots']} rows_rewritten {c['rows_rewritten']} cuts {c['cuts']}")
+    names = ["entry", "exam", "integrer", "A prow+guard", "A column", "A worklist+det", "B rest", "C flags", "epilogue", "B load wait", "B multipliers", "B update_row", "B store+publish", "entry tables", "entry pass", "entry sort"]
+    print(f"launches {e.last_solve_launches()} kernel {ms:.2f} ms pivots {c['pivots']} rows_rewritten {c['rows_rewritten']} cuts {c['cuts']}")
     for n, x in zip(names, v):
         print(f"  {n:10s} {100*x/v.sum():5.1f}%  {x/c['pivots']:9.0f} cycles/pivot")
