@@ -9,7 +9,7 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on): per GPU a 
 column; no parameters), integer solve with Gomory cuts, one workgroup per tableau.
 A "step" = tab_get-style load of the batch into the HBM row store + the whole traiter()
 pivot loop for every tableau (inputs are resident in HBM before the timed region).
-Steps are pipelined: up to --pipeline (default 3) batches are in flight on separate HIP streams
+Steps are pipelined: up to --pipeline (default 12) batches are in flight on separate HIP streams
 (each step is a complete load + solve of its batch); ms_per_step is total time / steps.
 Multi-GPU: independent problems, so each rank owns its own batch (weak scaling, no
 data-path collective); RCCL is used only to gather the totals.
@@ -67,20 +67,24 @@ def cpu_baseline(rows, max_procs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--batch", type=int, default=10000, help="tableaux per GPU")
     ap.add_argument("--waves", type=int, default=0, help="waves per tableau (0 = engine default)")
     ap.add_argument("--round", type=int, default=0, help="pivots per tableau per launch (0 = engine default)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch tableaux per GPU (default); strong: --batch tableaux in all, sharded over the ranks")
-    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (streams/threads)")
+    ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (streams/threads)")
     ap.add_argument("--stagger", type=float, default=-1.0,
                     help="ms between the lanes' starts (0 = none, <0 = step latency / lanes, measured in warm-up)")
     ap.add_argument("--no-dense", action="store_true", help="skip the row-skipping-off measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
+    # Batches in flight run on separate HIP streams; the runtime multiplexes streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels that share a queue serialise, so
+    # give every lane a queue of its own (a HIP runtime setting, read when the runtime starts).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import numpy as np
     import torch
     from piplib_amd import engine as eng

@@ -241,13 +241,13 @@ extern "C" int pipamd_batch_counters(pipamd_engine *e, const void *d_ws, const p
 extern "C" int pipamd_debug_profile(pipamd_engine *e, int enable, uint64_t *host_out10) {
   if (!e) return PIPAMD_E_INVALID;
   if (enable && !e->d_prof) {
-    HIPCHK(hipMalloc((void **)&e->d_prof, 16 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(e->d_prof, 0, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&e->d_prof, 32 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(e->d_prof, 0, 32 * sizeof(unsigned long long)));
   }
   if (host_out10 && e->d_prof) {
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(host_out10, e->d_prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(e->d_prof, 0, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemcpy(host_out10, e->d_prof, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->d_prof, 0, 32 * sizeof(unsigned long long)));
   }
   return PIPAMD_OK;
 }

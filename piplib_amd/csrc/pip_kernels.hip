@@ -296,6 +296,10 @@ __device__ __forceinline__ void bsync() {
     pf_acc[i] += pf_n - pf_t;                  \
     pf_t = pf_n;                               \
   } while (0)
+#define PROF_CNT(buf, i, c)                                                     \
+  do {                                                                          \
+    if ((threadIdx.x & 63) == 0 && buf && (c)) atomicAdd(&buf[16 + (i)], 1ull); \
+  } while (0)
 #define PROF_FLUSH(buf)                                                \
   do {                                                                 \
     if (threadIdx.x == 0 && buf)                                       \
@@ -304,6 +308,7 @@ __device__ __forceinline__ void bsync() {
 #else
 #define PROF_DECL
 #define PROF(i)
+#define PROF_CNT(buf, i, c)
 #define PROF_FLUSH(buf)
 #endif
 
@@ -330,6 +335,12 @@ __device__ __forceinline__ int cls_of(typename ET<T>::U orall) {  // wave-collec
 // that holds the row, register (c = j/128, h = j&1); a row's non-zero bitmap uses the same
 // geometry: word 2c+h, bit (j%128)/2.  Everything that only real rows have is indexed by
 // slot, so the per-pivot loops run over the real rows only.
+// bytes of the LDS region shared by prow and the entry-time sort keys (Smax floats)
+__host__ __device__ __forceinline__ size_t prow_bytes(size_t prow, int Smax) {
+  size_t k = sizeof(float) * (size_t)Smax;
+  return ((prow > k ? prow : k) + 15) & ~(size_t)15;
+}
+
 template <class T>
 struct Shared {
   T *den;     // [S]  denominator of the row in slot s
@@ -910,10 +921,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   {
     unsigned char *p = smem;
     S.den = (T *)p;      p += sizeof(T) * Smax;
-    S.prow = (T *)p;     p += sizeof(T) * WP;
+    // the sort keys are dead once the rows are sorted (before the first pivot row is staged):
+    // they share prow's storage, which is sized for the larger of the two
+    S.prow = (T *)p;
+    S.size = (float *)p;
+    p += prow_bytes(sizeof(T) * WP, Smax);
     S.cst = (T *)p;      p += sizeof(T) * Smax;
     S.nzm = (u64 *)p;    p += sizeof(u64) * (size_t)Smax * NM;
-    S.size = (float *)p; p += sizeof(float) * Smax;
     S.sig = (u16 *)p;    p += sizeof(u16) * Smax;
     S.srow = (u16 *)p;   p += sizeof(u16) * Smax;
     S.work = (u16 *)p;   p += sizeof(u16) * Smax;
@@ -953,10 +967,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   u8 *g_rcls = (u8 *)(g_sig + Sl);
 
   // ---- stage the row tables in LDS -------------------------------------
-  for (int j = tid; j < WP; j += NT) {
-    S.urow[j] = NOROW;
-    S.prow[j] = 0;
-  }
+  for (int j = tid; j < WP; j += NT) S.urow[j] = NOROW;  // prow is written whole by every phase A
   if (tid == 0) {
     sc.aux = 0;
     sc.smaxbits = 0;
@@ -1383,6 +1394,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
               if (lane == 0) sc.bad = 1;
             }
             PROF(11);
+            PROF_CNT(prof, 0, true);
+            PROF_CNT(prof, 1, pivot != 1);
+            PROF_CNT(prof, 2, d != 1);
+            PROF_CNT(prof, 3, g0 != 1);
+            PROF_CNT(prof, 4, nd != g0);
+            PROF_CNT(prof, 5, uni64(S.den[s]) != 1);
+            PROF_CNT(prof, 6, (u64)uabs64(pivot) >> 16 != 0);
             row_store<T, NCH>(r, row, ncolp, lane);
             row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane);
             if (lane == 0) S.den[s] = nd;
@@ -1766,7 +1784,7 @@ extern "C" hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, i
 extern "C" size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax, int ebits) {
   const size_t WP = (size_t)wp_of(Wmax, ebits);
   const size_t NM = WP / 64, EB = ebits == 128 ? 16 : 8;
-  size_t shm = EB * (2 * (size_t)Smax + WP) + sizeof(u64) * (size_t)Smax * NM + sizeof(float) * (size_t)Smax +
+  size_t shm = EB * 2 * (size_t)Smax + prow_bytes(EB * WP, Smax) + sizeof(u64) * (size_t)Smax * NM +
                sizeof(u16) * (3 * (size_t)Smax + (size_t)Lmax + WP) + 3 * (size_t)Smax + (size_t)Lmax;
   return (shm + 15) & ~(size_t)15;
 }

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpipamd.so")
+# PIPAMD_LIB: tuning experiments with an alternative build of the same library (tools/ only)
+LIB_PATH = os.environ.get("PIPAMD_LIB") or os.path.join(HERE, "libpipamd.so")
 
 ST_RUN, ST_SOLUTION, ST_NIL, ST_NEED_COMPA, ST_NEED_PARMCUT, ST_OVERFLOW, ST_CAPACITY, ST_RANGE, ST_INTERNAL, ST_MAXCOL = range(10)
 T_INT, T_DUAL = 1, 2

@@ -15,12 +15,16 @@ b = eng.Batch(e, rows, 127, 0, tflags=eng.T_INT)
 L.pipamd_debug_profile(e._h, 1, None)
 for it in range(2):
     b.load(); b.solve()
-    out = (C.c_uint64 * 16)()
+    out = (C.c_uint64 * 32)()
     L.pipamd_debug_profile(e._h, 1, out)
     ms = b.last_solve_ms()
     v = np.array(list(out), dtype=np.float64)
     c = b.counters()
     names = ["entry", "exam", "integrer", "A prow+guard", "A column", "A worklist+det", "B rest", "C flags", "epilogue", "B load wait", "B multipliers", "B update_row", "B store+publish", "entry tables", "entry pass", "entry sort"]
     print(f"launches {e.last_solve_launches()} kernel {ms:.2f} ms pivots {c['pivots']} rows_rewritten {c['rows_rewritten']} cuts {c['cuts']}")
+    cn = ["rows updated", "pivot != 1", "gcd(pivot, foo) != 1", "g0 != 1", "row divided (g != 1)", "den != 1", "pivot >= 2^16"]
+    for n, x in zip(cn, v[16:]):
+        print(f"  {n:24s} {x / c['pivots']:7.3f} per pivot")
+    v = v[:16]
     for n, x in zip(names, v):
         print(f"  {n:10s} {100*x/v.sum():5.1f}%  {x/c['pivots']:9.0f} cycles/pivot")
