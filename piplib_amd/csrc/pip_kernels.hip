@@ -61,6 +61,16 @@ typedef unsigned char u8;
 #define BIG_I 0x7fffffff
 #define NOROW 0xffff
 
+#ifdef PIP_PROFILE
+__device__ unsigned long long *pf_buf;  // diagnostic build: event counters behind the phase stamps
+#define CNT(i, n)                                                                          \
+  do {                                                                                     \
+    if ((threadIdx.x & 63) == 0 && pf_buf) atomicAdd(&pf_buf[16 + (i)], (unsigned long long)(n)); \
+  } while (0)
+#else
+#define CNT(i, n)
+#endif
+
 // ---------------------------------------------------------------- integer ops
 // piplib.h:128-169 + integrer.c:43-74 on wrap-around 64-bit integers.
 __device__ __forceinline__ u64 uabs64(i64 x) { return x < 0 ? 0ull - (u64)x : (u64)x; }
@@ -75,7 +85,9 @@ __device__ __forceinline__ u64 gcd_u64(u64 a, u64 b) {
   if (b == 0) return a;
   int sh = __builtin_ctzll(a | b);
   a >>= __builtin_ctzll(a);
+  CNT(7, 1);
   do {
+    CNT(8, 1);
     b >>= __builtin_ctzll(b);
     if (a > b) {
       u64 t = a;
@@ -91,7 +103,9 @@ __device__ __forceinline__ unsigned gcd_u32(unsigned a, unsigned b) {
   if (b == 0) return a;
   int sh = __builtin_ctz(a | b);
   a >>= __builtin_ctz(a);
+  CNT(9, 1);
   do {
+    CNT(10, 1);
     b >>= __builtin_ctz(b);
     if (a > b) {
       unsigned t = a;
@@ -126,7 +140,11 @@ __device__ __forceinline__ i64 cquo(i64 a, i64 b) {
   if (b == 1) return a;
   if (b == 0) return 0;
   if (b == -1) return wneg(a);
-  if ((i64)(int)a == a && (i64)(int)b == b) return (i64)((int)a / (int)b);
+  if ((i64)(int)a == a && (i64)(int)b == b) {
+    CNT(11, 1);
+    return (i64)((int)a / (int)b);
+  }
+  CNT(12, 1);
   return a / b;
 }
 __device__ __forceinline__ i64 crem(i64 a, i64 b) {
@@ -496,6 +514,8 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
         U m = g == 0 ? a : umod_small(a, g, small);
         rr = rr ? rr : m;
       }
+    CNT(13, 1);
+    CNT(14, small ? 0 : 1);
     u64 nz = __ballot(rr != 0);
     if (!nz) break;
     int src = __ffsll((long long)nz) - 1;
@@ -916,6 +936,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   constexpr int NM = NCH * ET<T>::CPL;
   (void)Wmax;
   PROF_DECL;
+#ifdef PIP_PROFILE
+  if (threadIdx.x == 0 && prof) pf_buf = prof;
+#endif
 
   Shared<T> S;
   {

@@ -22,7 +22,7 @@ for it in range(2):
     c = b.counters()
     names = ["entry", "exam", "integrer", "A prow+guard", "A column", "A worklist+det", "B rest", "C flags", "epilogue", "B load wait", "B multipliers", "B update_row", "B store+publish", "entry tables", "entry pass", "entry sort"]
     print(f"launches {e.last_solve_launches()} kernel {ms:.2f} ms pivots {c['pivots']} rows_rewritten {c['rows_rewritten']} cuts {c['cuts']}")
-    cn = ["rows updated", "pivot != 1", "gcd(pivot, foo) != 1", "g0 != 1", "row divided (g != 1)", "den != 1", "pivot >= 2^16"]
+    cn = ["rows updated", "pivot != 1", "gcd(pivot, foo) != 1", "g0 != 1", "row divided (g != 1)", "den != 1", "pivot >= 2^16", "gcd_u64 calls", "gcd_u64 iterations", "gcd_u32 calls", "gcd_u32 iterations", "cquo 32-bit divisions", "cquo 64-bit divisions", "refinement rounds", "refinement rounds (64-bit mod)"]
     for n, x in zip(cn, v[16:]):
         print(f"  {n:24s} {x / c['pivots']:7.3f} per pivot")
     v = v[:16]
