@@ -260,6 +260,7 @@ def main():
                          "measured": "HIP events around each launch, 2 un-pipelined steps after the timed "
                                      "region (= `bench.py --pipeline 1`, the command of profiles/r01_kernel_stats.csv)",
                          "algorithmic_bytes_per_step": algo_bytes,
+                         "timed_region_GBps": algo_bytes / (ms_step * 1e-3) / 1e9,
                          "dense_equivalent_GBps": b.pivot_bytes() * piv_rank / (k_ms * 1e-3) / 1e9,
                          "note": "sparse workload: ~2.7 of ~80 rows change per pivot, so the pivot loop is "
                                  "latency/issue-bound, not HBM-bound; see roofline_dense_mode for the "

@@ -273,7 +273,7 @@ __device__ __forceinline__ i128 uni64(i128 v) {
   return (i128)(((u128)hi << 64) | lo);
 }
 __device__ __forceinline__ u128 umod_small(u128 a, u128 g, bool small32) {
-  (void)small32;
+  if (small32) return (u128)((unsigned)a % (unsigned)g);
   return umod128(a, g);
 }
 __device__ __forceinline__ u64 umod_small(u64 a, u64 g, bool small32) {
