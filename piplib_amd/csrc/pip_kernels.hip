@@ -204,10 +204,30 @@ __device__ __forceinline__ int bitlen64(u128 x) {
   return hi ? 128 - __builtin_clzll(hi) : bitlen64((u64)x);
 }
 __device__ __forceinline__ bool fits64(i128 x) { return (i128)(i64)x == x; }
+// a mod b for a 32-bit b != 0, one 32-bit digit of a at a time: t = r*2^32 + digit < b*2^32,
+// so the quotient of each step is below 2^32 and a double-precision estimate of it is off by
+// at most one.
+__device__ __forceinline__ unsigned umod128_32(u128 a, unsigned b) {
+  unsigned r = 0;
+#pragma unroll
+  for (int k = 3; k >= 0; k--) {
+    const u64 t = ((u64)r << 32) | (unsigned)(a >> (32 * k));
+    const u64 q = (u64)((double)t / (double)b);
+    i64 d = (i64)(t - q * b);
+    if (d < 0) d += b;
+    if (d >= (i64)b) d -= b;
+    r = (unsigned)d;
+  }
+  return r;
+}
 __device__ __forceinline__ u128 gcd_mag(u128 a, u128 b) {
   if (((a | b) >> 64) == 0) return gcd_mag((u64)a, (u64)b);
   if (a == 0) return b;
   if (b == 0) return a;
+  // a wide determinant limb against a small denominator: one Euclid step first -- the
+  // subtractive binary gcd below needs a 128-bit iteration per bit of the size difference
+  if ((b >> 32) == 0) return (u128)gcd_mag((u64)(unsigned)b, (u64)umod128_32(a, (unsigned)b));
+  if ((a >> 32) == 0) return (u128)gcd_mag((u64)(unsigned)a, (u64)umod128_32(b, (unsigned)a));
   int sh = ctz128(a | b);
   a >>= ctz128(a);
   do {
@@ -937,7 +957,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   (void)Wmax;
   PROF_DECL;
 #ifdef PIP_PROFILE
-  if (threadIdx.x == 0 && prof) pf_buf = prof;
+  if (threadIdx.x == 0) pf_buf = (prof && prof[31]) ? prof : nullptr;
 #endif
 
   Shared<T> S;
