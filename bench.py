@@ -94,9 +94,14 @@ def main():
     rank, world, local = pdist.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # PIPAMD_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than
+    # ranks (ranks then share GPUs); the driver's runs use nccl (== RCCL on ROCm), one GPU per rank
+    backend = os.environ.get("PIPAMD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    pdist.init("nccl", dev)  # nccl == RCCL on ROCm
+    pdist.init(backend, dev)
 
     if args.scaling == "strong":  # BASELINE configs[3]: one 10k batch sharded over the GPUs
         lo, hi = pdist.shard_range(args.batch, rank, world)

@@ -160,7 +160,7 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
     const int waves = e->waves_per_job ? e->waves_per_job : (running >= 2048 ? 1 : 4);
     // few tableaux left: the GPU is under-filled whatever we do, so let them run to the end in
     // one launch (LDS image sized for every spare row) instead of paying a launch per round
-    int budget = (waves == 4 && running < 2048) ? e->iter_limit : K;
+    int budget = running < 2048 ? e->iter_limit : K;
     if (e->iter_limit < budget) budget = e->iter_limit;
     int smax = budget >= lay.S ? lay.S : max_ni + budget;  // a cut is always followed by a pivot
     if (smax > lay.S) smax = lay.S;
