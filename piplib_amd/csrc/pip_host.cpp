@@ -241,17 +241,17 @@ extern "C" int pipamd_batch_counters(pipamd_engine *e, const void *d_ws, const p
 extern "C" int pipamd_debug_profile(pipamd_engine *e, int enable, uint64_t *host_out10) {
   if (!e) return PIPAMD_E_INVALID;
   if (enable && !e->d_prof) {
-    HIPCHK(hipMalloc((void **)&e->d_prof, 32 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(e->d_prof, 0, 32 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&e->d_prof, 64 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(e->d_prof, 0, 64 * sizeof(unsigned long long)));
   }
   if (host_out10 && e->d_prof) {
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(host_out10, e->d_prof, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(e->d_prof, 0, 32 * sizeof(unsigned long long)));
+    HIPCHK(hipMemcpy(host_out10, e->d_prof, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->d_prof, 0, 64 * sizeof(unsigned long long)));
   }
-  if (e->d_prof) {  // slot 31 switches the event counters on (enable == 2): their atomics distort the cycle stamps
+  if (e->d_prof) {  // slot 63 switches the event counters on (enable == 2): their atomics distort the cycle stamps
     const unsigned long long ev = enable == 2 ? 1 : 0;
-    HIPCHK(hipMemcpy(e->d_prof + 31, &ev, sizeof ev, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_prof + 63, &ev, sizeof ev, hipMemcpyHostToDevice));
   }
   return PIPAMD_OK;
 }

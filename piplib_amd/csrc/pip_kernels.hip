@@ -1353,14 +1353,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     const T dpiv = uni64(S.den[pslot]);
     {
       T d = gcd_i64(pivot, dpiv);
-      T ppivot = cquo(pivot, d), dppiv = cquo(dpiv, d);
-      for (int i = 0; i < ldet; i++) {
+      T ppivot = pivot, dppiv = dpiv;
+      if (d != 1) {
+        ppivot = cquo(pivot, d);
+        dppiv = cquo(dpiv, d);
+      }
+      // once dppiv is 1 the remaining limbs would be divided by gcd(limb, 1) = 1
+      for (int i = 0; i < ldet && dppiv != 1; i++) {
         d = gcd_i64(det[i], dppiv);
-        det[i] = cquo(det[i], d);
-        dppiv = cquo(dppiv, d);
+        if (d != 1) {
+          det[i] = cquo(det[i], d);
+          dppiv = cquo(dppiv, d);
+        }
       }
       bool ovf = dppiv != 1;
-      if (!ovf) {
+      // ppivot == 1 with room in the first limb: det[0] *= 1
+      if (!ovf && !(ppivot == 1 && log2_64(det[0]) + 1 < ET<T>::BITS)) {
         int i = 0;
         for (; i < ldet; i++)
           if (log2_64(det[i]) + log2_64(ppivot) < ET<T>::BITS) {
@@ -1428,10 +1436,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
               if (lane == 0) S.sig[s] &= ~0xC0;
               continue;
             }
-            const T d = gcd_i64(pivot, foo);
-            const T lp = cquo(pivot, d);
-            foo = cquo(foo, d);
-            const T g0 = wmul(lp, uni64(S.den[s]));
+            // pivot > 0 (choisir_piv only takes positive entries): with pivot == 1, or
+            // gcd(pivot, foo) == 1, the divisions of traiter.c:472-474 are by 1
+            const T den_s = uni64(S.den[s]);
+            T d = 1, lp = pivot, g0 = den_s;
+            if (pivot != 1) {
+              d = gcd_i64(pivot, foo);
+              if (d != 1) {
+                lp = cquo(pivot, d);
+                foo = cquo(foo, d);
+              }
+              g0 = wmul(lp, den_s);
+            }
             PROF(10);
             if (!update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
               if (lane == 0) sc.bad = 1;
@@ -1542,10 +1558,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       sol_den[i] = (rf & UNITBIT) ? 1 : S.den[rf];
     }
   }
-  if (tid == 0) {
-    int mc = 0;
-    for (int s = 0; s < ni; s++)
+  int mc = 0;
+  if (wave == 0) {
+    for (int s = lane; s < ni; s += 64)
       if (S.rcls[s] > mc) mc = S.rcls[s];
+    mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
+  }
+  if (tid == 0) {
     J->ni = ni;
     J->npiv = npiv;
     J->ncut = ncut;

@@ -18,15 +18,15 @@ EVENTS = int(os.environ.get("EVENTS", "0"))  # 1: event counters instead of trus
 L.pipamd_debug_profile(e._h, 2 if EVENTS else 1, None)
 for it in range(2):
     b.load(); b.solve()
-    out = (C.c_uint64 * 32)()
+    out = (C.c_uint64 * 64)()
     L.pipamd_debug_profile(e._h, 2 if EVENTS else 1, out)
     ms = b.last_solve_ms()
     v = np.array(list(out), dtype=np.float64)
     c = b.counters()
     names = ["entry", "exam", "integrer", "A prow+guard", "A column", "A worklist+det", "B rest", "C flags", "epilogue", "B load wait", "B multipliers", "B update_row", "B store+publish", "entry tables", "entry pass", "entry sort"]
     print(f"launches {e.last_solve_launches()} kernel {ms:.2f} ms pivots {c['pivots']} rows_rewritten {c['rows_rewritten']} cuts {c['cuts']}")
-    cn = ["rows updated", "pivot != 1", "gcd(pivot, foo) != 1", "g0 != 1", "row divided (g != 1)", "den != 1", "pivot >= 2^16", "gcd_u64 calls", "gcd_u64 iterations", "gcd_u32 calls", "gcd_u32 iterations", "cquo 32-bit divisions", "cquo 64-bit divisions", "refinement rounds", "refinement rounds (64-bit mod)"]
-    for n, x in zip(cn, v[16:] if EVENTS else []):
+    cn = ["rows updated", "pivot != 1", "gcd(pivot, foo) != 1", "g0 != 1", "row divided (g != 1)", "den != 1", "pivot >= 2^16", "gcd_u64 calls", "gcd_u64 iterations", "gcd_u32 calls", "gcd_u32 iterations", "cquo 32-bit divisions", "cquo 64-bit divisions", "refinement rounds", "refinement rounds (64-bit mod)", "choose: ratio-loop passes", "choose: rows loaded", "choose: rows considered", "choose: 64-row blocks", "choose: single candidate"]
+    for n, x in zip(cn, v[16:63] if EVENTS else []):
         print(f"  {n:24s} {x / c['pivots']:7.3f} per pivot")
     v = v[:16]
     for n, x in zip(names, v):
