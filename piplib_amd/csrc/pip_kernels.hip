@@ -58,6 +58,14 @@ typedef unsigned char u8;
 #ifndef PIP_MINWAVES
 #define PIP_MINWAVES 1
 #endif
+// Diagnostic builds only (tools/pmc_dup.sh): -DPIP_DUP=n executes one idempotent piece of the
+// pivot loop twice, so that the difference of the SQ_INSTS_* counters against the normal build
+// is that piece's dynamic instruction count.  0 = off (every shipped/timed build).
+#ifndef PIP_DUP
+#define PIP_DUP 0
+#endif
+#define PIP_DUP_REPS(n) ((PIP_DUP == (n)) ? 2 : 1)
+#define PIP_OPAQUE_MEM() asm volatile("" ::: "memory")
 #define BIG_I 0x7fffffff
 #define NOROW 0xffff
 
@@ -1143,10 +1151,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       } else {
         // the flags exam_coef would assign were computed with the post-pivot hints; they are
         // applied up to the first row it proves negative (traiter.c:154-156)
-        pivi = sc.pivi2;
-        for (int s = tid; s < ni; s += NT)
-          if (S.fl[s] == PIPAMD_F_UNKNOWN && (int)S.srow[s] <= pivi) S.fl[s] = S.nf[s];
-        bsync<NW>();
+        for (int rep11 = 0; rep11 < PIP_DUP_REPS(11); rep11++) {
+          if (PIP_DUP == 11) PIP_OPAQUE_MEM();
+          pivi = sc.pivi2;
+          for (int s = tid; s < ni; s += NT)
+            if (S.fl[s] == PIPAMD_F_UNKNOWN && (int)S.srow[s] <= pivi) S.fl[s] = S.nf[s];
+          bsync<NW>();
+        }
       }
       PROF(1);
       if (pivi == BIG_I) {
@@ -1424,10 +1435,31 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
               }
             row_store<T, NCH>(r, row, ncolp, lane);
             row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
+            if (PIP_DUP == 9) {  // the recycled row once more
+              PIP_OPAQUE_MEM();
+#pragma unroll
+              for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int h = 0; h < ET<T>::CPL; h++) {
+                  int j = colof<T>(c, lane, h);
+                  r.v[c][h] = (j == pivj) ? dpiv : wneg(S.prow[j]);
+                }
+              row_store<T, NCH>(r, row, ncolp, lane);
+              row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
+            }
           } else {
             T nd;
+            if (PIP_DUP == 12) {  // the row's load and pivot-column read once more
+              PIP_OPAQUE_MEM();
+              row_load<T, NCH>(r, vals + (size_t)S.work[w] * W, ncolp, lane);
+            }
             // multipliers from the row's own pivot-column entry (traiter.c:470-476)
             T foo = row_entry<T, NCH>(r, pc, ph, pl);
+            if (PIP_DUP == 12) {
+              asm volatile("" : "+v"(r.v[0][0]));
+              foo ^= row_entry<T, NCH>(r, pc, ph, pl);
+              foo = row_entry<T, NCH>(r, pc, ph, pl);
+            }
             PROF(9);
             if (foo == 0 && (S.sig[s] & SIG_RED)) {
               // only reached with PIPAMD_T_NOSKIP: multipliers (1, 0) and gcd 1, the reference
@@ -1480,7 +1512,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       S.uflag[pivi] = PIPAMD_F_UNIT | PIPAMD_F_ZERO;
       S.urow[pivj] = (u16)pivi;
     }
+    for (int rep10 = 0; rep10 < PIP_DUP_REPS(10); rep10++)
     for (int s = tid; s < ni; s += NT) {
+      if (PIP_DUP == 10) PIP_OPAQUE_MEM();
       int ff, k;
       if (s == pslot) {  // traiter.c:503-513: its slot now holds the row that replaces ku's unit row
         k = ku;
