@@ -1,0 +1,47 @@
+"""Manual GPU fuzz (not a test): random parametric problems through the host decision tree
+(lock-step forest and per-problem trees) against the CPU oracle: same sol_edit text, same pivot
+count, same abort verdict.  Usage: python tools/fuzz_param.py [seconds] [seed]"""
+import os, sys, time, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from piplib_amd import engine as eng, synth
+import pipbatch as pb
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+e = eng.Engine(0)
+t0 = time.time(); ncase = nprob = npiv = nsplit = 0
+while time.time() - t0 < budget:
+    nvar = int(rng.integers(2, 12)); nparm = int(rng.integers(0, 5)); ni = int(rng.integers(2, 14))
+    nc = int(rng.integers(0, 4)) if nparm else 0
+    nq = int(rng.integers(0, 2)); deepest = bool(nq and rng.random() < 0.25)
+    seed = int(rng.integers(1, 1 << 30))
+    cmax = int(rng.choice([2, 4, 9])); bmax = int(rng.choice([5, 12, 40]))
+    tag = f"nvar={nvar} nparm={nparm} ni={ni} nc={nc} nq={nq} deepest={deepest} seed={seed} cmax={cmax} bmax={bmax}"
+    probs, want = [], []
+    for p in synth.random_problems(seed, 24, nvar, nparm, ni, nc, nq, cmax=cmax, bmax=bmax):
+        try:  # some random parametric problems make the reference itself cut forever
+            r = pb.run_batch(pb.ORACLEPIP, [p], pb.F_DEEPEST if deepest else 0, timeout=2).results[0]
+        except subprocess.TimeoutExpired:
+            continue
+        if r.pivots <= 2000:
+            probs.append(p); want.append(r)
+    if not probs:
+        continue
+    for mode in ("lockstep", "threads"):
+        got = eng.solve_tableaux(e, probs, simplify=True, deepest_cut=deepest, lockstep=(mode == "lockstep"), nthreads=4)
+        for i, ((text, rc, st, piv), r) in enumerate(zip(got, want)):
+            if r.status == pb.ST_ABORT:
+                bad = rc == 0
+            else:
+                w = "void" if r.status == pb.ST_VOID else pb.squash(r.text)
+                bad = rc != 0 or pb.squash(text or "") != w or piv != r.pivots
+            if bad:
+                print(f"MISMATCH ({mode}) problem {i}:", tag, "rc", rc, "status", st, "pivots", piv, r.pivots, flush=True)
+                print(" got ", (text or "")[:300]); print(" want", r.text[:300])
+                sys.exit(1)
+    ncase += 1; nprob += len(probs); npiv += sum(r.pivots for r in want); nsplit += sum("if" in r.text for r in want)
+    if ncase % 10 == 0:
+        print(f"{ncase} cases, {nprob} problems ({nsplit} with splits), {npiv} pivots, {time.time()-t0:.0f} s", flush=True)
+print(f"OK: {ncase} cases, {nprob} problems ({nsplit} with splits), {npiv} pivots checked")
