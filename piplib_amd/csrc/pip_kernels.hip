@@ -1296,6 +1296,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     if (wave == 0) {
       RowRegs<T, NCH> pr;
       row_load<T, NCH>(pr, vals + (size_t)pslot * W, ncolp, lane);
+      // (while the pivot row is on its way) largest magnitude class of any row, for the guard below
+      int mc = 0;
+      for (int s = lane; s < ni; s += 64)
+        if (S.rcls[s] > mc) mc = S.rcls[s];
+      mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
       typename ET<T>::U amax = 0;
 #pragma unroll
       for (int c = 0; c < NCH; c++)
@@ -1308,10 +1313,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         }
       // exactness guard of the tournament: (max candidate a_j) * (max |entry|) < 2^62
       const int abits = cls_bits<T>(cls_of<T>(amax));
-      int mc = 0;
-      for (int s = lane; s < ni; s += 64)
-        if (S.rcls[s] > mc) mc = S.rcls[s];
-      mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
       const bool safe = abits + cls_bits<T>(mc) <= ET<T>::BITS - 2;
       PROF(3);
       int pj = safe ? choose_column<T, NCH>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc)
@@ -1359,6 +1360,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       status = PIPAMD_ST_RANGE;
       break;
     }
+    // The first rows of the work list are requested from HBM before the scalar bookkeeping
+    // below, so that their latency overlaps it (up to PF rows per wave in flight: a wave owns
+    // only a few rows per pivot on sparse tableaux).
+    constexpr int PF = NCH <= 2 ? 4 : (NCH == 4 ? 2 : 1);
+    const int nwork = sc.nwork;
+    RowRegs<T, NCH> rr[PF];
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+      const int w = wave + q * NW;
+      if (w < nwork && S.work[w] != pslot) row_load<T, NCH>(rr[q], vals + (size_t)S.work[w] * W, ncolp, lane);
+    }
     // pivot scalars + determinant bookkeeping, traiter.c:394-446 (uniform, every thread)
     const T pivot = uni64(S.prow[pivj]);
     const T dpiv = uni64(S.den[pslot]);
@@ -1405,17 +1417,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     PROF(5);
     // ---------------- B: eliminate the pivot column (all waves) ----------------
     {
-      const int nwork = sc.nwork;
       nupd += nwork - 1;
-      // up to PF rows per wave are loaded before the first one is reduced, so their HBM
-      // latencies overlap (a wave owns only a few rows per pivot on sparse tableaux)
-      constexpr int PF = NCH <= 2 ? 4 : (NCH == 4 ? 2 : 1);
       for (int w0 = wave; w0 < nwork; w0 += NW * PF) {
-        RowRegs<T, NCH> rr[PF];
+        if (w0 != wave) {  // the first PF rows are already on their way
 #pragma unroll
-        for (int q = 0; q < PF; q++) {
-          const int w = w0 + q * NW;
-          if (w < nwork && S.work[w] != pslot) row_load<T, NCH>(rr[q], vals + (size_t)S.work[w] * W, ncolp, lane);
+          for (int q = 0; q < PF; q++) {
+            const int w = w0 + q * NW;
+            if (w < nwork && S.work[w] != pslot) row_load<T, NCH>(rr[q], vals + (size_t)S.work[w] * W, ncolp, lane);
+          }
         }
 #pragma unroll
         for (int q = 0; q < PF; q++) {
