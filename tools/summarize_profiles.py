@@ -7,9 +7,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
 def one(pat):
-    f = glob.glob(os.path.join(G, pat))
-    assert len(f) == 1, (pat, f)
-    return f[0]
+    f = sorted(glob.glob(os.path.join(G, pat)), key=os.path.getmtime)  # merged runs accumulate: newest wins
+    assert f, pat
+    return f[-1]
 
 
 shutil.copy(one("prof_np/*/*kernel_stats.csv"), os.path.join(P, f"{tag}_kernel_stats.csv"))
