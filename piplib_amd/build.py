@@ -29,6 +29,9 @@ def build(force=False, verbose=True, profile=False):
     if os.environ.get("PIP_MINWAVES"):  # tuning experiments only
         return _compile(os.path.join(HERE, "libpipamd_mw%s.so" % os.environ["PIP_MINWAVES"]),
                         ["-DPIP_MINWAVES=" + os.environ["PIP_MINWAVES"]], verbose)
+    if os.environ.get("PIP_VARIANT"):  # tuning experiments: PIP_VARIANT=name PIP_DEFS="-DPIP_PF=2 ..."
+        return _compile(os.path.join(HERE, "libpipamd_%s.so" % os.environ["PIP_VARIANT"]),
+                        os.environ.get("PIP_DEFS", "").split(), verbose)
     if os.environ.get("PIP_DUP"):  # instruction-count experiments only (tools/pmc_dup.sh)
         return _compile(os.path.join(HERE, "libpipamd_dup%s.so" % os.environ["PIP_DUP"]),
                         ["-DPIP_DUP=" + os.environ["PIP_DUP"]], verbose)

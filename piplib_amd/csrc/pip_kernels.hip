@@ -1363,7 +1363,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     // The first rows of the work list are requested from HBM before the scalar bookkeeping
     // below, so that their latency overlaps it (up to PF rows per wave in flight: a wave owns
     // only a few rows per pivot on sparse tableaux).
-    constexpr int PF = NCH <= 2 ? 4 : (NCH == 4 ? 2 : 1);
+#ifndef PIP_PF
+#define PIP_PF 2
+#endif
+    constexpr int PF = NCH <= 2 ? PIP_PF : (NCH == 4 ? 2 : 1);
     const int nwork = sc.nwork;
     RowRegs<T, NCH> rr[PF];
 #pragma unroll
