@@ -332,6 +332,8 @@ __device__ __forceinline__ void bsync() {
 #define SIG_PIV(s) (((s) >> 6) & 3)
 #define SIG_RED 256  // gcd(row, denominator) is known to be 1 (the row needs no reduction)
 #define UNITBIT 0x8000
+#define UNITZERO 0x4000  // a unit row flagged Unit|Zero (it was a pivot row, traiter.c:514); else just Unit
+#define UNITCOL(rf) ((rf)&0x3ff)
 
 // Optional phase profile (diagnostic build only: -DPIP_PROFILE; never shipped/timed).
 #ifdef PIP_PROFILE
@@ -397,12 +399,11 @@ struct Shared {
   u16 *sig;     // [S]  sign summary
   u16 *srow;    // [S]  slot -> logical row
   u16 *work;    // [S]  slots the current pivot rewrites
-  u16 *ref;     // [L]  logical row -> slot, or UNITBIT | column for a unit row
+  u16 *ref;     // [L]  logical row -> slot, or UNITBIT | (UNITZERO) | column for a unit row
   u16 *urow;    // [WP] unknown column -> logical row of its unit row
   u8 *fl;       // [S]  flag of the row in slot s (Plus/Minus/Zero/Critic/Unknown)
   u8 *nf;       // [S]  flag exam_coef would give an Unknown row
   u8 *rcls;     // [S]  magnitude class of the row's largest entry (see CLS_BITS)
-  u8 *uflag;    // [L]  flag of a unit row (Unit or Unit|Zero)
 };
 
 struct Scalars {
@@ -807,8 +808,8 @@ __device__ int choose_column_slow(const Shared<T> &S, const T *vals, int W, int 
         const int rf = S.ref[k];
         T vj, vb;
         if (rf & UNITBIT) {  // valeur(): the unit row's denominator (1) in its own column
-          vj = ((rf & ~UNITBIT) == j) ? 1 : 0;
-          vb = ((rf & ~UNITBIT) == pivj) ? 1 : 0;
+          vj = (UNITCOL(rf) == j) ? 1 : 0;
+          vb = (UNITCOL(rf) == pivj) ? 1 : 0;
         } else {
           vj = vals[(size_t)rf * W + j];
           vb = vals[(size_t)rf * W + pivj];
@@ -987,7 +988,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     S.fl = (u8 *)p;      p += Smax;
     S.nf = (u8 *)p;      p += Smax;
     S.rcls = (u8 *)p;    p += Smax;
-    S.uflag = (u8 *)p;
   }
 
   const int nvar = J->nvar, nparm = J->nparm, bigparm = J->bigparm;
@@ -1031,12 +1031,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   for (int i = tid; i < nligne; i += NT) {
     const int f = g_flag[i], rf = g_ref[i];
     if (f & PIPAMD_F_UNIT) {
-      S.ref[i] = (u16)(UNITBIT | rf);
-      S.uflag[i] = (u8)f;
+      S.ref[i] = (u16)(UNITBIT | ((f & PIPAMD_F_ZERO) ? UNITZERO : 0) | rf);
       S.urow[rf] = (u16)i;
     } else {
       S.ref[i] = (u16)rf;
-      S.uflag[i] = 0;
       S.srow[rf] = (u16)i;
       S.fl[rf] = (u8)f;
       S.den[rf] = g_den[i];
@@ -1269,7 +1267,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
               S.nf[ni] = 0;
               S.den[ni] = D;
               S.ref[nligne] = (u16)ni;
-              S.uflag[nligne] = 0;
               S.srow[ni] = (u16)nligne;
             }
           }
@@ -1520,8 +1517,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     }
     // ---------------- C: swap roles, refresh the sign hints, next chercher ------
     if (tid == 0) {  // traiter.c:514-516: the pivot row becomes the unit row of column pivj
-      S.ref[pivi] = (u16)(UNITBIT | pivj);
-      S.uflag[pivi] = PIPAMD_F_UNIT | PIPAMD_F_ZERO;
+      S.ref[pivi] = (u16)(UNITBIT | UNITZERO | pivj);
       S.urow[pivj] = (u16)pivi;
     }
     for (int rep10 = 0; rep10 < PIP_DUP_REPS(10); rep10++)
@@ -1534,7 +1530,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         S.den[s] = pivot;
         S.srow[s] = (u16)ku;
         S.ref[ku] = (u16)s;
-        S.uflag[ku] = 0;
       } else {
         k = S.srow[s];
         ff = S.fl[s];
@@ -1568,8 +1563,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     const int rf = S.ref[i];
     if (rf & UNITBIT) {
       g_den[i] = 1;
-      g_flag[i] = S.uflag[i];
-      g_ref[i] = rf & ~UNITBIT;
+      g_flag[i] = PIPAMD_F_UNIT | ((rf & UNITZERO) ? PIPAMD_F_ZERO : 0);
+      g_ref[i] = UNITCOL(rf);
     } else {
       g_den[i] = S.den[rf];
       g_flag[i] = S.fl[rf];
@@ -1893,7 +1888,7 @@ extern "C" size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax, int ebits
   const size_t WP = (size_t)wp_of(Wmax, ebits);
   const size_t NM = WP / 64, EB = ebits == 128 ? 16 : 8;
   size_t shm = EB * 2 * (size_t)Smax + prow_bytes(EB * WP, Smax) + sizeof(u64) * (size_t)Smax * NM +
-               sizeof(u16) * (3 * (size_t)Smax + (size_t)Lmax + WP) + 3 * (size_t)Smax + (size_t)Lmax;
+               sizeof(u16) * (3 * (size_t)Smax + (size_t)Lmax + WP) + 3 * (size_t)Smax;
   return (shm + 15) & ~(size_t)15;
 }
 
