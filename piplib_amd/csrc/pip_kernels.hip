@@ -408,7 +408,7 @@ struct Shared {
 
 struct Scalars {
   int pivi, pivi2, pivj, tmp, tmp2, aux;
-  int flagor, nwork, bad;
+  int flagor, nwork, bad, ovf;
   u64 smaxbits;
 };
 
@@ -955,6 +955,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
                                                          int Wmax, int iter_limit, u64 *prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Scalars sc;
+  // Determinant limbs (traiter.c:413-446).  64-bit entries: scalar registers.  128-bit entries:
+  // eight limbs of four registers each do not fit, and a dynamically indexed local array would
+  // live in scratch memory -- they are kept in LDS and updated by wave 0 in phase A.
+  constexpr bool DET_LDS = sizeof(T) == 16;
+  __shared__ T sdet[DET_LDS ? PIPAMD_MAXDET : 1];
+  __shared__ int sldet;
   const int jb = blockIdx.x;
   if (jb >= njobs) return;
   PipJob *J = &jobs[jb];
@@ -1004,12 +1010,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   int nligne = nvar + ni;
   int npiv = J->npiv, ncut = J->ncut, nupd = J->nupd;
   int ldet = J->ldet;
-  T det[PIPAMD_MAXDET];
-  for (int i = 0; i < PIPAMD_MAXDET; i++) {
-    if constexpr (ET<T>::EW == 1)
-      det[i] = J->det[i];
-    else
-      det[i] = (T)(((u128)(u64)J->det[2 * i + 1] << 64) | (u64)J->det[2 * i]);
+  T det[DET_LDS ? 1 : PIPAMD_MAXDET];
+  if constexpr (!DET_LDS) {
+    for (int i = 0; i < PIPAMD_MAXDET; i++) det[i] = J->det[i];
   }
   if (ni > Smax || nligne > Lmax) return;  // this launch's LDS image is too small: stay RUN for a larger one
   // saved LDS state of a paused job (bitmaps, sign summaries, magnitude classes)
@@ -1019,7 +1022,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
 
   // ---- stage the row tables in LDS -------------------------------------
   for (int j = tid; j < WP; j += NT) S.urow[j] = NOROW;  // prow is written whole by every phase A
+  if constexpr (DET_LDS) {
+    if (tid < PIPAMD_MAXDET) sdet[tid] = (T)(((u128)(u64)J->det[2 * tid + 1] << 64) | (u64)J->det[2 * tid]);
+    if (tid == 0) sldet = ldet;
+  }
   if (tid == 0) {
+    sc.ovf = 0;
     sc.aux = 0;
     sc.smaxbits = 0;
     sc.pivi = BIG_I;
@@ -1341,6 +1349,49 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         }
         if (lane == 0) sc.nwork = base;
       }
+      if constexpr (DET_LDS) {
+        if (pj >= 0) {  // determinant bookkeeping on the LDS limbs (wave-uniform; lane 0 writes)
+          const T pivot = uni64(S.prow[pj]), dpiv = uni64(S.den[pslot]);
+          T d = gcd_i64(pivot, dpiv);
+          T ppivot = pivot, dppiv = dpiv;
+          if (d != 1) {
+            ppivot = cquo(pivot, d);
+            dppiv = cquo(dpiv, d);
+          }
+          int ld = __builtin_amdgcn_readfirstlane(sldet);
+          for (int i = 0; i < ld && dppiv != 1; i++) {
+            T x = uni64(sdet[i]);
+            d = gcd_i64(x, dppiv);
+            if (d != 1) {
+              x = cquo(x, d);
+              dppiv = cquo(dppiv, d);
+              if (lane == 0) sdet[i] = x;
+            }
+          }
+          bool ovf = dppiv != 1;
+          if (!ovf) {
+            const int lpp = log2_64(ppivot);
+            int i = 0;
+            for (; i < ld; i++) {
+              const T x = uni64(sdet[i]);
+              if (log2_64(x) + lpp < ET<T>::BITS) {
+                if (ppivot != 1 && lane == 0) sdet[i] = wmul(x, ppivot);
+                break;
+              }
+            }
+            if (i >= ld) {
+              ld++;
+              if (ld >= PIPAMD_MAXDET)
+                ovf = true;
+              else if (lane == 0) {
+                sdet[i] = ppivot;
+                sldet = ld;
+              }
+            }
+          }
+          if (ovf && lane == 0) sc.ovf = 1;
+        }
+      }
       if (lane == 0) sc.pivj = pj;
     }
     bsync<NW>();
@@ -1374,7 +1425,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     // pivot scalars + determinant bookkeeping, traiter.c:394-446 (uniform, every thread)
     const T pivot = uni64(S.prow[pivj]);
     const T dpiv = uni64(S.den[pslot]);
-    {
+    if constexpr (DET_LDS) {
+      if (sc.ovf) {  // "Integer overflow", traiter.c:424,442
+        status = PIPAMD_ST_OVERFLOW;
+        break;
+      }
+    } else {
       T d = gcd_i64(pivot, dpiv);
       T ppivot = pivot, dppiv = dpiv;
       if (d != 1) {
@@ -1610,14 +1666,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     J->npiv = npiv;
     J->ncut = ncut;
     J->nupd = nupd;
-    J->ldet = ldet;
-    for (int i = 0; i < PIPAMD_MAXDET; i++) {
-      if constexpr (ET<T>::EW == 1)
-        J->det[i] = det[i];
-      else {
-        J->det[2 * i] = (i64)(u64)(u128)det[i];
-        J->det[2 * i + 1] = (i64)(u64)((u128)det[i] >> 64);
+    if constexpr (DET_LDS) {
+      J->ldet = sldet;
+      for (int i = 0; i < PIPAMD_MAXDET; i++) {
+        J->det[2 * i] = (i64)(u64)(u128)sdet[i];
+        J->det[2 * i + 1] = (i64)(u64)((u128)sdet[i] >> 64);
       }
+    } else {
+      J->ldet = ldet;
+      for (int i = 0; i < PIPAMD_MAXDET; i++) J->det[i] = det[i];
     }
     J->tflags = tflags;
     J->state_nch = NCH;
