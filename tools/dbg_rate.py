@@ -9,6 +9,8 @@ def rate(rows, nvar, nq, depth=3, steps=9, **kw):
     lanes = []
     for _ in range(depth):
         e = eng.Engine(0)
+        if os.environ.get("WAVES"):
+            e.set_waves_per_job(int(os.environ["WAVES"]))
         lanes.append((e, eng.Batch(e, rows_d, nvar, 0, tflags=eng.T_INT if nq else 0, **kw), torch.cuda.Stream(dev)))
     def work(i, n):
         with torch.cuda.stream(lanes[i][2]):
