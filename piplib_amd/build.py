@@ -24,6 +24,8 @@ def needs_build():
 def build(force=False, verbose=True, profile=False):
     """profile=True builds the diagnostic variant libpipamd_prof.so (-DPIP_PROFILE: per-phase
     cycle stamps in the kernel; never used for timing or shipped results)."""
+    if profile == "events":
+        return _compile(os.path.join(HERE, "libpipamd_prof_events.so"), ["-DPIP_PROFILE", "-DPIP_PROFILE_EVENTS"], verbose)
     if profile:
         return _compile(os.path.join(HERE, "libpipamd_prof.so"), ["-DPIP_PROFILE"], verbose)
     if os.environ.get("PIP_MINWAVES"):  # tuning experiments only
@@ -53,4 +55,5 @@ def _compile(out, extra, verbose):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, profile="--profile" in sys.argv)
+    build(force="--force" in sys.argv,
+          profile="events" if "--profile-events" in sys.argv else ("--profile" in sys.argv))

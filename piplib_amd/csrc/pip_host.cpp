@@ -249,10 +249,6 @@ extern "C" int pipamd_debug_profile(pipamd_engine *e, int enable, uint64_t *host
     HIPCHK(hipMemcpy(host_out10, e->d_prof, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(e->d_prof, 0, 64 * sizeof(unsigned long long)));
   }
-  if (e->d_prof) {  // slot 63 switches the event counters on (enable == 2): their atomics distort the cycle stamps
-    const unsigned long long ev = enable == 2 ? 1 : 0;
-    HIPCHK(hipMemcpy(e->d_prof + 63, &ev, sizeof ev, hipMemcpyHostToDevice));
-  }
   return PIPAMD_OK;
 }
 

@@ -69,8 +69,8 @@ typedef unsigned char u8;
 #define BIG_I 0x7fffffff
 #define NOROW 0xffff
 
-#ifdef PIP_PROFILE
-__device__ unsigned long long *pf_buf;  // diagnostic build: event counters behind the phase stamps
+#ifdef PIP_PROFILE_EVENTS  // second diagnostic build: event counters (their atomics distort the cycle stamps)
+__device__ unsigned long long *pf_buf;
 #define CNT(i, n)                                                                          \
   do {                                                                                     \
     if ((threadIdx.x & 63) == 0 && pf_buf) atomicAdd(&pf_buf[16 + (i)], (unsigned long long)(n)); \
@@ -344,10 +344,14 @@ __device__ __forceinline__ void bsync() {
     pf_acc[i] += pf_n - pf_t;                  \
     pf_t = pf_n;                               \
   } while (0)
+#ifdef PIP_PROFILE_EVENTS
 #define PROF_CNT(buf, i, c)                                                     \
   do {                                                                          \
     if ((threadIdx.x & 63) == 0 && buf && (c)) atomicAdd(&buf[16 + (i)], 1ull); \
   } while (0)
+#else
+#define PROF_CNT(buf, i, c)
+#endif
 #define PROF_FLUSH(buf)                                                \
   do {                                                                 \
     if (threadIdx.x == 0 && buf)                                       \
@@ -672,7 +676,9 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
       count += __popcll(cm[ET<T>::CPL * c + h]);
     }
   if (count == 0) return -1;
+  CNT(19, count == 1);
   for (int k0 = 0; k0 < nligne && count > 1; k0 += 64) {
+    CNT(18, 1);
     const int k = k0 + lane;
     bool rel = false;
     if (k < nligne && k != pivi) {
@@ -689,6 +695,7 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
     while (relmask && count > 1) {
       const int kk = k0 + __ffsll((long long)relmask) - 1;
       relmask &= relmask - 1;
+      CNT(17, 1);
       const int sl = S.ref[kk];
       // unit rows above kk knock out their own column
       int nel = 0;
@@ -717,7 +724,9 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
       // real row kk: keep the minimal ratios
       RowRegs<T, NCH> n;
       row_load<T, NCH>(n, vals + (size_t)sl * W, ncolp, lane);
+      CNT(16, 1);
       for (;;) {
+        CNT(15, 1);
         // reference column b = first remaining candidate
         T ab = 0, nb = 0;
         bool got = false;
@@ -971,8 +980,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   constexpr int NM = NCH * ET<T>::CPL;
   (void)Wmax;
   PROF_DECL;
-#ifdef PIP_PROFILE
-  if (threadIdx.x == 0) pf_buf = (prof && prof[31]) ? prof : nullptr;
+#ifdef PIP_PROFILE_EVENTS
+  if (threadIdx.x == 0) pf_buf = prof;
 #endif
 
   Shared<T> S;

@@ -3,7 +3,8 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from piplib_amd import engine as eng, synth
-eng.LIB_PATH = os.path.join(eng.HERE, "libpipamd_prof.so")
+EVENTS = int(os.environ.get("EVENTS", "0"))  # 1: event counters (python -m piplib_amd.build --profile-events)
+eng.LIB_PATH = os.path.join(eng.HERE, "libpipamd_prof_events.so" if EVENTS else "libpipamd_prof.so")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 EBITS = int(os.environ.get("EBITS", "64"))
 NVAR, NI = (int(x) for x in os.environ.get("SHAPE", "127,64").split(","))
@@ -14,12 +15,11 @@ if len(sys.argv) > 3: e.set_round_pivots(int(sys.argv[3]))
 L = eng.lib()
 L.pipamd_debug_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 b = eng.Batch(e, rows, NVAR, 0, tflags=eng.T_INT, entier_bits=EBITS)
-EVENTS = int(os.environ.get("EVENTS", "0"))  # 1: event counters instead of trustworthy cycle stamps
-L.pipamd_debug_profile(e._h, 2 if EVENTS else 1, None)
+L.pipamd_debug_profile(e._h, 1, None)
 for it in range(2):
     b.load(); b.solve()
     out = (C.c_uint64 * 64)()
-    L.pipamd_debug_profile(e._h, 2 if EVENTS else 1, out)
+    L.pipamd_debug_profile(e._h, 1, out)
     ms = b.last_solve_ms()
     v = np.array(list(out), dtype=np.float64)
     c = b.counters()
