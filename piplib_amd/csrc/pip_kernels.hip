@@ -1408,7 +1408,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       sc.pivi = BIG_I;
       sc.pivi2 = BIG_I;
     }
-    const int pivj = sc.pivj;
+    // everything phase A left in LDS for this point is read in one go (one wait instead of a
+    // chain of round trips)
+    const int pivj = sc.pivj, nwork = sc.nwork;
+    const int wq0 = S.work[wave], wq1 = S.work[wave + NW < Smax ? wave + NW : 0];
+    const T dpiv_v = S.den[pslot];
+    const int psig_v = S.sig[pslot];
     if (pivj == -1) {  // traiter.c:782-785
       status = PIPAMD_ST_NIL;
       break;
@@ -1424,16 +1429,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
 #define PIP_PF 2
 #endif
     constexpr int PF = NCH <= 2 ? PIP_PF : (NCH == 4 ? 2 : 1);
-    const int nwork = sc.nwork;
     RowRegs<T, NCH> rr[PF];
 #pragma unroll
     for (int q = 0; q < PF; q++) {
       const int w = wave + q * NW;
-      if (w < nwork && S.work[w] != pslot) row_load<T, NCH>(rr[q], vals + (size_t)S.work[w] * W, ncolp, lane);
+      const int sw = q == 0 ? wq0 : (q == 1 ? wq1 : (int)S.work[w < nwork ? w : 0]);
+      if (w < nwork && sw != pslot) row_load<T, NCH>(rr[q], vals + (size_t)sw * W, ncolp, lane);
     }
     // pivot scalars + determinant bookkeeping, traiter.c:394-446 (uniform, every thread)
     const T pivot = uni64(S.prow[pivj]);
-    const T dpiv = uni64(S.den[pslot]);
+    const T dpiv = uni64(dpiv_v);
     if constexpr (DET_LDS) {
       if (sc.ovf) {  // "Integer overflow", traiter.c:424,442
         status = PIPAMD_ST_OVERFLOW;
@@ -1477,7 +1482,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       }
     }
     const int ku = S.urow[pivj];  // unit row of the entering column
-    const int pred = S.sig[pslot] & SIG_RED;
+    const int pred = psig_v & SIG_RED;
     const int pc = pivj / (64 * ET<T>::CPL), ph = pivj % ET<T>::CPL, pl = (pivj % (64 * ET<T>::CPL)) / ET<T>::CPL;
     PROF(5);
     // ---------------- B: eliminate the pivot column (all waves) ----------------
