@@ -558,6 +558,29 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
   }
   if (g == 1) return true;
   if (g == 0) return false;  // the reference would divide by zero here
+  if (small) {
+    // every |z| and g fit 32 bits: the exact quotients do too, so a 32-bit odd inverse (four
+    // Newton steps of single multiplies) replaces the 64-bit one
+    const unsigned g32 = (unsigned)g;
+    const int s = __builtin_ctz(g32);
+    const unsigned m = g32 >> s;
+    unsigned inv = m;  // 3 correct bits, doubled by every step
+    inv *= 2u - m * inv;
+    inv *= 2u - m * inv;
+    inv *= 2u - m * inv;
+    inv *= 2u - m * inv;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+      for (int h = 0; h < ET<T>::CPL; h++) {
+        const T z = r.v[c][h];
+        const unsigned q = ((unsigned)uabs64(z) >> s) * inv;
+        r.v[c][h] = z < 0 ? wneg((T)q) : (T)q;
+      }
+    const unsigned qd = ((unsigned)uabs64(g0) >> s) * inv;
+    newden = g0 < 0 ? wneg((T)qd) : (T)qd;
+    return true;
+  }
   int s = ctzU(g);
   U inv = inv_odd64(g >> s);
 #pragma unroll
