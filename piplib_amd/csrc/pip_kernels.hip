@@ -300,6 +300,26 @@ __device__ __forceinline__ i128 uni64(i128 v) {
   u64 lo = (u64)uni64((i64)(u64)(u128)v), hi = (u64)uni64((i64)(u64)((u128)v >> 64));
   return (i128)(((u128)hi << 64) | lo);
 }
+// a / d for d = a positive gcd that divides a: when both fit 32 bits, shift + 32-bit odd inverse
+// (four single multiplies) instead of a division; two quotients by the same d share the inverse.
+template <class T>
+__device__ __forceinline__ T exact_quo(T a, T d) {
+  const auto ua = uabs64(a);
+  if (((ua | (decltype(ua))d) >> 32) == 0) {
+    unsigned m = (unsigned)d;
+    const int sh = __builtin_ctz(m);
+    m >>= sh;
+    unsigned inv = m;
+    inv *= 2u - m * inv;
+    inv *= 2u - m * inv;
+    inv *= 2u - m * inv;
+    inv *= 2u - m * inv;
+    const unsigned q = ((unsigned)ua >> sh) * inv;
+    return a < 0 ? wneg((T)q) : (T)q;
+  }
+  return cquo(a, d);
+}
+
 __device__ __forceinline__ u128 umod_small(u128 a, u128 g, bool small32) {
   if (small32) return (u128)((unsigned)a % (unsigned)g);
   return umod128(a, g);
@@ -1471,15 +1491,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       T d = gcd_i64(pivot, dpiv);
       T ppivot = pivot, dppiv = dpiv;
       if (d != 1) {
-        ppivot = cquo(pivot, d);
-        dppiv = cquo(dpiv, d);
+        ppivot = exact_quo(pivot, d);
+        dppiv = exact_quo(dpiv, d);
       }
       // once dppiv is 1 the remaining limbs would be divided by gcd(limb, 1) = 1
       for (int i = 0; i < ldet && dppiv != 1; i++) {
         d = gcd_i64(det[i], dppiv);
         if (d != 1) {
-          det[i] = cquo(det[i], d);
-          dppiv = cquo(dppiv, d);
+          det[i] = exact_quo(det[i], d);
+          dppiv = exact_quo(dppiv, d);
         }
       }
       bool ovf = dppiv != 1;
@@ -1577,8 +1597,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             if (pivot != 1) {
               d = gcd_i64(pivot, foo);
               if (d != 1) {
-                lp = cquo(pivot, d);
-                foo = cquo(foo, d);
+                lp = exact_quo(pivot, d);
+                foo = exact_quo(foo, d);
               }
               g0 = wmul(lp, den_s);
             }
