@@ -480,15 +480,34 @@ __device__ __forceinline__ void row_store(const RowRegs<T, NCH> &r, T *row, int 
   }
 }
 
+// select the register that holds column pivj (uniform c,h) and read it from its owner lane
+template <class T, int NCH>
+__device__ __forceinline__ T row_entry(const RowRegs<T, NCH> &r, int pc, int ph, int pl) {
+  T mine = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int h = 0; h < ET<T>::CPL; h++)
+      if (c == pc && h == ph) mine = r.v[c][h];
+  return readlane64(mine, pl);
+}
+
 // Sign summary, non-zero bitmap and magnitude class of a row held in registers
 // (wave-collective).  Lane 0 publishes them for slot s.
 template <class T, int NCH>
 __device__ __forceinline__ void row_publish(const RowRegs<T, NCH> &r, const Shared<T> &S, int s, int nvar, int ncol,
                                             int bigparm, int pivj, int extra_sig, bool has_parm, int lane) {
-  int cs = 0, bs = 0, ps = 0;
+  int bs = 0;
   bool ppos = false, pneg = false;
   typename ET<T>::U mx = 0;
   u64 nz[NCH * ET<T>::CPL];
+  // the constant term and the entry in the column just pivoted on: read from their owner lanes
+  // into scalars (cheaper than per-lane sign codes and ballots)
+  constexpr int CW = 64 * ET<T>::CPL;
+  const T cz = row_entry<T, NCH>(r, nvar / CW, nvar % ET<T>::CPL, (nvar % CW) / ET<T>::CPL);
+  const int cs = sign_code(cz);
+  int ps = 0;
+  if (pivj >= 0) ps = sign_code(row_entry<T, NCH>(r, pivj / CW, pivj % ET<T>::CPL, (pivj % CW) / ET<T>::CPL));
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
@@ -496,11 +515,6 @@ __device__ __forceinline__ void row_publish(const RowRegs<T, NCH> &r, const Shar
       int j = colof<T>(c, lane, h);
       T z = r.v[c][h];
       mx |= uabs64(z);
-      if (j == nvar) {
-        cs = sign_code(z);
-        S.cst[s] = z;
-      }
-      if (j == pivj) ps = sign_code(z);
       if (has_parm) {
         if (j == bigparm) bs = sign_code(z);
         if (j > nvar && j < ncol) {
@@ -510,9 +524,7 @@ __device__ __forceinline__ void row_publish(const RowRegs<T, NCH> &r, const Shar
       }
       nz[ET<T>::CPL * c + h] = __ballot(z != 0);
     }
-  int sig = extra_sig;
-  sig |= (__ballot(cs == 1) ? 1 : 0) | (__ballot(cs == 2) ? 2 : 0);
-  sig |= (__ballot(ps == 1) ? 64 : 0) | (__ballot(ps == 2) ? 128 : 0);
+  int sig = extra_sig | cs | (ps << 6);
   if (has_parm) {
     sig |= (__ballot(ppos) ? 4 : 0) | (__ballot(pneg) ? 8 : 0);
     sig |= (__ballot(bs == 1) ? 16 : 0) | (__ballot(bs == 2) ? 32 : 0);
@@ -521,6 +533,7 @@ __device__ __forceinline__ void row_publish(const RowRegs<T, NCH> &r, const Shar
   if (lane == 0) {
     S.sig[s] = (u16)sig;
     S.rcls[s] = (u8)cls;
+    S.cst[s] = cz;
 #pragma unroll
     for (int e = 0; e < NCH * ET<T>::CPL; e++) S.nzm[(size_t)s * (NCH * ET<T>::CPL) + e] = nz[e];
   }
@@ -987,18 +1000,6 @@ __device__ void sort_rows(const Shared<T> &S, int nvar, int nligne, double smax)
 __device__ __forceinline__ int trunc_int_x86(double t) {
   if (!(t > -2147483649.0 && t < 2147483648.0)) return (int)0x80000000;
   return (int)t;
-}
-
-// select the register that holds column pivj (uniform c,h) and read it from its owner lane
-template <class T, int NCH>
-__device__ __forceinline__ T row_entry(const RowRegs<T, NCH> &r, int pc, int ph, int pl) {
-  T mine = 0;
-#pragma unroll
-  for (int c = 0; c < NCH; c++)
-#pragma unroll
-    for (int h = 0; h < ET<T>::CPL; h++)
-      if (c == pc && h == ph) mine = r.v[c][h];
-  return readlane64(mine, pl);
 }
 
 // ================================================================ main kernel
