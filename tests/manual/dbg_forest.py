@@ -1,7 +1,7 @@
 """Manual GPU measurement: lock-step Forest vs threaded trees on mid-size parametric problems."""
 import sys, os, time, json
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pipbatch as pb
 from piplib_amd import engine as eng, synth
 cfg = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "forest_good.json")))

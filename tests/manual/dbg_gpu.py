@@ -1,7 +1,7 @@
 """Manual GPU debug driver (not a test): python tests/dbg_gpu.py nvar ni batch nq"""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import pipbatch as pb
 from gpu_common import *

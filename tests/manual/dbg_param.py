@@ -1,7 +1,7 @@
 """Manual GPU debug: random parametric problems one by one with progress output."""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pipbatch as pb
 from piplib_amd import engine as eng, synth
 seed, nvar, nparm, ni, nc, nq, deepest = [int(x) for x in sys.argv[1:8]]

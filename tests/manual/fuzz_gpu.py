@@ -1,8 +1,8 @@
 """Manual GPU fuzz (not a test): random shapes / densities / magnitudes, HIP engine vs the CPU
 oracle, bit-exact (status, pivots, solution); plus skipping off and 128-bit entries against the
-int64 engine.  Usage: python tools/fuzz_gpu.py [seconds] [seed]"""
+int64 engine.  Usage: python tests/manual/fuzz_gpu.py [seconds] [seed]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from piplib_amd import engine as eng, synth

@@ -1,8 +1,8 @@
 """Manual GPU fuzz (not a test): random parametric problems through the host decision tree
 (lock-step forest and per-problem trees) against the CPU oracle: same sol_edit text, same pivot
-count, same abort verdict.  Usage: python tools/fuzz_param.py [seconds] [seed]"""
+count, same abort verdict.  Usage: python tests/manual/fuzz_param.py [seconds] [seed]"""
 import os, sys, time, subprocess
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from piplib_amd import engine as eng, synth
