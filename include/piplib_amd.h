@@ -7,16 +7,15 @@
  *   integrer() (Gomory cut rows)                    reference source/integrer.c:305-534
  *   tab_alloc()/tab_get()/expanser() row store      reference source/tab.c:158-248, traiter.c:55-88
  *
- * Three layers, lowest first:
+ * Two public layers, lowest first:
  *   1. pipamd_batch_*   : a *uniform* batch of tableaux that lives in HBM; one
  *                         workgroup per tableau runs the whole pivot loop on the GPU.
- *   2. pipamd_jobs_*    : heterogeneous "jobs" (any shapes) in one arena; the
- *                         engine advances every job until it is finished or needs a
- *                         host decision (context test / parametric cut).  This is
- *                         what the host-side quast builder (layer 3) drives.
- *   3. pipamd_solve_*   : PipLib's own front-end semantics (maind.c / pip_solve,
+ *   3. pipamd_solve_*, pipamd_pip_solve
+ *                       : PipLib's own front-end semantics (maind.c / pip_solve,
  *                         piplib.c:722-880) with the decision tree on the host and
  *                         every pivot on the GPU.
+ * (Layer 2 -- heterogeneous jobs of any shape in one arena, advanced until each is finished or
+ *  needs a host decision -- is internal: it is what layer 3's quast builder drives.)
  *
  * All device pointers are ordinary HIP device pointers (e.g. torch
  * `tensor.data_ptr()`); `stream` is a hipStream_t passed as void*.
