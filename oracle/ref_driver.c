@@ -175,6 +175,7 @@ static int mode_pip(void) {
   if (bignum > 0) bignum += domain->NbColumns - context->NbColumns;
   solution = pip_solve_dp(domain, context, bignum, options);
   pip_quast_print_dp(stdout, solution, 0);
+  fprintf(stderr, "pivots %lld\n", g_pivots);
   return 0;
 }
 

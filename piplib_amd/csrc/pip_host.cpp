@@ -80,7 +80,8 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
   lay->S = d->ni + d->cap_cuts;
   lay->L = round_even(d->nvar + lay->S);
   lay->W = ebits == 128 ? ncol + d->cap_newparm : round_even(ncol + d->cap_newparm);
-  if (lay->L > PIPAMD_LMAX || lay->S > PIPAMD_SMAX || lay->W > PIPAMD_MAXCOL || lay->S < 1) {
+  if (lay->L > PIPAMD_LMAX || lay->S > PIPAMD_SMAX || lay->W > PIPAMD_MAXCOL || lay->S < 1 ||
+      pipk_advance_lds_bytes((lay->L + 3) & ~3, (lay->S + 3) & ~3, lay->W, ebits) > PIPAMD_LDS_BUDGET) {
     pipamd_set_error("batch shape exceeds engine limits (L=%d<=%d, S=%d<=%d, W=%d<=%d)", lay->L, PIPAMD_LMAX, lay->S,
                      PIPAMD_SMAX, lay->W, PIPAMD_MAXCOL);
     return PIPAMD_E_TOOLARGE;

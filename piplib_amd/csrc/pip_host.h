@@ -26,6 +26,9 @@ void pipamd_set_error(const char *fmt, ...);
 int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t *jobs_bytes);
 
 extern "C" {
+/* bytes of the LDS image a launch over jobs of at most (Lmax, Smax, Wmax) needs; a job only fits
+ * the engine if this stays within the 159 KiB a workgroup can get (PIPAMD_LDS_BUDGET) */
+size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax, int ebits);
 hipError_t pipk_launch_advance(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
                                int waves_per_job, int ebits, unsigned long long *prof, hipStream_t stream);
 hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long long *rows, PipBatchLayout lay,

@@ -2022,7 +2022,7 @@ static void launch_advance_t(PipJob *jobs, i64 *arena, int njobs, int Lmax, int 
     static bool raised = false;
     if (!raised) {
       (void)hipFuncSetAttribute((const void *)pip_advance_kernel<T, NCH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024 - 1024);
+                                PIPAMD_LDS_BUDGET);
       raised = true;
     }
   }

@@ -193,7 +193,9 @@ class Tree {
     memset(&j.pj, 0, sizeof j.pj);
     S = std::max(S, ni + 1);
     W = even(std::max(W, nvar + nparm + 1));
-    if (W > PIPAMD_MAXCOL || S > PIPAMD_SMAX || nvar + S > PIPAMD_LMAX) fail(PIPAMD_ST_CAPACITY);
+    if (W > PIPAMD_MAXCOL || S > PIPAMD_SMAX || nvar + S > PIPAMD_LMAX ||
+        pipk_advance_lds_bytes((even(nvar + S) + 3) & ~3, (S + 3) & ~3, W, 64) > PIPAMD_LDS_BUDGET)
+      fail(PIPAMD_ST_CAPACITY);
     const int L = even(nvar + S);
     const int nm = 8;  // room for the bitmaps of any launch geometry (jobs of mixed widths share launches)
     const size_t sol = (size_t)even(nvar * (W - nvar) + nvar);
@@ -1139,7 +1141,9 @@ class Forest {
     memset(&pj, 0, sizeof pj);
     S = std::max(S, ni + 1);
     W = even(std::max(W, nvar + nparm + 1));
-    if (W > PIPAMD_MAXCOL || S > PIPAMD_SMAX || nvar + S > PIPAMD_LMAX) throw (int)PIPAMD_E_TOOLARGE;
+    if (W > PIPAMD_MAXCOL || S > PIPAMD_SMAX || nvar + S > PIPAMD_LMAX ||
+        pipk_advance_lds_bytes((even(nvar + S) + 3) & ~3, (S + 3) & ~3, W, 64) > PIPAMD_LDS_BUDGET)
+      throw (int)PIPAMD_E_TOOLARGE;
     const int L = even(nvar + S);
     const size_t words = block_words(nvar, S, W);
     if (q.top + words > q.region_words) throw (int)PIPAMD_E_TOOLARGE;

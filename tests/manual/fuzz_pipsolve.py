@@ -1,0 +1,59 @@
+"""Manual GPU fuzz (not a test): pipamd_pip_solve (PolyLib matrices in, PipQuast out) with random
+option sets (Maximize / Urs_unknowns / Urs_parms / Rational / bignum) against the CPU oracle's
+`pip` mode, which prints what the reference's example.c prints.
+Usage: python tests/manual/fuzz_pipsolve.py [seconds] [seed]"""
+import os, sys, time, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from piplib_amd import engine as eng
+import pipbatch as pb
+from datfile import matrix_text
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+e = eng.Engine(0)
+t0 = time.time(); n = nskip = nabort = nsplit = 0
+while time.time() - t0 < budget:
+    nn, npar = int(rng.integers(1, 6)), int(rng.integers(0, 4))
+    nrow, ncrow = int(rng.integers(1, 9)), int(rng.integers(0, 4)) if npar else 0
+    dom = rng.integers(-3, 4, size=(nrow, nn + npar + 2)).astype(np.int64)
+    dom[:, 0] = rng.random(nrow) < 0.85
+    dom[:, -1] = rng.integers(-6, 12, size=nrow)
+    ctx = rng.integers(-2, 3, size=(ncrow, npar + 2)).astype(np.int64)
+    if ncrow:
+        ctx[:, 0] = 1
+        ctx[:, -1] = rng.integers(0, 9, size=ncrow)
+    opts = {}
+    words = ""
+    if rng.random() < 0.25: opts["Maximize"] = 1; words += "Maximize\n"
+    if rng.random() < 0.25: opts["Urs_unknowns"] = 1; words += "Urs_unknowns\n"
+    if npar and rng.random() < 0.25: opts["Urs_parms"] = 1; words += "Urs_parms\n"
+    if rng.random() < 0.3: opts["Nq"] = 0; words += "Rational\n"
+    bignum = -1
+    txt = (matrix_text(ctx) + f"\n{bignum}\n\n" + matrix_text(dom) + "\n" + words).encode()
+    try:
+        o = subprocess.run([pb.ORACLEPIP, "pip"], input=txt, capture_output=True, timeout=3)
+    except subprocess.TimeoutExpired:
+        nskip += 1
+        continue
+    tag = f"dom={dom.tolist()} ctx={ctx.tolist()} opts={opts}"
+    try:
+        text, _ = eng.pip_solve(e, dom, ctx, bignum, **opts)
+    except eng.SolverError as ex:
+        if o.returncode == 0:
+            print("MISMATCH: engine aborted, oracle did not:", tag, ex, flush=True); sys.exit(1)
+        nabort += 1
+        continue
+    if o.returncode != 0:
+        print("MISMATCH: oracle aborted, engine did not:", tag, flush=True); sys.exit(1)
+    got = ("[PIP2-like future input] Please enter:\n- the context matrix,\n" + matrix_text(ctx) +
+           "- the bignum column (start at 0, -1 if no bignum),\n" + f"{bignum}\n" +
+           "- the constraint matrix.\n" + matrix_text(dom) + "\n" + text)
+    want = o.stdout.decode("latin-1")
+    if pb.squash(got) != pb.squash(want):
+        print("MISMATCH:", tag, "\n got ", text[:400], "\n want", want[-400:], flush=True); sys.exit(1)
+    n += 1; nsplit += "(if" in text
+    if n % 200 == 0:
+        print(f"{n} problems ({nsplit} with splits, {nabort} aborts, {nskip} skipped), {time.time()-t0:.0f} s", flush=True)
+print(f"OK: {n} problems ({nsplit} with splits, {nabort} aborts on both sides, {nskip} skipped) checked")
