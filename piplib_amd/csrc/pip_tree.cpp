@@ -152,6 +152,8 @@ class Tree {
 
  public:  // (internal class; the lock-step Forest below reuses its helpers)
   int deepest_;
+  bool speculative_ = false;           // run(): bounded effort (compa_test sub-problems that may never be needed)
+  enum { SPEC_PIVOTS = 256 };
   hipStream_t st_ = 0;
   i64 *d_arena_ = nullptr;
   size_t arena_words_ = 0, top_ = 0;
@@ -300,6 +302,15 @@ class Tree {
       Sm = std::max(Sm, (int)tab[i].S);
       Wm = std::max(Wm, (int)tab[i].W);
     }
+    if (speculative_) {
+      // bounded effort: one launch of at most SPEC_PIVOTS pivots per job, no re-housing; jobs
+      // that are not done stay PIPAMD_ST_RUN / PIPAMD_ST_CAPACITY for a later, unbounded run
+      copy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice);
+      HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, SPEC_PIVOTS, n >= 2048 ? 1 : 4, 64, nullptr, st_));
+      copy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost);
+      for (int i = 0; i < n; i++) js[i]->pj = tab[i];
+      return;
+    }
     for (int pass = 0; pass < 64; pass++) {
       copy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice);
       for (int guard = 0; guard < 4096; guard++) {
@@ -330,6 +341,7 @@ class Tree {
   void run_to_final(std::vector<HostJob *> &js) {
     for (int guard = 0; guard < 100000; guard++) {
       run(js);
+      if (speculative_) return;
       bool again = false;
       for (HostJob *j : js)
         if (j->pj.status == PIPAMD_ST_NEED_PARMCUT) {
@@ -414,11 +426,22 @@ class Tree {
     }
     std::vector<HostJob *> ptr;
     for (auto &h : sub) ptr.push_back(&h);
+    // All sub-problems at once, but with bounded effort: the reference only solves the rows up to
+    // the first negative one, and a row behind it may be arbitrarily hard (or make the cut
+    // generator run forever) without the reference ever noticing.
+    speculative_ = true;
     run_to_final(ptr);
+    speculative_ = false;
     // apply in the reference's order; sub-problems behind the first negative row were
-    // speculative and are ignored (their pivots are not counted either)
+    // speculative and are ignored (their pivots are not counted either).  A sub-problem the
+    // bounded run did not finish is finished now that it is known to be needed.
     for (size_t t = 0; t < rows.size(); t++) {
       HostJob &jp = sub[2 * t], &jm = sub[2 * t + 1];
+      std::vector<HostJob *> need;
+      for (HostJob *h : {&jp, &jm})
+        if (h->pj.status == PIPAMD_ST_RUN || h->pj.status == PIPAMD_ST_CAPACITY || h->pj.status == PIPAMD_ST_NEED_PARMCUT)
+          need.push_back(h);
+      if (!need.empty()) run_to_final(need);
       pivots += jp.pj.npiv + jm.pj.npiv;
       check_final(jp);
       check_final(jm);

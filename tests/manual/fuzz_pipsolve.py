@@ -30,16 +30,19 @@ while time.time() - t0 < budget:
     if rng.random() < 0.25: opts["Urs_unknowns"] = 1; words += "Urs_unknowns\n"
     if npar and rng.random() < 0.25: opts["Urs_parms"] = 1; words += "Urs_parms\n"
     if rng.random() < 0.3: opts["Nq"] = 0; words += "Rational\n"
-    bignum = -1
+    # the bignum column is given in context-matrix columns (example.c); pip_solve wants it in
+    # domain-matrix columns
+    bignum = int(rng.integers(1, npar + 1)) if (npar and rng.random() < 0.2) else -1
+    bg = bignum + (dom.shape[1] - ctx.shape[1]) if bignum > 0 else bignum
     txt = (matrix_text(ctx) + f"\n{bignum}\n\n" + matrix_text(dom) + "\n" + words).encode()
     try:
         o = subprocess.run([pb.ORACLEPIP, "pip"], input=txt, capture_output=True, timeout=3)
     except subprocess.TimeoutExpired:
         nskip += 1
         continue
-    tag = f"dom={dom.tolist()} ctx={ctx.tolist()} opts={opts}"
+    tag = f"dom={dom.tolist()} ctx={ctx.tolist()} opts={opts} bignum={bignum}"
     try:
-        text, _ = eng.pip_solve(e, dom, ctx, bignum, **opts)
+        text, _ = eng.pip_solve(e, dom, ctx, bg, **opts)
     except eng.SolverError as ex:
         if o.returncode == 0:
             print("MISMATCH: engine aborted, oracle did not:", tag, ex, flush=True); sys.exit(1)
