@@ -1,7 +1,7 @@
 """Manual GPU fuzz (not a test): pipamd_pip_solve (PolyLib matrices in, PipQuast out) with random
 option sets (Maximize / Urs_unknowns / Urs_parms / Rational / bignum) against the CPU oracle's
 `pip` mode, which prints what the reference's example.c prints.
-Usage: python tests/manual/fuzz_pipsolve.py [seconds] [seed]"""
+Usage: python tests/manual/fuzz_pipsolve.py [seconds] [seed] [big]"""
 import os, sys, time, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,12 +12,14 @@ from datfile import matrix_text
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+BIG = len(sys.argv) > 3  # larger shapes and coefficients: more aborts and skips, deeper trees
 e = eng.Engine(0)
 t0 = time.time(); n = nskip = nabort = nsplit = 0
 while time.time() - t0 < budget:
-    nn, npar = int(rng.integers(1, 6)), int(rng.integers(0, 4))
-    nrow, ncrow = int(rng.integers(1, 9)), int(rng.integers(0, 4)) if npar else 0
-    dom = rng.integers(-3, 4, size=(nrow, nn + npar + 2)).astype(np.int64)
+    nn, npar = int(rng.integers(1, 9 if BIG else 6)), int(rng.integers(0, 5 if BIG else 4))
+    nrow, ncrow = int(rng.integers(1, 13 if BIG else 9)), int(rng.integers(0, 4)) if npar else 0
+    cm = int(rng.choice([3, 6, 12])) if BIG else 3
+    dom = rng.integers(-cm, cm + 1, size=(nrow, nn + npar + 2)).astype(np.int64)
     dom[:, 0] = rng.random(nrow) < 0.85
     dom[:, -1] = rng.integers(-6, 12, size=nrow)
     ctx = rng.integers(-2, 3, size=(ncrow, npar + 2)).astype(np.int64)
