@@ -109,3 +109,34 @@ def test_plain_c_example():
                          np.array([[-1, 12]], dtype=np.int64))
     o = pb.run_batch(pb.ORACLEPIP, [prob])
     assert out.endswith(pb.squash(o.results[0].text))
+
+
+@pytest.mark.parametrize("name,dom,ctx,opts", [
+    # found by tests/manual/fuzz_pipsolve.py: (1) a sub-problem of compa_test behind the first negative
+    # row never terminates (the reference never looks at it); (2) 179,996 pivots and > 768 rows
+    ("speculative_compa",
+     [[0, -3, 2, 0, 1, -3, -3, 1, -4], [1, -1, -2, -3, -1, 3, -2, -2, 7], [1, 1, 2, -2, 3, 1, 3, 0, 9],
+      [0, 0, -1, -2, 3, 1, 3, 1, -2], [1, 2, 3, -1, 2, -3, 1, 0, 1], [1, -1, 2, -2, -1, -2, 1, -1, 8],
+      [1, 0, -1, -1, -3, 0, 0, 2, 4]],
+     [[1, -2, -1, 3], [1, 0, 1, 1]], {"Urs_parms": 1}),
+    ("many_rows",
+     [[1, 3, 2, 2, -3, 1, 1, 0, 1], [1, 3, 1, -2, -2, -2, -2, 0, 7], [1, -1, 2, 3, 2, 0, -3, -3, -1],
+      [1, -1, -2, -3, 2, 0, 1, 1, 10], [0, -2, 3, 2, -1, -1, 1, 1, 1]],
+     [[1, 2, -1, -2, 6], [1, -2, 1, 0, 0]], {}),
+])
+def test_pip_solve_fuzz_regressions(name, dom, ctx, opts):
+    """pipamd_pip_solve vs the oracle's `pip` mode on inputs that once failed with PIPAMD_ST_CAPACITY."""
+    import subprocess
+    import numpy as np
+    from datfile import matrix_text
+    from piplib_amd import engine as eng
+    dom, ctx = np.array(dom, dtype=np.int64), np.array(ctx, dtype=np.int64)
+    words = "".join(k + "\n" for k in opts)
+    txt = (matrix_text(ctx) + "\n-1\n\n" + matrix_text(dom) + "\n" + words).encode()
+    o = subprocess.run([pb.ORACLEPIP, "pip"], input=txt, capture_output=True, timeout=120)
+    assert o.returncode == 0
+    text, _ = eng.pip_solve(eng.Engine(0), dom, ctx, -1, **opts)
+    got = ("[PIP2-like future input] Please enter:\n- the context matrix,\n" + matrix_text(ctx) +
+           "- the bignum column (start at 0, -1 if no bignum),\n-1\n- the constraint matrix.\n" +
+           matrix_text(dom) + "\n" + text)
+    assert pb.squash(got) == pb.squash(o.stdout.decode("latin-1"))
