@@ -111,7 +111,7 @@ class Batch:
         B, ni, ncol = rows.shape
         assert ncol == nvar + nparm + 1
         if cap_cuts is None:
-            cap_cuts = min(ni + 64, 768 - ni) if (tflags & T_INT) else 0
+            cap_cuts = max(0, min(ni + 64, 2048 - ni)) if (tflags & T_INT) else 0
         self.desc = BatchDesc(B, nvar, nparm, ni, bigparm, tflags, cap_cuts, cap_newparm, entier_bits)
         self.entier_bits = entier_bits
         ew = 2 if entier_bits == 128 else 1

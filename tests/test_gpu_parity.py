@@ -14,6 +14,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
     (15, 48, 63, 32, 1, dict()),
     (16, 32, 127, 64, 1, dict()),     # BASELINE configs[2] shape: 64x128, integer + cuts
     (17, 16, 200, 90, 1, dict()),     # two 128-column chunks per row
+    (18, 4, 60, 1900, 0, dict()),     # many rows: close to the 2048-slot limit, LDS image ~90 KB
 ])
 def test_lexmin_batch_vs_oracle(seed, batch, nvar, ni, nq, kw):
     from gpu_common import compare
