@@ -1756,9 +1756,14 @@ T *zalloc() {
 pipamd_vector *q_vector(const std::vector<Cell> &t, size_t *i, int Bg, int Urs_p, int flags) {
   const Cell *p = &t[*i];
   int n = (int)p->a, j, k, unbounded = 0;
-  pipamd_vector *v = zalloc<pipamd_vector>();
   if (flags & SOL_REMOVE) --n;
   n -= Urs_p;
+  // sol.c:452-471 walks n kept entries whatever the Form holds.  Some option combinations
+  // (Compute_dual with Urs_parms: one-entry dual Forms minus the "unrestricted" columns) give a
+  // negative length or a walk past the tape: the reference exits ("Memory Overflow") or faults
+  // there; we refuse the call instead.
+  if (n < 0 || *i + (size_t)(int)p->a >= t.size()) throw (int)PIPAMD_E_INVALID;
+  pipamd_vector *v = zalloc<pipamd_vector>();
   const int first_urs = Urs_p + (Bg >= 0);
   v->nb_elements = n;
   v->the_vector = (long long *)calloc((size_t)(n > 0 ? n : 1), sizeof(long long));
@@ -1766,6 +1771,12 @@ pipamd_vector *q_vector(const std::vector<Cell> &t, size_t *i, int Bg, int Urs_p
   for (j = 0, k = 0; k < n; j++) {
     (*i)++;
     p++;
+    if (*i >= t.size()) {
+      free(v->the_vector);
+      free(v->the_deno);
+      free(v);
+      throw (int)PIPAMD_E_INVALID;
+    }
     i64 N = p->a, D = p->b;
     const i64 d = gcd(N, D);
     if ((flags & SOL_SHIFT) && j == Bg) {
@@ -2109,7 +2120,14 @@ extern "C" int pipamd_pip_solve(pipamd_engine *e, const pipamd_matrix *inequnk, 
   if (!non_vide) return PIPAMD_OK;
   if (opt->Simplify) t_simplify(t.tape, 0);
   size_t xq = 0;
-  *quast = q_quast(t.tape, &xq, nullptr, Bg - Nn - 1, Urs_parms, sol_flags);
+  try {
+    *quast = q_quast(t.tape, &xq, nullptr, Bg - Nn - 1, Urs_parms, sol_flags);
+  } catch (int code) {
+    *quast = nullptr;  // (nodes built so far are leaked: an unsupported option combination, not a hot path)
+    pipamd_set_error("pip_solve: this option combination makes the reference read outside its solution tape "
+                     "(e.g. Compute_dual with Urs_parms); refused");
+    return code;
+  }
   if ((sol_flags & SOL_DUAL) && Nl > inequnk->NbRows) equalities_dual(*quast, inequnk);
   return PIPAMD_OK;
 }

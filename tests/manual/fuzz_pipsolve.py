@@ -31,7 +31,10 @@ while time.time() - t0 < budget:
     if rng.random() < 0.25: opts["Maximize"] = 1; words += "Maximize\n"
     if rng.random() < 0.25: opts["Urs_unknowns"] = 1; words += "Urs_unknowns\n"
     if npar and rng.random() < 0.25: opts["Urs_parms"] = 1; words += "Urs_parms\n"
-    if rng.random() < 0.3: opts["Nq"] = 0; words += "Rational\n"
+    if rng.random() < 0.3:
+        opts["Nq"] = 0; words += "Rational\n"
+        # (not with Urs_parms: the reference itself exits or faults on that combination)
+        if "Urs_parms" not in opts and rng.random() < 0.4: opts["Compute_dual"] = 1; words += "Dual\n"
     # the bignum column is given in context-matrix columns (example.c); pip_solve wants it in
     # domain-matrix columns
     bignum = int(rng.integers(1, npar + 1)) if (npar and rng.random() < 0.2) else -1
@@ -43,6 +46,9 @@ while time.time() - t0 < budget:
         nskip += 1
         continue
     tag = f"dom={dom.tolist()} ctx={ctx.tolist()} opts={opts} bignum={bignum}"
+    if os.environ.get("FUZZ_LAST_CASE"):  # a crash in the library leaves the input behind
+        with open(os.environ["FUZZ_LAST_CASE"], "w") as f:
+            f.write(tag + "\n")
     try:
         text, _ = eng.pip_solve(e, dom, ctx, bg, **opts)
     except eng.SolverError as ex:

@@ -140,3 +140,16 @@ def test_pip_solve_fuzz_regressions(name, dom, ctx, opts):
            "- the bignum column (start at 0, -1 if no bignum),\n-1\n- the constraint matrix.\n" +
            matrix_text(dom) + "\n" + text)
     assert pb.squash(got) == pb.squash(o.stdout.decode("latin-1"))
+
+
+def test_pip_solve_refuses_dual_with_urs_parms():
+    """Compute_dual + Urs_parms makes the reference's sol_vector_edit take a negative-length vector
+    (it exits with "Memory Overflow" or faults); the library must refuse the call, not crash."""
+    import numpy as np
+    from piplib_amd import engine as eng
+    dom = np.array([[1, 3, -3, -3, 2, -2, -2, 4], [1, -3, 1, -3, 0, 1, -3, 10], [1, 1, 0, 2, -1, 2, -1, -5],
+                    [1, 2, 3, 2, -2, -1, 3, 10], [1, 0, 3, 1, -1, -2, 0, -5], [1, -3, 0, 2, -3, -2, 0, -3]], dtype=np.int64)
+    for npar in (1, 2, 3):
+        ctx = np.zeros((0, npar + 2), dtype=np.int64)
+        with pytest.raises(RuntimeError):
+            eng.pip_solve(eng.Engine(0), dom, ctx, -1, Urs_unknowns=1, Urs_parms=1, Nq=0, Compute_dual=1)
