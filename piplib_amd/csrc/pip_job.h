@@ -8,8 +8,8 @@
 #define PIPAMD_MAXDET 4   /* reference tab.h:67 MAX_DETERMINANT */
 #define PIPAMD_MAXCOL 512 /* reference type.h:44 */
 #define PIPAMD_MAXPARM 50 /* reference type.h:45 */
-#define PIPAMD_LMAX 2560  /* logical rows the engine can stage in LDS (pipamd_lds_fits has the last word) */
-#define PIPAMD_SMAX 2048  /* real rows (slots) per job */
+#define PIPAMD_LMAX 4096  /* logical rows the engine can stage in LDS (pipamd_lds_fits has the last word) */
+#define PIPAMD_SMAX 3584  /* real rows (slots) per job */
 #define PIPAMD_LDS_BUDGET (160 * 1024 - 1024) /* dynamic LDS a workgroup can get */
 
 /* One problem ("job") in the device arena.  All offsets are in int64 units from the

@@ -196,8 +196,11 @@ class Tree {
     S = std::max(S, ni + 1);
     W = even(std::max(W, nvar + nparm + 1));
     if (W > PIPAMD_MAXCOL || S > PIPAMD_SMAX || nvar + S > PIPAMD_LMAX ||
-        pipk_advance_lds_bytes((even(nvar + S) + 3) & ~3, (S + 3) & ~3, W, 64) > PIPAMD_LDS_BUDGET)
+        pipk_advance_lds_bytes((even(nvar + S) + 3) & ~3, (S + 3) & ~3, W, 64) > PIPAMD_LDS_BUDGET) {
+      if (getenv("PIPAMD_TREE_TRACE"))
+        fprintf(stderr, "[tree] job beyond the engine's limits: nvar %d nparm %d ni %d S %d W %d\n", nvar, nparm, ni, S, W);
       fail(PIPAMD_ST_CAPACITY);
+    }
     const int L = even(nvar + S);
     const int nm = 8;  // room for the bitmaps of any launch geometry (jobs of mixed widths share launches)
     const size_t sol = (size_t)even(nvar * (W - nvar) + nvar);

@@ -123,6 +123,11 @@ def test_plain_c_example():
      [[1, 3, 2, 2, -3, 1, 1, 0, 1], [1, 3, 1, -2, -2, -2, -2, 0, 7], [1, -1, 2, 3, 2, 0, -3, -3, -1],
       [1, -1, -2, -3, 2, 0, 1, 1, 10], [0, -2, 3, 2, -1, -1, 1, 1, 1]],
      [[1, 2, -1, -2, 6], [1, -2, 1, 0, 0]], {}),
+    ("sub_problem_2000_cuts",
+     [[1, -2, 0, 1, 3, -3, 0, -1, -1], [1, -1, 1, 3, 0, 0, 1, -2, 10], [1, -1, 0, 3, -3, 2, -1, 0, -2],
+      [0, 2, -2, 1, -2, 2, -3, -3, 2], [0, -2, 3, -3, -2, 0, 2, -2, -4], [1, 0, 2, -2, 1, -2, 3, 0, -6],
+      [0, 3, 1, 2, -1, -1, 3, 3, 5], [1, 3, 1, 3, -2, 2, -1, 2, 6], [1, -1, -3, -3, -1, -3, -3, 0, -5]],
+     [[1, 2, -2, 0, 1], [1, 2, -1, 0, 4]], {"Urs_parms": 1}),
 ])
 def test_pip_solve_fuzz_regressions(name, dom, ctx, opts):
     """pipamd_pip_solve vs the oracle's `pip` mode on inputs that once failed with PIPAMD_ST_CAPACITY."""
