@@ -22,6 +22,13 @@ while time.time() - t0 < budget:
     dom = rng.integers(-cm, cm + 1, size=(nrow, nn + npar + 2)).astype(np.int64)
     dom[:, 0] = rng.random(nrow) < 0.85
     dom[:, -1] = rng.integers(-6, 12, size=nrow)
+    u = rng.random()
+    if u < 0.06:    # degenerate inputs: an all-zero row, a duplicated row, no rows at all
+        dom[int(rng.integers(0, nrow)), 1:] = 0
+    elif u < 0.12 and nrow > 1:
+        dom[int(rng.integers(0, nrow))] = dom[int(rng.integers(0, nrow))]
+    elif u < 0.16:
+        dom = dom[:0]
     ctx = rng.integers(-2, 3, size=(ncrow, npar + 2)).astype(np.int64)
     if ncrow:
         ctx[:, 0] = 1
