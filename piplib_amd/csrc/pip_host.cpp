@@ -82,8 +82,9 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
   lay->W = ebits == 128 ? ncol + d->cap_newparm : round_even(ncol + d->cap_newparm);
   if (lay->L > PIPAMD_LMAX || lay->S > PIPAMD_SMAX || lay->W > PIPAMD_MAXCOL || lay->S < 1 ||
       pipk_advance_lds_bytes((lay->L + 3) & ~3, (lay->S + 3) & ~3, lay->W, ebits) > PIPAMD_LDS_BUDGET) {
-    pipamd_set_error("batch shape exceeds engine limits (L=%d<=%d, S=%d<=%d, W=%d<=%d)", lay->L, PIPAMD_LMAX, lay->S,
-                     PIPAMD_SMAX, lay->W, PIPAMD_MAXCOL);
+    pipamd_set_error("batch shape exceeds engine limits (L=%d<=%d, S=%d<=%d, W=%d<=%d, LDS image %zu<=%d bytes)", lay->L,
+                     PIPAMD_LMAX, lay->S, PIPAMD_SMAX, lay->W, PIPAMD_MAXCOL,
+                     pipk_advance_lds_bytes((lay->L + 3) & ~3, (lay->S + 3) & ~3, lay->W, ebits), PIPAMD_LDS_BUDGET);
     return PIPAMD_E_TOOLARGE;
   }
   if (d->bigparm >= ncol || (d->bigparm >= 0 && d->bigparm <= d->nvar)) {
