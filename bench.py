@@ -115,6 +115,11 @@ def main():
     # while one batch's last stragglers finish (a latency-bound tail that leaves most CUs idle)
     # the next batch's bulk rounds already run.  Every step is still a full load + solve.
     depth = max(1, min(args.pipeline, args.steps))
+    # every lane should time the same number of steps: prefer a lane count that divides --steps
+    for d in range(depth, max(1, depth // 2) - 1, -1):
+        if args.steps % d == 0:
+            depth = d
+            break
     lanes = []
     for _ in range(depth):
         e = eng.Engine(local)
