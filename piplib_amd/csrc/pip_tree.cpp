@@ -329,7 +329,10 @@ class Tree {
       for (int i = 0; i < n; i++) {
         js[i]->pj = tab[i];
         if (tab[i].status == PIPAMD_ST_CAPACITY) {
-          grow(*js[i], js[i]->pj.S + 32, js[i]->pj.W);
+          // geometric growth (as far as the engine's row limit allows): a sub-problem may need
+          // thousands of cut rows, and every re-housing copies the whole tableau
+          grow(*js[i], std::min(std::max(js[i]->pj.S + 32, js[i]->pj.S * 3 / 2), std::max(js[i]->pj.S + 32, (int)PIPAMD_SMAX)),
+               js[i]->pj.W);
           tab[i] = js[i]->pj;
           Lm = std::max(Lm, (int)tab[i].L);
           Sm = std::max(Sm, (int)tab[i].S);
@@ -713,7 +716,9 @@ class Tree {
           if (flags & PIPAMD_T_DUAL) emit_dual(job, nvar, ni0, pos);
           return;
         case PIPAMD_ST_NIL: push(S_NIL, 0, 0); return;
-        case PIPAMD_ST_CAPACITY: grow(job, job.pj.S + 32, job.pj.W); continue;
+        case PIPAMD_ST_CAPACITY:
+          grow(job, std::min(std::max(job.pj.S + 32, job.pj.S * 3 / 2), std::max(job.pj.S + 32, (int)PIPAMD_SMAX)), job.pj.W);
+          continue;
         case PIPAMD_ST_NEED_PARMCUT:
           if (!host_cut(job, ctx, nvar, nparm, ni, bigparm)) {
             push(S_NIL, 0, 0);
