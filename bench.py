@@ -71,7 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--batch", type=int, default=10000, help="tableaux per GPU")
     ap.add_argument("--waves", type=int, default=0, help="waves per tableau (0 = engine default)")
-    ap.add_argument("--round", type=int, default=0, help="pivots per tableau per launch (0 = engine default)")
+    ap.add_argument("--round", type=int, default=0, help="pivot budget per tableau in the bulk launch (0 = engine default)")
+    ap.add_argument("--round-rows", type=int, default=0, help="spare rows in the bulk launch's LDS image (0 = engine default)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch tableaux per GPU (default); strong: --batch tableaux in all, sharded over the ranks")
     ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (streams/threads)")
@@ -127,6 +128,8 @@ def main():
             e.set_waves_per_job(args.waves)
         if args.round:
             e.set_round_pivots(args.round)
+        if args.round_rows:
+            e.set_round_rows(args.round_rows)
         lanes.append((e, eng.Batch(e, rows_d, NVAR, NPARM, tflags=eng.T_INT), torch.cuda.Stream(dev)))
     e, b, _ = lanes[0]
 

@@ -135,9 +135,14 @@ size_t pipamd_pivot_bytes(const pipamd_batch_desc *d);
  * measured with HIP events on the launch stream, and the number of those launches. */
 int pipamd_last_solve_ms(pipamd_engine *e, float *ms);
 int pipamd_last_solve_launches(pipamd_engine *e);
-/* Pivots per tableau per launch (default 48): pipamd_batch_solve runs the pivot loop in
- * rounds so that every CU stays busy although tableaux need different numbers of pivots. */
+/* pipamd_batch_solve serves a batch of >= 2048 tableaux with two queue-fed launches and no host
+ * round trip in between: a bulk launch of persistent one-wave workgroups that draw tableaux from
+ * a device queue and give one up when it is finished, has used `pivots` pivots (default 96) or
+ * `rows` Gomory-cut rows (default 48: the bulk launch's LDS image holds the input rows plus that
+ * many, so that 24 tableaux fit a CU), and a tail launch that runs what is left to completion
+ * with four waves per tableau. */
 int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots);
+int pipamd_engine_set_round_rows(pipamd_engine *e, int rows);
 
 /* ------------------------------------------------------------------ layer 3 */
 /* One problem in PIP's native tableau form (what maind.c reads from a .dat file):

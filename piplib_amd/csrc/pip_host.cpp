@@ -49,7 +49,7 @@ extern "C" int pipamd_engine_create(pipamd_engine **out, int device) {
 extern "C" void pipamd_engine_destroy(pipamd_engine *e) {
   if (!e) return;
   for (int i = 0; i < 2 * e->nev; i++) hipEventDestroy(e->ev[i]);
-  if (e->d_run) hipFree(e->d_run);
+  if (e->d_q) hipFree(e->d_q);
   if (e->h_run) hipHostFree(e->h_run);
   if (e->d_scratch) hipFree(e->d_scratch);
   free(e);
@@ -131,12 +131,19 @@ extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batc
   return PIPAMD_OK;
 }
 
-// traiter() for the whole batch.  The pivot loop runs in rounds of at most `round_pivots`
-// pivots per tableau: a round ends for a tableau when it is finished, has used its pivot
-// budget, or has no room left in the LDS image of that launch; it is then resumed by the
-// next launch.  Rounds keep every CU busy although tableaux need very different numbers of
-// pivots, and let each launch size its LDS image to the rows the running tableaux have *now*
-// (Gomory cuts add rows as the solve goes on).
+// traiter() for the whole batch, as a short sequence of launches without a host round trip in
+// between (each launch writes the list of tableaux it left unfinished, the next one reads it):
+//   bulk  (batches of >= 2048 tableaux): one wave per tableau; a tableau's workgroup ends when the
+//         tableau is finished, has spent `round_pivots` pivots or has filled the LDS image (sized
+//         for the rows it has plus `round_rows` Gomory cuts, so that 24 tableaux fit a CU).  The
+//         workgroup dispatcher starts the next tableau in its place, so every CU stays busy until
+//         all have had their turn.
+//   tail  : what the bulk launch left unfinished (the few tableaux that need many more pivots or
+//         rows) runs to completion with four waves per tableau and an image for every spare row:
+//         little parallelism is left, so the latency of a pivot is what counts.
+// Only then the host looks at the number of tableaux still running (normally 0; tableaux that
+// hit the per-launch pivot limit `iter_limit` go through further tail launches).
+#define Q_CTRL 2 /* control words per launch: out_count, out_maxni */
 extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, void *stream) {
   if (e && hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;  // HIP's current device is per host thread
   PipBatchLayout lay;
@@ -147,42 +154,62 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
   PipJob *jobs = (PipJob *)d_ws;
   long long *arena = (long long *)((char *)d_ws + jb);
   hipStream_t st = (hipStream_t)stream;
-  if (!e->d_run) {
-    HIPCHK(hipMalloc((void **)&e->d_run, 2 * sizeof(int)));
-    HIPCHK(hipHostMalloc((void **)&e->h_run, 2 * sizeof(int), hipHostMallocDefault));
+  if (!e->h_run) HIPCHK(hipHostMalloc((void **)&e->h_run, 2 * sizeof(int), hipHostMallocDefault));
+  const int nctrl = Q_CTRL * PIPAMD_MAX_ROUNDS;
+  if (!e->d_q || e->q_cap < lay.batch) {
+    if (e->d_q) HIPCHK(hipFree(e->d_q));
+    e->d_q = nullptr;
+    HIPCHK(hipMalloc((void **)&e->d_q, ((size_t)nctrl + 2 * (size_t)lay.batch) * sizeof(int)));
+    e->q_cap = lay.batch;
   }
-  int running = lay.batch, max_ni = lay.ni;
+  int *ctrl = e->d_q, *list[2] = {e->d_q + nctrl, e->d_q + nctrl + e->q_cap};
+  HIPCHK(hipMemsetAsync(ctrl, 0, (size_t)nctrl * sizeof(int), st));
   e->nlaunch = 0;
-  const int K = e->round_pivots > 0 ? e->round_pivots : 48;
-  while (running > 0) {
-    if (e->nlaunch >= PIPAMD_MAX_ROUNDS) {
-      pipamd_set_error("batch_solve: more than %d rounds", PIPAMD_MAX_ROUNDS);
+  const bool integer = (lay.tflags & PIPAMD_T_INT) != 0;
+  const int K1 = e->round_pivots > 0 ? e->round_pivots : 96;
+  const int KA = !integer ? 0 : (e->round_rows > 0 ? e->round_rows : 48);
+  int stage = 0;          // launches issued
+  bool have_list = false; // the previous launch's out list is this launch's input
+  auto launch = [&](int waves, int budget, int smax, int upper) -> int {
+    if (stage >= PIPAMD_MAX_ROUNDS) {
+      pipamd_set_error("batch_solve: more than %d launches", PIPAMD_MAX_ROUNDS);
       return PIPAMD_E_SOLVER;
     }
-    const int waves = e->waves_per_job ? e->waves_per_job : (running >= 2048 ? 1 : 4);
-    // few tableaux left: the GPU is under-filled whatever we do, so let them run to the end in
-    // one launch (LDS image sized for every spare row) instead of paying a launch per round
-    int budget = running < 2048 ? e->iter_limit : K;
-    if (e->iter_limit < budget) budget = e->iter_limit;
-    int smax = budget >= lay.S ? lay.S : max_ni + budget;  // a cut is always followed by a pivot
     if (smax > lay.S) smax = lay.S;
-    if (smax < max_ni) smax = max_ni;
-    const int lmax = lay.nvar + smax;
+    int *c = ctrl + Q_CTRL * stage;
+    void *q5[5] = {nullptr, nullptr, list[stage & 1], c, c + 1};
+    if (have_list) {
+      q5[0] = list[(stage - 1) & 1];
+      q5[1] = ctrl + Q_CTRL * (stage - 1);
+    }
     if (e->nlaunch >= e->nev) {
       HIPCHK(hipEventCreate(&e->ev[2 * e->nev]));
       HIPCHK(hipEventCreate(&e->ev[2 * e->nev + 1]));
       e->nev++;
     }
     HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch], st));
-    HIPCHK(pipk_launch_advance(jobs, arena, lay.batch, lmax, smax, lay.W, budget, waves, lay.ebits, e->d_prof, st));
+    HIPCHK(pipk_launch_advance_q(jobs, arena, lay.batch, lay.nvar + smax, smax, lay.W, budget, waves, lay.ebits, q5, upper,
+                                 e->d_prof, st));
     HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
     e->nlaunch++;
-    HIPCHK(pipk_launch_batch_running(jobs, lay.batch, e->d_run, st));
-    HIPCHK(hipMemcpyAsync(e->h_run, e->d_run, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    stage++;
+    have_list = true;
+    return PIPAMD_OK;
+  };
+  const int tail_waves = e->waves_per_job ? e->waves_per_job : 4;
+  if (lay.batch >= 2048 && e->waves_per_job != 4 && !e->single_launch) {
+    const int budget = e->iter_limit < K1 ? e->iter_limit : K1;
+    rc = launch(1, budget, lay.ni + (KA < budget ? KA : budget), lay.batch);
+    if (rc) return rc;
+  }
+  int upper = lay.batch;  // what the host knows about the length of the next input list
+  for (;;) {
+    rc = launch(tail_waves, e->iter_limit, lay.S, upper);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->h_run, ctrl + Q_CTRL * (stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    running = e->h_run[0];
-    max_ni = e->h_run[1];
-    if (e->single_launch) break;
+    if (e->h_run[0] <= 0 || e->single_launch) break;
+    upper = e->h_run[0];
   }
   e->timed = 1;
   return PIPAMD_OK;
@@ -205,9 +232,23 @@ extern "C" int pipamd_last_solve_ms(pipamd_engine *e, float *ms) {
 
 extern "C" int pipamd_last_solve_launches(pipamd_engine *e) { return e ? e->nlaunch : 0; }
 
+// Duration of launch `i` of the last pipamd_batch_solve (diagnostics, tools/).
+extern "C" int pipamd_last_launch_ms(pipamd_engine *e, int i, float *ms) {
+  if (!e || !ms || !e->timed || i < 0 || i >= e->nlaunch) return PIPAMD_E_INVALID;
+  HIPCHK(hipEventSynchronize(e->ev[2 * i + 1]));
+  HIPCHK(hipEventElapsedTime(ms, e->ev[2 * i], e->ev[2 * i + 1]));
+  return PIPAMD_OK;
+}
+
 extern "C" int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots) {
   if (!e || pivots < 1) return PIPAMD_E_INVALID;
   e->round_pivots = pivots;
+  return PIPAMD_OK;
+}
+
+extern "C" int pipamd_engine_set_round_rows(pipamd_engine *e, int rows) {
+  if (!e || rows < 1) return PIPAMD_E_INVALID;
+  e->round_rows = rows;
   return PIPAMD_OK;
 }
 

@@ -12,9 +12,12 @@ struct pipamd_engine {
   hipEvent_t ev[2 * PIPAMD_MAX_ROUNDS];
   int nev, nlaunch;
   int timed;
-  int round_pivots;  /* pivots per tableau per launch (0 = default) */
+  int round_pivots;  /* pivot budget per tableau in the bulk launch (0 = default) */
+  int round_rows;    /* spare rows (Gomory cuts) in the bulk launch's LDS image (0 = default) */
   int single_launch; /* debug: stop after one launch */
-  int *d_run, *h_run;
+  int *h_run;        /* pinned: {jobs still running, their largest row count} */
+  int *d_q;          /* work-queue control words and the two job lists of pipamd_batch_solve */
+  int q_cap;         /* jobs the lists hold */
   int iter_limit;
   int waves_per_job; /* 0 = choose by batch size */
   unsigned long long *d_prof; /* diagnostic builds only (-DPIP_PROFILE) */
@@ -31,6 +34,9 @@ extern "C" {
 size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax, int ebits);
 hipError_t pipk_launch_advance(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
                                int waves_per_job, int ebits, unsigned long long *prof, hipStream_t stream);
+hipError_t pipk_launch_advance_q(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
+                                 int waves_per_job, int ebits, void *const *q5, int grid, unsigned long long *prof,
+                                 hipStream_t stream);
 hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long long *rows, PipBatchLayout lay,
                                   hipStream_t stream);
 hipError_t pipk_launch_batch_results(const PipJob *jobs, const long long *arena, int njobs, int nvar, int nparm,

@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "pip_job.h"
 
 typedef long long i64;
@@ -1003,9 +1005,25 @@ __device__ __forceinline__ int trunc_int_x86(double t) {
 }
 
 // ================================================================ main kernel
+// Work list of one launch (see pip_host.cpp, pipamd_batch_solve): workgroup b runs entry b of the
+// input list.  The hardware's workgroup dispatcher is the queue: a workgroup ends when its job is
+// finished, needs the host, has spent the launch's pivot budget or has no room left in the LDS
+// image, and the next one starts in its place, so every CU stays busy while work is left.
+//   in_list/in_count : jobs to run (NULL: all jobs 0..njobs-1); workgroups beyond *in_count exit
+//   out_list/out_count/out_maxni : jobs still PIPAMD_ST_RUN when their workgroup let go of them and
+//                      the largest row count among them -- the input of the next launch, without a
+//                      host round trip in between (NULL: not recorded)
+struct PipQueue {
+  const int *in_list;
+  const int *in_count;
+  int *out_list;
+  int *out_count;
+  int *out_maxni;
+};
+
 template <class T, int NCH, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? PIP_MINWAVES : 1) void pip_advance_kernel(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax,
-                                                         int Wmax, int iter_limit, u64 *prof) {
+__global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? PIP_MINWAVES : 1) void pip_advance_kernel(
+    PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit, PipQueue q, u64 *prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Scalars sc;
   // Determinant limbs (traiter.c:413-446).  64-bit entries: scalar registers.  128-bit entries:
@@ -1014,15 +1032,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   constexpr bool DET_LDS = sizeof(T) == 16;
   __shared__ T sdet[DET_LDS ? PIPAMD_MAXDET : 1];
   __shared__ int sldet;
-  const int jb = blockIdx.x;
-  if (jb >= njobs) return;
+  (void)Wmax;
+  const int nq = q.in_count ? *q.in_count : njobs;
+  if ((int)blockIdx.x >= nq) return;
+  const int jb = q.in_list ? q.in_list[blockIdx.x] : (int)blockIdx.x;
   PipJob *J = &jobs[jb];
   if (J->status != PIPAMD_ST_RUN) return;
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int WP = NCH * 64 * ET<T>::CPL;  // columns a wave's registers cover; prow/urow are padded to it
   constexpr int NM = NCH * ET<T>::CPL;
-  (void)Wmax;
   PROF_DECL;
 #ifdef PIP_PROFILE_EVENTS
   if (threadIdx.x == 0) pf_buf = prof;
@@ -1067,7 +1086,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   if constexpr (!DET_LDS) {
     for (int i = 0; i < PIPAMD_MAXDET; i++) det[i] = J->det[i];
   }
-  if (ni > Smax || nligne > Lmax) return;  // this launch's LDS image is too small: stay RUN for a larger one
+  if (ni > Smax || nligne > Lmax) {  // this launch's LDS image is too small: stay RUN for a larger one
+    if (tid == 0 && q.out_count) {
+      q.out_list[atomicAdd(q.out_count, 1)] = jb;
+      atomicMax(q.out_maxni, ni);
+    }
+    return;
+  }
   // saved LDS state of a paused job (bitmaps, sign summaries, magnitude classes)
   u64 *g_nzm = (u64 *)(arena + J->state_off);
   u16 *g_sig = (u16 *)(g_nzm + (size_t)Sl * NM);
@@ -1739,6 +1764,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     J->maxabs = (u64)mc;  // magnitude class of the largest entry
     J->aux = sc.aux;
     J->status = status;
+    if (status == PIPAMD_ST_RUN && q.out_count) {  // paused: the next launch resumes it
+      q.out_list[atomicAdd(q.out_count, 1)] = jb;
+      atomicMax(q.out_maxni, ni);
+    }
   }
   PROF(8);
   PROF_FLUSH(prof);
@@ -2015,58 +2044,100 @@ extern "C" hipError_t pipk_launch_batch_counters(const PipJob *jobs, int njobs, 
   return hipGetLastError();
 }
 
+// What a launch needs besides the jobs: its LDS image (Lmax, Smax, Wmax), the pivot budget per
+// job, waves per job, entry width, the work queue and the number of workgroups.
+struct AdvanceLaunch {
+  PipJob *jobs;
+  i64 *arena;
+  int njobs, Lmax, Smax, Wmax, iter_limit;
+  PipQueue q;
+  int grid;  // workgroups = upper bound on the entries of the input list (0: njobs)
+  unsigned long long *prof;
+  size_t shm;
+  hipStream_t stream;
+};
+
+// hipFuncSetAttribute applies to the current device only: remember per (instantiation, device)
+// whether the opt-in to more than 48 KiB of dynamic LDS was made.
 template <class T, int NCH, int NW>
-static void launch_advance_t(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
-                             unsigned long long *prof, size_t shm, hipStream_t stream) {
-  if (shm > 48 * 1024) {  // large tableaux: opt in to more than the default dynamic LDS (160 KiB per CU)
-    static bool raised = false;
-    if (!raised) {
-      (void)hipFuncSetAttribute((const void *)pip_advance_kernel<T, NCH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                PIPAMD_LDS_BUDGET);
-      raised = true;
+static hipError_t launch_advance_t(const AdvanceLaunch &a) {
+  const void *fn = (const void *)pip_advance_kernel<T, NCH, NW>;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (a.shm > 48 * 1024) {  // large tableaux: opt in to more than the default dynamic LDS (160 KiB per CU)
+    static std::atomic<unsigned long long> raised{0};
+    if (!((raised.load(std::memory_order_acquire) >> dev) & 1)) {
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PIPAMD_LDS_BUDGET);
+      if (e != hipSuccess) return e;
+      raised.fetch_or(1ull << dev, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW>), dim3(njobs), dim3(64 * NW), shm, stream, jobs, arena, njobs, Lmax,
-                     Smax, Wmax, iter_limit, prof);
+  int grid = a.grid > 0 && a.grid < a.njobs ? a.grid : a.njobs;
+  hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW>), dim3(grid), dim3(64 * NW), a.shm, a.stream, a.jobs, a.arena, a.njobs,
+                     a.Lmax, a.Smax, a.Wmax, a.iter_limit, a.q, a.prof);
+  return hipGetLastError();
 }
 template <class T, int NCH>
-static void launch_advance_w(bool one, PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
-                             int iter_limit, unsigned long long *prof, size_t shm, hipStream_t stream) {
-  if (one)
-    launch_advance_t<T, NCH, 1>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
-  else
-    launch_advance_t<T, NCH, 4>(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream);
+static hipError_t launch_advance_w(bool one, const AdvanceLaunch &a) {
+  return one ? launch_advance_t<T, NCH, 1>(a) : launch_advance_t<T, NCH, 4>(a);
 }
 
 // waves_per_job: 1 = one wave64 per tableau (latency-bound sparse batches: more tableaux in
 // flight per CU), 4 = four waves share a tableau's rows (few, large tableaux).
 // ebits: 64 or 128 -- every job of the launch must have that entry width.
-extern "C" hipError_t pipk_launch_advance(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
-                                          int iter_limit, int waves_per_job, int ebits, unsigned long long *prof,
-                                          hipStream_t stream) {
+// q5: NULL = job b is workgroup b's; else five device pointers {in_list, in_count, out_list,
+// out_count, out_maxni} (see PipQueue; the in_ pair and the out_ triple may each be NULL) and
+// `grid` = an upper bound on *in_count (0: njobs).
+extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
+                                            int iter_limit, int waves_per_job, int ebits, void *const *q5, int grid,
+                                            unsigned long long *prof, hipStream_t stream) {
   if (njobs <= 0) return hipSuccess;
   // LDS arrays are carved at 16/8/4/2/1-byte granularity in that order: keep Lmax, Smax multiples of 4
   Lmax = (Lmax + 3) & ~3;
   Smax = (Smax + 3) & ~3;
   if (Wmax > 512) return hipErrorInvalidValue;
-  const size_t shm = pipk_advance_lds_bytes(Lmax, Smax, Wmax, ebits);
+  AdvanceLaunch a;
+  a.jobs = jobs;
+  a.arena = arena;
+  a.njobs = njobs;
+  a.Lmax = Lmax;
+  a.Smax = Smax;
+  a.Wmax = Wmax;
+  a.iter_limit = iter_limit;
+  a.q = PipQueue{nullptr, nullptr, nullptr, nullptr, nullptr};
+  a.grid = njobs;
+  if (q5) {
+    a.q = PipQueue{(const int *)q5[0], (const int *)q5[1], (int *)q5[2], (int *)q5[3], (int *)q5[4]};
+    a.grid = grid;
+  }
+  a.prof = prof;
+  a.shm = pipk_advance_lds_bytes(Lmax, Smax, Wmax, ebits);
+  if (a.shm > PIPAMD_LDS_BUDGET) return hipErrorInvalidConfiguration;  // the image of this job mix does not fit a CU
+  a.stream = stream;
   const bool one = waves_per_job == 1;
   const int wp = wp_of(Wmax, ebits);
   if (ebits == 128) {
     switch (wp) {
-      case 64: launch_advance_w<i128, 1>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
-      case 128: launch_advance_w<i128, 2>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
-      case 256: launch_advance_w<i128, 4>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
-      default: launch_advance_w<i128, 8>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
-    }
-  } else {
-    switch (wp) {
-      case 128: launch_advance_w<i64, 1>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
-      case 256: launch_advance_w<i64, 2>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
-      default: launch_advance_w<i64, 4>(one, jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, prof, shm, stream); break;
+      case 64: return launch_advance_w<i128, 1>(one, a);
+      case 128: return launch_advance_w<i128, 2>(one, a);
+      case 256: return launch_advance_w<i128, 4>(one, a);
+      default: return launch_advance_w<i128, 8>(one, a);
     }
   }
-  return hipGetLastError();
+  switch (wp) {
+    case 128: return launch_advance_w<i64, 1>(one, a);
+    case 256: return launch_advance_w<i64, 2>(one, a);
+    default: return launch_advance_w<i64, 4>(one, a);
+  }
+}
+
+extern "C" hipError_t pipk_launch_advance(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
+                                          int iter_limit, int waves_per_job, int ebits, unsigned long long *prof,
+                                          hipStream_t stream) {
+  return pipk_launch_advance_q(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, waves_per_job, ebits, nullptr, 0, prof,
+                               stream);
 }
 
 extern "C" hipError_t pipk_launch_batch_load(PipJob *jobs, i64 *arena, const i64 *rows, PipBatchLayout lay,

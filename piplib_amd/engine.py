@@ -43,6 +43,8 @@ def lib():
         L.pipamd_engine_set_iter_limit.argtypes = [C.c_void_p, C.c_int]
         L.pipamd_engine_set_waves_per_job.argtypes = [C.c_void_p, C.c_int]
         L.pipamd_engine_set_round_pivots.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(L, "pipamd_engine_set_round_rows"):
+            L.pipamd_engine_set_round_rows.argtypes = [C.c_void_p, C.c_int]
         L.pipamd_last_solve_launches.argtypes = [C.c_void_p]
         L.pipamd_batch_load.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p, C.c_void_p]
         L.pipamd_batch_solve.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p]
@@ -78,6 +80,9 @@ class Engine:
 
     def set_round_pivots(self, n):
         _check(lib().pipamd_engine_set_round_pivots(self._h, int(n)))
+
+    def set_round_rows(self, n):
+        _check(lib().pipamd_engine_set_round_rows(self._h, int(n)))
 
     def last_solve_launches(self):
         return int(lib().pipamd_last_solve_launches(self._h))

@@ -1,0 +1,339 @@
+"""Exact-arithmetic (Python int) restatement of PipLib's non-parametric pivot loop.
+
+TEST INFRASTRUCTURE ONLY (like oracle/): used by tests/golden/make_bigint_fixtures.py to
+produce the fixtures that pin the 128-bit Entier engine, and by tests that cross-check it
+against oracle/oraclepip.  Nothing under piplib_amd/ imports it.
+
+What is restated (reference file:line), for problems without parameters (nparm = 0, no big
+parameter), exactly as the reference's fixed-width builds run them:
+
+  tab_sort_rows   source/traiter.c:556-623   sort_rows()
+  traiter loop    source/traiter.c:628-791   solve()
+  chercher        source/traiter.c:39-44
+  exam_coef       source/traiter.c:101-159   (nparm = 0: the sign of the constant term)
+  choisir_piv     source/traiter.c:297-341   pick_column()
+  pivoter         source/traiter.c:345-548   pivot_step(), incl. the multi-limb determinant and its
+                                             "Integer overflow" exits (traiter.c:412-446)
+  integrer        source/integrer.c:305-486  gomory() (constant cuts; no deepest cut)
+
+Integers are Python ints, so nothing wraps.  `bits` is the width of the fixed-width build being
+modelled (64 = the reference's `long long` flavour, 128 = the overflow-safe flavour,
+include/piplib/piplib.h:42-88): it enters the algorithm only through the determinant limbs
+(piplib_lllog2 sums against 8*sizeof(Entier)).  Every product, difference and row entry the
+fixed-width code would form is also checked against that width: `Stats.max_bits` is the largest
+magnitude met, and a result is only comparable with a fixed-width run when
+`max_bits < bits` (no wrap-around happened) -- callers check `Stats.exact`.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+UNIT, PLUS, MINUS, ZERO, CRITIC, UNKNOWN = 1, 2, 4, 8, 16, 32
+MAXDET = 4  # reference tab.h:67 MAX_DETERMINANT
+
+ST_SOLUTION, ST_NIL, ST_OVERFLOW = 1, 2, 5  # == PIPAMD_ST_* of include/piplib_amd.h
+
+
+@dataclass
+class Stats:
+    bits: int
+    max_bits: int = 0          # largest bit length of any intermediate the fixed-width code forms
+    max_entry_bits: int = 0    # largest bit length of a stored tableau entry or denominator
+    pivots: int = 0
+    cuts: int = 0
+    rows_changed: List[int] = field(default_factory=list)   # per pivot: rows whose bits change
+    entry_bits: List[int] = field(default_factory=list)     # per pivot: max entry bits after it
+    nrows: List[int] = field(default_factory=list)          # per pivot: real rows
+
+    @property
+    def exact(self):
+        return self.max_bits < self.bits
+
+
+@dataclass
+class Result:
+    status: int
+    pivots: int
+    cuts: int
+    sol_num: Optional[List[int]]   # per unknown: numerator of the constant term (solution(), traiter.c:255-271)
+    sol_den: Optional[List[int]]
+    stats: Stats
+
+
+def _log2(x):
+    """integrer.c:51-59 piplib_lllog2: bit length of |x|, 1 for 0."""
+    n = abs(x).bit_length()
+    return n if n else 1
+
+
+def _sgn(x):
+    return MINUS if x < 0 else (PLUS if x > 0 else ZERO)
+
+
+class _Row:
+    __slots__ = ("flag", "den", "v", "unit", "size")
+
+    def __init__(self, flag, den, v=None, unit=-1):
+        self.flag, self.den, self.v, self.unit, self.size = flag, den, v, unit, np.float32(0)
+
+
+def _note(st, *vals):
+    for x in vals:
+        b = abs(int(x)).bit_length()
+        if b > st.max_bits:
+            st.max_bits = b
+
+
+def _note_arr(st, a):
+    if len(a):
+        m = max(abs(int(a.max())), abs(int(a.min())))
+        b = m.bit_length()
+        if b > st.max_bits:
+            st.max_bits = b
+        return b
+    return 0
+
+
+def sort_rows(rows, nvar, nligne):
+    """traiter.c:576-614 for rows with denominator 1 (a freshly loaded tableau)."""
+    smax = 0.0
+    for i in range(nvar, nligne):
+        r = rows[i]
+        if r.flag & UNIT:
+            continue
+        assert r.den == 1
+        s = 0.0
+        for x in r.v[:nvar]:
+            x = int(x)
+            # (int)((double)x / 1.0) as cvttsd2si computes it: INT_MIN out of range, and abs(INT_MIN)
+            # stays negative so it never wins the max
+            if -2**31 < x < 2**31:
+                a = float(abs(x))
+                if a > s:
+                    s = a
+        r.size = np.float32(s)
+        if s > smax:
+            smax = s
+    for i in range(nvar, nligne):
+        if rows[i].flag & UNIT:
+            continue
+        s = smax
+        pivi = i
+        for j in range(i, nligne):
+            if rows[j].flag & UNIT:
+                continue
+            if float(rows[j].size) < s:
+                s = float(rows[j].size)
+                pivi = j
+        if pivi != i:
+            rows[pivi], rows[i] = rows[i], rows[pivi]
+
+
+def _cell(rows, k, j):
+    """traiter.c valeur(): a unit row is its denominator (1) in its own column."""
+    r = rows[k]
+    if r.flag & UNIT:
+        return r.den if r.unit == j else 0
+    return int(r.v[j])
+
+
+def pick_column(rows, pivi, nvar, nligne, st):
+    pivj, pivot = -1, 0
+    prow = rows[pivi].v
+    for j in range(nvar):
+        foo = int(prow[j])
+        if foo <= 0:
+            continue
+        if pivj < 0:
+            pivj, pivot = j, foo
+            continue
+        x = 0
+        for k in range(nligne):
+            a, b = pivot * _cell(rows, k, j), _cell(rows, k, pivj) * foo
+            x = a - b
+            _note(st, a, b, x)
+            if x != 0:
+                break
+        if x < 0:
+            pivj, pivot = j, foo
+    return pivj
+
+
+class Overflow(Exception):
+    pass
+
+
+def pivot_step(rows, det, pivi, nvar, ni, st):
+    ncol = nvar + 1
+    nligne = nvar + ni
+    st.pivots += 1
+    pivj = pick_column(rows, pivi, nvar, nligne, st)
+    if pivj < 0:
+        return -1
+    prow = rows[pivi].v
+    pivot, dpiv = int(prow[pivj]), rows[pivi].den
+    d = math.gcd(pivot, dpiv)
+    ppivot, dppiv = pivot // d, dpiv // d
+    # multi-limb determinant, traiter.c:412-446
+    for i in range(len(det)):
+        d = math.gcd(det[i], dppiv)
+        det[i] //= d
+        dppiv //= d
+    if dppiv != 1:
+        raise Overflow()
+    for i in range(len(det)):
+        if _log2(det[i]) + _log2(ppivot) < st.bits:
+            det[i] *= ppivot
+            _note(st, det[i])
+            break
+    else:
+        if len(det) + 1 >= MAXDET:
+            raise Overflow()
+        det.append(ppivot)
+    fresh = -prow
+    fresh[pivj] = dpiv
+    changed = 0
+    for k in range(nligne):
+        r = rows[k]
+        if (r.flag & UNIT) or k == pivi:
+            continue
+        foo = int(r.v[pivj])
+        d = math.gcd(pivot, foo)
+        lpiv, foo = pivot // d, foo // d
+        g = lpiv * r.den
+        _note(st, g)
+        if foo == 0 and lpiv == 1:
+            z = r.v  # z = v * 1 - q * 0: same entries; the gcd with g = den may still reduce them
+        else:
+            a, b = r.v * lpiv, prow * foo
+            z = a - b
+            z[pivj] = dpiv * foo
+            _note_arr(st, a)
+            _note_arr(st, b)
+            _note_arr(st, z)
+        gg = g
+        if gg != 1:
+            for x in z:
+                gg = math.gcd(gg, int(x))
+                if gg == 1:
+                    break
+        newden = g
+        if gg != 1:
+            z = z // gg  # exact: gg divides every entry
+            newden = g // gg
+        if newden != r.den or (z is not r.v and bool((z != r.v).any())):
+            changed += 1
+        r.v, r.den = z, newden
+    for k in range(nligne):
+        if (rows[k].flag & UNIT) and rows[k].unit == pivj:
+            break
+    else:
+        raise AssertionError("no unit row for the pivot column")
+    rows[k] = _Row(PLUS, pivot, fresh)
+    rows[pivi] = _Row(UNIT | ZERO, 1, None, pivj)
+    mb = 0
+    for k in range(nligne):
+        r = rows[k]
+        if r.flag & UNIT:
+            continue
+        b = max(abs(int(r.v.max())), abs(int(r.v.min())), r.den).bit_length()
+        if b > mb:
+            mb = b
+        ff, fff = r.flag, _sgn(int(r.v[pivj]))
+        if fff != ZERO and fff != ff:
+            ff = (UNKNOWN if fff == MINUS else fff) if ff == ZERO else UNKNOWN
+        r.flag = ff
+    if mb > st.max_entry_bits:
+        st.max_entry_bits = mb
+    st.rows_changed.append(changed)
+    st.entry_bits.append(mb)
+    st.nrows.append(ni)
+    return 0
+
+
+def gomory(rows, nvar, ni, st):
+    """integrer.c:305-486 for nparm = 0: index of the appended cut row, 0 (all integral), -1 (nil)."""
+    nligne = nvar + ni
+    for i in range(nvar):
+        r = rows[i]
+        D = r.den
+        if D == 1 or (r.flag & UNIT):
+            continue
+        cut = r.v % D  # D > 0: Python's % is piplib_llmod (integrer.c:69-74)
+        ok_var = bool((cut[:nvar] > 0).any())
+        x = -((-int(r.v[nvar])) % D)
+        cut[nvar] = x
+        if x == 0:
+            continue  # integral row
+        if not ok_var:
+            return -1
+        rows.append(_Row(MINUS, D, cut))
+        assert len(rows) == nligne + 1
+        st.cuts += 1
+        return nligne
+    return 0
+
+
+def solve(ineq, integer=True, bits=64) -> Result:
+    """ineq: (ni, nvar+1) integers (unknowns | constant).  Returns what traiter() leaves on the
+    solution tape for a problem without parameters."""
+    ineq = np.asarray(ineq, dtype=object)
+    ni, ncol = ineq.shape
+    nvar = ncol - 1
+    st = Stats(bits)
+    rows = [_Row(UNIT, 1, None, i) for i in range(nvar)]
+    rows += [_Row(UNKNOWN, 1, np.array([int(x) for x in ineq[i]], dtype=object)) for i in range(ni)]
+    for r in rows[nvar:]:
+        _note_arr(st, r.v)
+    det = [1]
+    sort_rows(rows, nvar, nvar + ni)
+    status = None
+    try:
+        while True:
+            nligne = nvar + ni
+            pivi = next((i for i in range(nligne) if rows[i].flag & MINUS), nligne)
+            if pivi >= nligne:
+                # exam_coef with no parameters: an Unknown row gets the sign of its constant term;
+                # stop at the first one proven negative
+                for i in range(nligne):
+                    r = rows[i]
+                    if r.flag != UNKNOWN:
+                        continue
+                    r.flag = _sgn(int(r.v[nvar]))
+                    if r.flag == MINUS:
+                        pivi = i
+                        break
+            if pivi >= nligne:
+                if not integer:
+                    status = ST_SOLUTION
+                    break
+                pivi = gomory(rows, nvar, ni, st)
+                if pivi == 0:
+                    status = ST_SOLUTION
+                    break
+                if pivi < 0:
+                    status = ST_NIL
+                    break
+                ni += 1
+            if pivot_step(rows, det, pivi, nvar, ni, st) < 0:
+                status = ST_NIL
+                break
+    except Overflow:
+        return Result(ST_OVERFLOW, st.pivots, st.cuts, None, None, st)
+    if status == ST_SOLUTION:
+        num = [0 if (rows[i].flag & UNIT) else int(rows[i].v[nvar]) for i in range(nvar)]
+        den = [1 if (rows[i].flag & UNIT) else int(rows[i].den) for i in range(nvar)]
+        return Result(status, st.pivots, st.cuts, num, den, st)
+    return Result(status, st.pivots, st.cuts, None, None, st)
+
+
+def solution_text(num, den):
+    """sol_edit text of the solution list (sol.c:335-378), as tests/gpu_common.solution_text."""
+    out = ["(list "]
+    for n, d in zip(num, den):
+        g = math.gcd(n, d)
+        out.append("#[ %d]\n" % (n // g) if g == d else "#[ %d/%d]\n" % (n // g, d // g))
+    out.append(")\n")
+    return "".join(out)
