@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- pivots/s of the HIP PIP engine on BASELINE.json's headline workload.
+"""bench.py -- pivots/s of the HIP PIP engine on BASELINE.json's workloads.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on): per GPU a batch of
+Headline workload (BASELINE.json configs[2], the one the metric is quoted on): per GPU a batch of
 10,000 synthetic 64x128 int64 tableaux (nvar = 127 unknowns, 64 inequality rows, constant
 column; no parameters), integer solve with Gomory cuts, one workgroup per tableau.
 A "step" = tab_get-style load of the batch into the HBM row store + the whole traiter()
 pivot loop for every tableau (inputs are resident in HBM before the timed region).
-Steps are pipelined: up to --pipeline (default 12) batches are in flight on separate HIP streams
-(each step is a complete load + solve of its batch); ms_per_step is total time / steps.
-Multi-GPU: independent problems, so each rank owns its own batch (weak scaling, no
-data-path collective); RCCL is used only to gather the totals.
+Steps are pipelined: up to --pipeline (default 12) batches are in flight on separate HIP streams,
+each lane with its own batch (own seed), engine and workspace (each step is a complete load +
+solve of its batch); ms_per_step is total time / steps.  `pipeline1_value` is the same workload
+with one batch at a time.  `other_configs` carries BASELINE configs[1] and configs[4] measured the
+same way (shorter runs).
+Multi-GPU: independent problems, so each rank owns its own batches (weak scaling, no data-path
+collective; --scaling strong shards one 10k batch, BASELINE configs[3]); RCCL only sums totals.
 
 Prints ONE JSON line (rank 0).
 """
@@ -20,48 +23,205 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-NVAR, NI, NPARM = 127, 64, 0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+# name, tableaux per batch, unknowns, rows, integer solve?, entry bits, generator keywords
+MAIN = dict(key="configs[2]", workload="10k-batch synthetic 64x128 tableaux, int64, integer solve with Gomory cuts",
+            batch=10000, nvar=127, ni=64, integer=True, ebits=64, gen={})
+OTHERS = [
+    dict(key="configs[1]", workload="1k-batch synthetic 32x64 tableaux, int64, rational (non-integer) solve",
+         batch=1000, nvar=63, ni=32, integer=False, ebits=64, gen={}),
+    # coefficients up to 30 in up to 6 columns per row: the determinant limbs of the int64 build overflow
+    # on these ("Integer overflow", traiter.c:424,442), the 128-bit Entier build solves them
+    dict(key="configs[4]", workload="1k-batch synthetic 128x256 tableaux, 128-bit Entier, integer solve "
+                                    "(inputs on which the int64 build stops with 'Integer overflow')",
+         batch=1000, nvar=255, ni=128, integer=True, ebits=128, gen=dict(nnz=6, cmax=30)),
+]
 
-def cpu_baseline(rows, max_procs):
-    """Reference CPU path (oracle/_ref, the real piplib int64 build) on a bounded sample of
-    the same workload, one process per host core; falls back to the CPU restatement
-    ("port") if the reference build did not travel."""
+
+def cpu_baseline(rows, nvar, ni):
+    """The reference CPU path on a bounded sample of the headline workload, one process per host
+    core: oracle/_ref/refpip_fast (the reference's five sources + our driver in one -O3 executable,
+    no pivot counter in the timed path); pivots are counted in a second, untimed pass of the
+    counting build.  Falls back to the CPU restatement ("port") if the reference build did not
+    travel."""
     import concurrent.futures as cf
     import numpy as np
     import pipbatch as pb
     from piplib_amd import synth
-    exe, kind = (pb.REFPIP, "reference") if pb.have_ref() else (pb.ORACLEPIP, "port")
-    if not os.access(exe, os.X_OK):
+    fast = pb.REFPIP + "_fast"
+    if os.access(fast, os.X_OK) and pb.have_ref():
+        exe, counter, kind = fast, pb.REFPIP, "reference"
+    elif pb.have_ref():
+        exe, counter, kind = pb.REFPIP, None, "reference"
+    elif os.access(pb.ORACLEPIP, os.X_OK):
+        exe, counter, kind = pb.ORACLEPIP, None, "port"
+    else:
         return None
-    cores = max(1, min(max_procs, len(os.sched_getaffinity(0))))
-    per = 640  # ~50k pivots per process: ~0.6-1.3 s each, ~10-20 s of CPU work in all, bounded
-    n = min(rows.shape[0], per * cores)
-    per = max(1, n // cores)
-    chunks = [rows[c * per:(c + 1) * per] for c in range(cores)]
+    cores = max(1, len(os.sched_getaffinity(0)))
+    # ~25k pivots per process (about 0.3-0.7 s each); all of the batch at most
+    per = max(1, min(320, rows.shape[0] // cores))
+    # on a many-core host a process's share of the batch is small: solve it `reps` times over, so
+    # that every process runs for a few tenths of a second (about 10-30 s of CPU work in all)
+    reps = max(1, min(8, 160 // per))
+    chunks = [np.concatenate([rows[c * per:(c + 1) * per]] * reps) for c in range(cores)]
 
-    def run(chunk):
-        probs = [synth.Problem(NVAR, NPARM, NI, 0, -1, 1, chunk[b], np.zeros((0, NPARM + 1), np.int64))
-                 for b in range(chunk.shape[0])]
-        return pb.run_batch(exe, probs, pb.F_NOSIMPLIFY | pb.F_NOTEXT)
+    def run_with(x):
+        def run(chunk):
+            probs = [synth.Problem(nvar, 0, ni, 0, -1, 1, chunk[b], np.zeros((0, 1), np.int64))
+                     for b in range(chunk.shape[0])]
+            return pb.run_batch(x, probs, pb.F_NOSIMPLIFY | pb.F_NOTEXT)
+        with cf.ThreadPoolExecutor(cores) as ex:
+            return list(ex.map(run, chunks))
 
+    run_with(exe)  # warm the page cache / CPU clocks
     t0 = time.time()
-    with cf.ThreadPoolExecutor(cores) as ex:
-        outs = list(ex.map(run, chunks))
+    outs = run_with(exe)
     wall = time.time() - t0
-    piv = sum(o.total_pivots for o in outs)
+    piv = sum(o.total_pivots for o in (run_with(counter) if counter else outs))
     tmax = max(o.solve_seconds for o in outs)
-    return {"value": piv / tmax, "unit": "pivots/s", "cores": cores, "kind": kind,
-            "sample": f"first {per * cores} tableaux of rank 0's batch ({piv} pivots), {cores} processes x "
-                      f"{per} tableaux, slowest process {tmax:.2f} s solve time (wall {wall:.1f} s incl. I/O)",
+    model = "?"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": piv / tmax, "unit": "pivots/s", "cores": cores, "kind": kind, "cpu": model,
+            "build": "gcc -O3 -fomit-frame-pointer, one executable (oracle/Makefile refpip_fast)" if exe == fast else "see oracle/Makefile",
+            "sample": f"first {per * cores} tableaux of rank 0's first batch, {cores} processes x {per} tableaux x "
+                      f"{reps} repeats ({piv} pivots), slowest process {tmax:.2f} s of traiter() time "
+                      f"(wall {wall:.1f} s incl. I/O)",
             "per_core": piv / sum(o.solve_seconds for o in outs)}
+
+
+class Lanes:
+    """`depth` batches in flight, each with its own engine, workspace, input rows (own seed), HIP
+    stream and host thread: while one batch's last stragglers finish (a latency-bound tail that
+    leaves most CUs idle) the other batches' bulk launches run.  Every step is a full load + solve."""
+
+    def __init__(self, cfg, depth, dev, local, seeds, args, gen=None):
+        import torch
+        from piplib_amd import engine as eng
+        from piplib_amd import synth
+        self.torch, self.eng, self.cfg, self.dev, self.depth = torch, eng, cfg, dev, depth
+        self.lanes = []
+        gen = gen or (lambda seed: synth.lexmin_batch(seed, cfg["batch"], cfg["nvar"], cfg["ni"], **cfg["gen"]))
+        for i in range(depth):
+            e = eng.Engine(local)
+            if args.waves:
+                e.set_waves_per_job(args.waves)
+            if args.round:
+                e.set_round_pivots(args.round)
+            if args.round_rows:
+                e.set_round_rows(args.round_rows)
+            b = eng.Batch(e, torch.as_tensor(gen(seeds[i]), dtype=torch.int64).to(dev), cfg["nvar"], 0,
+                          tflags=eng.T_INT if cfg["integer"] else 0, entier_bits=cfg["ebits"])
+            self.lanes.append((e, b, torch.cuda.Stream(dev)))
+        self.stagger = 0.0
+        self.done = [0] * depth
+
+    def _lane(self, i, nsteps):
+        _, bi, st = self.lanes[i]
+        # lanes start a fraction of a step apart, so that one batch's under-filled last launch
+        # coincides with another batch's bulk launch instead of with its last launch
+        if self.stagger > 0 and i:
+            time.sleep(i * self.stagger)
+        with self.torch.cuda.stream(st):
+            for _ in range(nsteps):
+                bi.load()
+                bi.solve()
+            st.synchronize()
+        self.done[i] += nsteps
+
+    def run(self, nsteps):
+        d = self.depth
+        share = [nsteps // d + (1 if i < nsteps % d else 0) for i in range(d)]
+        th = [threading.Thread(target=self._lane, args=(i, share[i])) for i in range(d) if share[i]]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return share
+
+    def totals(self, share):
+        """pivots, cuts, rows rewritten, tableaux, finished tableaux of `share[i]` steps of lane i"""
+        tot = [0, 0, 0, 0, 0]
+        for (e, b, _), n in zip(self.lanes, share):
+            if not n:
+                continue
+            c = b.counters()
+            tot[0] += n * c["pivots"]
+            tot[1] += n * c["cuts"]
+            tot[2] += n * c["rows_rewritten"]
+            tot[3] += n * b.desc.batch
+            tot[4] += n * c["finished"]
+        return tot
+
+
+def lane_count(pipeline, steps):
+    depth = max(1, min(pipeline, steps))
+    # every lane should time the same number of steps: prefer a lane count that divides --steps
+    for d in range(depth, max(1, depth // 2) - 1, -1):
+        if steps % d == 0:
+            return d
+    return depth
+
+
+def timed(lanes, steps, warmup, barrier, stagger_arg):
+    lanes.run(max(warmup, lanes.depth))
+    barrier()
+    if lanes.depth > 1 and stagger_arg != 0:
+        if stagger_arg > 0:
+            lanes.stagger = stagger_arg * 1e-3
+        else:  # one lane's own step latency with every lane busy, spread evenly over the lanes
+            tw = time.perf_counter()
+            lanes.run(lanes.depth)
+            lanes.torch.cuda.synchronize(lanes.dev)
+            lanes.stagger = (time.perf_counter() - tw) / lanes.depth
+        barrier()
+    t0 = time.perf_counter()
+    share = lanes.run(steps)
+    barrier()
+    return time.perf_counter() - t0, share
+
+
+def roofline_of(b, e, k_ms, cfg, extra=None):
+    """Algorithmic HBM bytes of the pivots of one step of THIS algorithm: read
+    the pivot row, write the row that replaces the entering unit row, read+write every row that
+    actually changes (counted by the kernel) -- rows with a zero multiplier keep their bits --
+    over the kernel's own launch durations (HIP events on its stream, un-pipelined)."""
+    c = b.counters()
+    eb = 16.0 if cfg["ebits"] == 128 else 8.0
+    ncol = cfg["nvar"] + 1
+    algo = eb * ncol * (2.0 * c["rows_rewritten"] + 2.0 * c["pivots"])
+    ach = algo / (k_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": None, "kernel": "pip_advance_kernel", "kernel_ms": k_ms,
+         "launches_per_step": e.last_solve_launches(),
+         "avg_launch_ms": k_ms / max(1, e.last_solve_launches()),
+         "algorithmic_bytes_per_step": algo,
+         "rows_rewritten_per_pivot": c["rows_rewritten"] / max(1, c["pivots"])}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def kernel_ms_of(b, reps=2):
+    ms = []
+    for _ in range(reps):
+        b.load()
+        b.solve()
+        ms.append(b.last_solve_ms())
+    return sum(ms) / len(ms)
 
 
 def main():
@@ -80,6 +240,7 @@ def main():
                     help="ms between the lanes' starts (0 = none, <0 = step latency / lanes, measured in warm-up)")
     ap.add_argument("--no-dense", action="store_true", help="skip the row-skipping-off measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-others", action="store_true", help="skip other_configs and pipeline1_value")
     args = ap.parse_args()
 
     # Batches in flight run on separate HIP streams; the runtime multiplexes streams onto
@@ -104,189 +265,154 @@ def main():
     dev = torch.device("cuda", local)
     pdist.init(backend, dev)
 
-    if args.scaling == "strong":  # BASELINE configs[3]: one 10k batch sharded over the GPUs
-        lo, hi = pdist.shard_range(args.batch, rank, world)
-        rows_h = synth.lexmin_batch(1000, args.batch, NVAR, NI)[lo:hi]
-    else:
-        rows_h = synth.lexmin_batch(pdist.shard_seed(1000, rank), args.batch, NVAR, NI)
-    my_batch = rows_h.shape[0]
-    rows_d = torch.as_tensor(rows_h, dtype=torch.int64).to(dev)
-
-    # `depth` batches in flight, each with its own engine, workspace, HIP stream and host thread:
-    # while one batch's last stragglers finish (a latency-bound tail that leaves most CUs idle)
-    # the next batch's bulk rounds already run.  Every step is still a full load + solve.
-    depth = max(1, min(args.pipeline, args.steps))
-    # every lane should time the same number of steps: prefer a lane count that divides --steps
-    for d in range(depth, max(1, depth // 2) - 1, -1):
-        if args.steps % d == 0:
-            depth = d
-            break
-    lanes = []
-    for _ in range(depth):
-        e = eng.Engine(local)
-        if args.waves:
-            e.set_waves_per_job(args.waves)
-        if args.round:
-            e.set_round_pivots(args.round)
-        if args.round_rows:
-            e.set_round_rows(args.round_rows)
-        lanes.append((e, eng.Batch(e, rows_d, NVAR, NPARM, tflags=eng.T_INT), torch.cuda.Stream(dev)))
-    e, b, _ = lanes[0]
-
     def barrier():
         torch.cuda.synchronize(dev)
         pdist.barrier()
         torch.cuda.synchronize(dev)
 
-    stagger = [0.0]
+    cfg = dict(MAIN)
+    cfg["batch"] = args.batch
+    depth = lane_count(args.pipeline, args.steps)
+    # lane i of rank r draws its own batch: seed 1000 + r + 7919 * i
+    seeds = [pdist.shard_seed(1000, rank) + 7919 * i for i in range(depth)]
+    gen = None
+    if args.scaling == "strong":  # BASELINE configs[3]: every 10k-tableau batch is sharded over the GPUs
+        lo, hi = pdist.shard_range(args.batch, rank, world)
+        cfg["batch"] = hi - lo
+        seeds = [1000 + 7919 * i for i in range(depth)]
 
-    def run_lane(i, nsteps):
-        _, bi, st = lanes[i]
-        # lanes start a fraction of a step apart, so that one batch's under-filled last rounds
-        # coincide with another batch's bulk rounds instead of with its last rounds
-        if stagger[0] > 0 and i:
-            time.sleep(i * stagger[0])
-        with torch.cuda.stream(st):
-            for _ in range(nsteps):
-                bi.load()
-                bi.solve()
-            st.synchronize()
+        def gen(seed):
+            return synth.lexmin_batch(seed, args.batch, cfg["nvar"], cfg["ni"])[lo:hi]
+    lanes = Lanes(cfg, depth, dev, local, seeds, args, gen)
+    my_batch = cfg["batch"]
+    e, b, _ = lanes.lanes[0]
 
-    def run_steps(nsteps):
-        import threading
-        share = [nsteps // depth + (1 if i < nsteps % depth else 0) for i in range(depth)]
-        th = [threading.Thread(target=run_lane, args=(i, share[i])) for i in range(depth) if share[i]]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-
-    run_steps(max(args.warmup, depth))
-    barrier()
-    if depth > 1 and args.stagger != 0:
-        if args.stagger > 0:
-            stagger[0] = args.stagger * 1e-3
-        else:  # one lane's own step latency with every lane busy, spread evenly over the lanes
-            tw = time.perf_counter()
-            run_steps(depth)
-            torch.cuda.synchronize(dev)
-            stagger[0] = (time.perf_counter() - tw) / depth
-        barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, share = timed(lanes, args.steps, args.warmup, barrier, args.stagger)
+    tot = lanes.totals(share)
 
     # the advance kernel's own launch durations (HIP events on its stream), un-overlapped
-    kernel_ms = []
-    for _ in range(2):
-        b.load()
-        b.solve()
-        kernel_ms.append(b.last_solve_ms())
+    k_ms = kernel_ms_of(b)
     torch.cuda.synchronize(dev)
+    gt, dt_max = pdist.gather_totals(tot, dt, dev)
 
-    b.fetch()
-    torch.cuda.synchronize(dev)
-    st = b.status.cpu().numpy()
-    piv = int(b.pivots.sum().item())
-    cuts = int(b.cuts.sum().item())
-    solved = int(((st == eng.ST_SOLUTION) | (st == eng.ST_NIL)).sum())
+    if rank != 0:
+        # ranks other than 0 only take part in the headline measurement
+        pdist.finish()
+        return
 
-    rowsw = b.counters()["rows_rewritten"]
-    tot, dt_max = pdist.gather_totals([piv, my_batch, solved, cuts, rowsw], dt, dev)
-
-    # Same workload once more with row skipping off: every real row is read and written on
-    # every pivot, which is the reference's access pattern (traiter.c:467-502) and the regime
-    # in which the row-update path is HBM-bound.  Reported beside the main number.
-    dense = None
-    if rank == 0 and not args.no_dense:
-        ed = eng.Engine(local)
-        ed.set_waves_per_job(4)  # streaming regime: four waves share a tableau's rows
-        bd = eng.Batch(ed, rows_d, NVAR, NPARM, tflags=eng.T_INT | eng.T_NOSKIP)
-        dms = []
-        for i in range(3):
-            bd.load()
-            bd.solve()
-            if i:
-                dms.append(bd.last_solve_ms())
-        cd = bd.counters()
-        dk = float(np.mean(dms))
-        # every real row (cut rows included, counted by the kernel) is read and written once per
-        # pivot, plus the pivot-row read and the write of the row that replaces the unit row
-        dbytes = 8.0 * (NVAR + NPARM + 1) * (2.0 * cd["rows_rewritten"] + 2.0 * cd["pivots"])
-        dense = {"bound": "hbm", "achieved": dbytes / (dk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": dbytes / (dk * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": dk, "pivots": cd["pivots"],
-                 "rows_rewritten_per_pivot": cd["rows_rewritten"] / max(1, cd["pivots"]),
-                 "algorithmic_bytes_per_step": dbytes,
-                 "note": "same batch with row skipping disabled (PIPAMD_T_NOSKIP, 4 waves per tableau): every "
-                         "real row is read and written on every pivot, the reference's access pattern"}
-        del bd, ed
-
-    if rank == 0:
-        ms_step = dt_max / args.steps * 1e3
-        piv_per_step = float(tot[0])
-        k_ms = float(np.mean(kernel_ms))
-        # Algorithmic HBM bytes of one pivot of THIS algorithm (DESIGN.md "Roofline"): read the
-        # pivot row, write the row that replaces the entering unit row, read+write every row that
-        # actually changes (counted by the kernel) -- rows with a zero multiplier keep their bits.
-        ncol = NVAR + NPARM + 1
-        rows_rw = float(tot[4]) / max(1.0, float(world))  # this rank's share is what its launch moved
-        piv_rank = piv
-        algo_bytes = 8.0 * ncol * (2.0 * b.counters()["rows_rewritten"] + 2.0 * piv_rank)
-        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    ms_step = dt_max / args.steps * 1e3
+    out = {
+        "metric": "pivots/sec (batched 64x128 int64 tableaux, integer solve with Gomory cuts)",
+        "value": gt[0] / dt_max,
+        "unit": "pivots/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_step,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "int64",
+        "data": "synthetic",
+        "config": {"workload": MAIN["workload"] + (" (BASELINE configs[2])" if args.scaling == "weak" else
+                                                     " sharded over the ranks (BASELINE configs[3])"),
+                   "batch_per_gpu": my_batch, "nvar": cfg["nvar"], "nparm": 0, "ni": cfg["ni"],
+                   "parallelism": f"{world} x independent batches (one workgroup per tableau)",
+                   "pipeline_depth": depth, "lane_seeds": "1000 + rank + 7919 * lane (strong: 1000 + 7919 * lane)"},
+        "problems_per_sec": gt[3] / dt_max,
+        "pivots_per_step": gt[0] / args.steps,
+        "cuts_per_step": gt[1] / args.steps,
+        "finished_fraction": gt[4] / max(1.0, gt[3]),
+        "rows_rewritten_per_pivot": gt[2] / max(1.0, gt[0]),
+    }
+    traffic = None
+    for tp in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+        tp = os.path.join(ROOT, "profiles", tp)
         if os.path.exists(tp):
             try:
                 t = json.load(open(tp))
                 if t.get("batch_per_gpu") == my_batch:
                     traffic = t["hbm_bytes_per_step"]
+                    break
             except Exception:
-                traffic = None
-        out = {
-            "metric": "pivots/sec (batched 64x128 int64 tableaux, integer solve with Gomory cuts)",
-            "value": piv_per_step / (ms_step * 1e-3),
-            "unit": "pivots/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_step,
-            "higher_is_better": True,
-            "scaling": args.scaling,
-            "vs_baseline": None,
-            "dtype": "int64",
-            "data": "synthetic",
-            "config": {"workload": "10k-batch synthetic 64x128 tableaux, int64, integer solve with Gomory cuts",
-                       "batch_per_gpu": my_batch, "nvar": NVAR, "nparm": NPARM, "ni": NI,
-                       "parallelism": f"{world} x independent batches (one workgroup per tableau)",
-                       "pipeline_depth": depth},
-            "problems_per_sec": float(tot[1]) / (ms_step * 1e-3),
-            "pivots_per_step": piv_per_step,
-            "cuts_per_step": float(tot[3]),
-            "finished_fraction": float(tot[2]) / float(tot[1]),
-            "rows_rewritten_per_pivot": float(tot[4]) / max(1.0, piv_per_step),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pip_advance_kernel", "kernel_ms": k_ms,
-                         "launches_per_step": e.last_solve_launches(),
-                         "avg_launch_ms": k_ms / max(1, e.last_solve_launches()),
-                         "measured": "HIP events around each launch, 2 un-pipelined steps after the timed "
-                                     "region (= `bench.py --pipeline 1`, the command of profiles/r01_kernel_stats.csv)",
-                         "algorithmic_bytes_per_step": algo_bytes,
-                         "timed_region_GBps": algo_bytes / (ms_step * 1e-3) / 1e9,
-                         "dense_equivalent_GBps": b.pivot_bytes() * piv_rank / (k_ms * 1e-3) / 1e9,
-                         "note": "sparse workload: ~2.7 of ~80 rows change per pivot, so the pivot loop is "
-                                 "latency/issue-bound, not HBM-bound; see roofline_dense_mode for the "
-                                 "HBM-bound regime of the same kernel"},
-        }
-        if dense:
-            out["roofline_dense_mode"] = dense
-        if not args.no_cpu:
-            cb = cpu_baseline(rows_h, 16)
-            if cb:
-                out["cpu_baseline"] = cb
-                out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
-        print(json.dumps(out), flush=True)
+                pass
+    c0 = b.counters()
+    out["roofline"] = roofline_of(b, e, k_ms, cfg, {
+        "traffic": traffic,
+        "measured": "HIP events around each launch, 2 un-pipelined steps after the timed region "
+                    "(= `bench.py --pipeline 1`, the command of profiles/r02_kernel_stats.csv)",
+        "timed_region_GBps": 8.0 * (cfg["nvar"] + 1) * (2.0 * gt[2] + 2.0 * gt[0]) / world / dt_max / 1e9,
+        "dense_equivalent_GBps": b.pivot_bytes() * c0["pivots"] / (k_ms * 1e-3) / 1e9,
+        "note": "sparse workload: ~2.7 of ~80 rows change per pivot, so the pivot loop is latency/issue-bound, "
+                "not HBM-bound; see roofline_dense_mode for the HBM-bound regime of the same kernel"})
+
+    # Same workload once more with row skipping off: every real row is read and written on
+    # every pivot, which is the reference's access pattern (traiter.c:467-502) and the regime
+    # in which the row-update path is HBM-bound.  Reported beside the main number.
+    if not args.no_dense:
+        ed = eng.Engine(local)
+        ed.set_waves_per_job(4)  # streaming regime: four waves share a tableau's rows
+        bd = eng.Batch(ed, b.rows, cfg["nvar"], 0, tflags=eng.T_INT | eng.T_NOSKIP)
+        bd.load()
+        bd.solve()
+        dk = kernel_ms_of(bd)
+        cd = bd.counters()
+        # every real row (cut rows included, counted by the kernel) is read and written once per
+        # pivot, plus the pivot-row read and the write of the row that replaces the unit row
+        dbytes = 8.0 * (cfg["nvar"] + 1) * (2.0 * cd["rows_rewritten"] + 2.0 * cd["pivots"])
+        out["roofline_dense_mode"] = {
+            "bound": "hbm", "achieved": dbytes / (dk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dbytes / (dk * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": dk, "pivots": cd["pivots"],
+            "rows_rewritten_per_pivot": cd["rows_rewritten"] / max(1, cd["pivots"]),
+            "algorithmic_bytes_per_step": dbytes,
+            "note": "same batch with row skipping disabled (PIPAMD_T_NOSKIP, 4 waves per tableau): every real row "
+                    "is read and written on every pivot, the reference's access pattern"}
+        del bd, ed
+
+    if not args.no_others and world == 1:
+        # one batch at a time (what a caller gets from a single pipamd_batch_load + pipamd_batch_solve)
+        one = Lanes.__new__(Lanes)
+        one.torch, one.eng, one.cfg, one.dev, one.depth = torch, eng, cfg, dev, 1
+        one.lanes, one.stagger, one.done = [lanes.lanes[0]], 0.0, [0]
+        n1 = max(8, min(24, args.steps))
+        dt1, sh1 = timed(one, n1, 2, barrier, 0)
+        t1 = one.totals(sh1)
+        out["pipeline1_value"] = t1[0] / dt1
+        out["pipeline1_ms_per_step"] = dt1 / n1 * 1e3
+        del lanes
+        torch.cuda.empty_cache()
+        others = []
+        for oc in OTHERS:
+            od = lane_count(args.pipeline, 4 * args.pipeline)
+            ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args)
+            osteps = 8 * od
+            odt, osh = timed(ol, osteps, od, barrier, args.stagger)
+            ot = ol.totals(osh)
+            oe, ob, _ = ol.lanes[0]
+            okm = kernel_ms_of(ob)
+            o1 = Lanes.__new__(Lanes)
+            o1.torch, o1.eng, o1.cfg, o1.dev, o1.depth = torch, eng, oc, dev, 1
+            o1.lanes, o1.stagger, o1.done = [ol.lanes[0]], 0.0, [0]
+            odt1, osh1 = timed(o1, 16, 2, barrier, 0)
+            ot1 = o1.totals(osh1)
+            others.append({
+                "config": oc["key"], "workload": oc["workload"], "dtype": "int128" if oc["ebits"] == 128 else "int64",
+                "value": ot[0] / odt, "unit": "pivots/s", "ms_per_step": odt / osteps * 1e3, "steps": osteps,
+                "pipeline_depth": od, "problems_per_sec": ot[3] / odt, "pivots_per_step": ot[0] / osteps,
+                "finished_fraction": ot[4] / max(1, ot[3]),
+                "pipeline1_value": ot1[0] / odt1, "pipeline1_ms_per_step": odt1 / 16 * 1e3,
+                "roofline": roofline_of(ob, oe, okm, oc)})
+            del ol, o1
+            torch.cuda.empty_cache()
+        out["other_configs"] = others
+
+    if not args.no_cpu:
+        rows_h = gen(seeds[0]) if gen else synth.lexmin_batch(seeds[0], args.batch, cfg["nvar"], cfg["ni"])
+        cb = cpu_baseline(rows_h, cfg["nvar"], cfg["ni"])
+        if cb:
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+    print(json.dumps(out), flush=True)
     pdist.finish()
 
 

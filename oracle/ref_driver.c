@@ -39,8 +39,12 @@
 extern int verbose_dp;
 extern int deepest_cut_dp;
 
-/* ---- pivot counter: interposes the reference's pivoter_dp (traiter.c:345) ---- */
+/* ---- pivot counter: interposes the reference's pivoter_dp (traiter.c:345) ----
+ * Not in the REF_NO_COUNT build (oracle/_ref/refpip_fast: this driver and the five reference
+ * sources in one -O3 executable, the reference's calls bound directly): that one is only timed,
+ * it reports 0 pivots and the caller takes the counts from a pass of the counting build. */
 static long long g_pivots;
+#ifndef REF_NO_COUNT
 static int (*real_pivoter)(Tableau_dp *, int, int, int, int);
 int pivoter_dp(Tableau_dp *tp, int pivi, int nvar, int nparm, int ni) {
   if (!real_pivoter)
@@ -48,6 +52,7 @@ int pivoter_dp(Tableau_dp *tp, int pivi, int nvar, int nparm, int ni) {
   g_pivots++;
   return real_pivoter(tp, pivi, nvar, nparm, ni);
 }
+#endif
 
 /* ---- exit() trap ---- */
 static jmp_buf g_trap;

@@ -2118,6 +2118,9 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
   a.stream = stream;
   const bool one = waves_per_job == 1;
   const int wp = wp_of(Wmax, ebits);
+#ifdef PIP_ONLY_MAIN  // diagnostic builds (tools/isa_lines.sh): only the 64-bit, <= 128-column, one-wave kernel
+  return (ebits == 64 && wp == 128 && one) ? launch_advance_t<i64, 1, 1>(a) : hipErrorInvalidValue;
+#else
   if (ebits == 128) {
     switch (wp) {
       case 64: return launch_advance_w<i128, 1>(one, a);
@@ -2131,6 +2134,7 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
     case 256: return launch_advance_w<i64, 2>(one, a);
     default: return launch_advance_w<i64, 4>(one, a);
   }
+#endif
 }
 
 extern "C" hipError_t pipk_launch_advance(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,

@@ -19,8 +19,9 @@ parameter), exactly as the reference's fixed-width builds run them:
 Integers are Python ints, so nothing wraps.  `bits` is the width of the fixed-width build being
 modelled (64 = the reference's `long long` flavour, 128 = the overflow-safe flavour,
 include/piplib/piplib.h:42-88): it enters the algorithm only through the determinant limbs
-(piplib_lllog2 sums against 8*sizeof(Entier)).  Every product, difference and row entry the
-fixed-width code would form is also checked against that width: `Stats.max_bits` is the largest
+(piplib_lllog2 sums against 8*sizeof(Entier); a limb product passes that test first, so it cannot
+wrap).  Every other product, difference and row entry the fixed-width code would form is checked
+against that width: `Stats.max_bits` is the largest
 magnitude met, and a result is only comparable with a fixed-width run when
 `max_bits < bits` (no wrap-around happened) -- callers check `Stats.exact`.
 """
@@ -185,8 +186,7 @@ def pivot_step(rows, det, pivi, nvar, ni, st):
         raise Overflow()
     for i in range(len(det)):
         if _log2(det[i]) + _log2(ppivot) < st.bits:
-            det[i] *= ppivot
-            _note(st, det[i])
+            det[i] *= ppivot  # below 2^(bits-1) by the test above: never a wrap
             break
     else:
         if len(det) + 1 >= MAXDET:
