@@ -10,10 +10,10 @@
  * Two public layers, lowest first:
  *   1. pipamd_batch_*   : a *uniform* batch of tableaux that lives in HBM; one
  *                         workgroup per tableau runs the whole pivot loop on the GPU.
- *   3. pipamd_solve_*, pipamd_pip_solve
- *                       : PipLib's own front-end semantics (maind.c / pip_solve,
- *                         piplib.c:722-880) with the decision tree on the host and
- *                         every pivot on the GPU.
+ *   3. pipamd_traiter, pipamd_solve_*
+ *                       : traiter() itself (traiter.c:628) -- the quast decision tree on the
+ *                         host, every pivot on the GPU -- filling the reference's solution tape,
+ *                         so that piplib.c / maind.c / sol.c stay the reference's own.
  * (Layer 2 -- heterogeneous jobs of any shape in one arena, advanced until each is finished or
  *  needs a host decision -- is internal: it is what layer 3's quast builder drives.)
  *
@@ -145,29 +145,60 @@ int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots);
 int pipamd_engine_set_round_rows(pipamd_engine *e, int rows);
 
 /* ------------------------------------------------------------------ layer 3 */
-/* One problem in PIP's native tableau form (what maind.c reads from a .dat file):
- * host arrays, row-major int64.  `simplify` applies tab_simplify (tab.c:396) first when
- * nq != 0, as both reference front ends do.  On success *text is a malloc'ed string in
- * sol_edit format (sol.c:291) -- free with pipamd_free -- or the string "void\n" when the
- * context is empty.  Returns PIPAMD_E_SOLVER and sets *status (PIPAMD_ST_*) when the
- * reference would have aborted. */
+/* The solution tape.  traiter() does not return a value: it pushes cells onto the tape of
+ * source/sol.c (struct S, sol.c:52-59: flags, param1, param2) through sol_nil / sol_if / sol_list /
+ * sol_forme / sol_new / sol_div / sol_val (sol.c:104-209), and the reference's front ends read
+ * that tape afterwards: sol_edit (sol.c:291) prints it, sol_quast_edit (sol.c:664) turns it into a
+ * PipQuast.  The engine hands the same cells out, in the order the reference would have pushed
+ * them, so those readers keep working unchanged (INTEGRATION.md shows the few lines that replay
+ * the cells into sol.c; bindings/piplib_traiter_hook.c is that code, compiled and run by the tests). */
+#define PIPAMD_SOL_NIL 1  /* sol_nil()                       sol.c:42-50 */
+#define PIPAMD_SOL_IF 2   /* sol_if()                                    */
+#define PIPAMD_SOL_LIST 3 /* sol_list(param1)                            */
+#define PIPAMD_SOL_FORM 4 /* sol_forme(param1)                           */
+#define PIPAMD_SOL_NEW 5  /* sol_new(param1)                             */
+#define PIPAMD_SOL_DIV 6  /* sol_div()                                   */
+#define PIPAMD_SOL_VAL 7  /* sol_val(param1, param2): numerator, denominator, not reduced */
+typedef struct pipamd_sol_cell {
+  int32_t kind, reserved;
+  int64_t param1, param2;
+} pipamd_sol_cell;
+
+/* traiter(tp, ctxt, nvar, nparm, ni, nc, bigparm, flags) -- reference source/traiter.c:628, as
+ * called from pip_solve (piplib.c:858), maind.c:205 and for the empty-context test
+ * (piplib.c:848, maind.c:198).  `tableau` = the ni inequality rows of `tp` (host, row-major,
+ * nvar+nparm+1 int64 each, PIP column order unknowns|constant|parameters; Unknown rows with
+ * denominator 1, as tab_get / tab_Matrix2Tableau build them), `context` = the nc rows of `ctxt`
+ * (nparm+1 each), flags = 0, PIPAMD_T_INT or PIPAMD_T_DUAL (funcall.h:32-33), deepest_cut = the
+ * reference's global of that name (piplib.c:53).  The quast decision tree runs on the host, every
+ * pivot on the GPU.  On success *cells is a malloc'ed array of *n_cells cells (free with
+ * pipamd_free).  Where the reference would have exit()ed ("Integer overflow", ...) the call
+ * returns PIPAMD_E_SOLVER and *status holds the PIPAMD_ST_* reason. */
+int pipamd_traiter(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int flags, int deepest_cut,
+                   const int64_t *tableau, const int64_t *context, pipamd_sol_cell **cells, size_t *n_cells,
+                   int *status, int64_t *pivots);
+
+/* One problem in PIP's native tableau form (what maind.c reads from a .dat file): the whole of
+ * maind.c:190-231 -- tab_simplify (tab.c:396) first when nq != 0 and `simplify`, the
+ * empty-context test, then traiter.  An empty tape (*n_cells == 0) with PIPAMD_OK is maind.c's
+ * "void" (empty context). */
 int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int nq,
                          const int64_t *ineq, const int64_t *ctx, int simplify, int deepest_cut,
-                         char **text, int *status, int64_t *pivots);
+                         pipamd_sol_cell **cells, size_t *n_cells, int *status, int64_t *pivots);
 void pipamd_free(void *p);
 
 /* The same for `n` independent problems: `nthreads` host threads, each with its own decision
- * tree, device arena and HIP stream, share the GPU (their launches overlap).  texts[i] / rcs[i] /
- * statuses[i] / pivots[i] are what pipamd_solve_tableau returns for problem i (statuses and
- * pivots may be NULL). */
+ * tree, device arena and HIP stream, share the GPU (their launches overlap).  cells[i] /
+ * n_cells[i] / rcs[i] / statuses[i] / pivots[i] are what pipamd_solve_tableau returns for
+ * problem i (statuses and pivots may be NULL). */
 typedef struct pipamd_problem {
   int32_t nvar, nparm, ni, nc, bigparm, nq;
   const int64_t *ineq; /* ni x (nvar+nparm+1) */
   const int64_t *ctx;  /* nc x (nparm+1) */
 } pipamd_problem;
 int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
-                          int deepest_cut, int nthreads, char **texts, int *rcs, int *statuses,
-                          int64_t *pivots);
+                          int deepest_cut, int nthreads, pipamd_sol_cell **cells, size_t *n_cells, int *rcs,
+                          int *statuses, int64_t *pivots);
 
 /* The same results from a lock-step scheduler: one explicit traiter() state machine per problem
  * and, per step, ONE clone / patch / pivot-kernel / gather sequence for the whole batch, so the
@@ -175,52 +206,8 @@ int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *problem
  * a rare path (tableau growth beyond the reserved block, deepest cuts) are finished by the
  * per-problem tree of pipamd_solve_tableau. */
 int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
-                                   int deepest_cut, char **texts, int *rcs, int *statuses,
-                                   int64_t *pivots);
-
-/* pip_solve() (reference source/piplib.c:722-880) with the same argument meaning.  The
- * structures below have the memory layout of the reference's int64 ("dp" / piplib64) types
- * PipMatrix, PipVector, PipNewparm, PipList, PipQuast and PipOptions
- * (include/piplib/piplib.h:194-329), and every node of the returned tree is malloc'ed on its
- * own, so the reference's pip_quast_print / pip_quast_free can be applied to it directly.
- * *quast is NULL for the reference's "void" answers. */
-typedef struct pipamd_matrix {
-  unsigned int NbRows, NbColumns;
-  long long **p;
-  long long *p_Init;
-  int p_Init_size;
-} pipamd_matrix;
-typedef struct pipamd_vector {
-  int nb_elements;
-  long long *the_vector;
-  long long *the_deno;
-} pipamd_vector;
-typedef struct pipamd_newparm {
-  int rank;
-  pipamd_vector *vector;
-  long long deno;
-  struct pipamd_newparm *next;
-} pipamd_newparm;
-typedef struct pipamd_list {
-  pipamd_vector *vector;
-  struct pipamd_list *next;
-} pipamd_list;
-typedef struct pipamd_quast {
-  pipamd_newparm *newparm;
-  pipamd_list *list;
-  pipamd_vector *condition;
-  struct pipamd_quast *next_then, *next_else, *father;
-} pipamd_quast;
-typedef struct pipamd_options {
-  int Nq, Verbose, Simplify, Deepest_cut, Maximize, Urs_parms, Urs_unknowns, Compute_dual;
-} pipamd_options;
-
-int pipamd_pip_solve(pipamd_engine *e, const pipamd_matrix *domain, const pipamd_matrix *context,
-                     int bignum, const pipamd_options *options, pipamd_quast **quast, int *status,
-                     int64_t *pivots);
-void pipamd_quast_free(pipamd_quast *q);
-/* pip_quast_print (piplib.c:290-317) into a malloc'ed string (free with pipamd_free) */
-char *pipamd_quast_to_string(const pipamd_quast *q, int indent);
+                                   int deepest_cut, pipamd_sol_cell **cells, size_t *n_cells, int *rcs,
+                                   int *statuses, int64_t *pivots);
 
 #ifdef __cplusplus
 }

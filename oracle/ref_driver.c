@@ -44,7 +44,12 @@ extern int deepest_cut_dp;
  * sources in one -O3 executable, the reference's calls bound directly): that one is only timed,
  * it reports 0 pivots and the caller takes the counts from a pass of the counting build. */
 static long long g_pivots;
-#ifndef REF_NO_COUNT
+#ifdef REF_GPU_HOOK
+/* oracle/_ref/refpip_gpu: traiter_dp is bound to bindings/piplib_traiter_hook.c (-Dtraiter_dp=...),
+ * the pivots run on the GPU and the hook counts them */
+extern long long pipamd_hook_pivots;
+#define g_pivots pipamd_hook_pivots
+#elif !defined(REF_NO_COUNT)
 static int (*real_pivoter)(Tableau_dp *, int, int, int, int);
 int pivoter_dp(Tableau_dp *tp, int pivi, int nvar, int nparm, int ni) {
   if (!real_pivoter)

@@ -106,7 +106,12 @@ class Tree {
  public:
   Tree(pipamd_engine *e, int deepest) : deepest_(deepest) {
     (void)e;
-    if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) st_ = 0;
+    const hipError_t err = hipStreamCreateWithFlags(&st_, hipStreamNonBlocking);
+    if (err != hipSuccess) {  // never fall back to the null stream: it would serialise every tree of the process
+      st_ = 0;
+      pipamd_set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(err));
+      throw (int)PIPAMD_E_HIP;
+    }
   }
   ~Tree() {
     if (d_arena_) hipFree(d_arena_);
@@ -126,6 +131,19 @@ class Tree {
   bool dual_ = false;  // Compute_dual (rational solves only, piplib.c:854-857)
   long long pivots = 0;
   int fail_status = 0;
+
+  // traiter() itself (traiter.c:628): one call on a freshly built tableau and context, what
+  // piplib.c:858 and maind.c:205 hand to it; the tape receives what traiter would have emitted
+  void traiter_call(int nvar, int nparm, int ni, int nc, int bigparm, int tfl, const i64 *ineq, const i64 *ctxrows) {
+    Ctx ctx;
+    ctx.reserve(nc + 4, nparm + 2);
+    ctx.nc = nc;
+    for (int r = 0; r < nc; r++)
+      for (int c = 0; c <= nparm; c++) ctx.at(r, c) = ctxrows[(size_t)r * (nparm + 1) + c];
+    dual_ = (tfl & PIPAMD_T_DUAL) != 0;
+    HostJob job = make_job(nvar, nparm, ni, bigparm, tfl, ineq);
+    node(job, ctx, nvar, nparm, ni, bigparm, tfl);
+  }
 
   // maind.c:196-231: context emptiness test, then traiter
   bool front(int nvar, int nparm, int ni, int nc, int bigparm, int nq, const i64 *ineq, const i64 *ctxrows) {
@@ -189,6 +207,24 @@ class Tree {
     arena_words_ = nw;
   }
   static int even(int x) { return (x + 1) & ~1; }
+  static bool rows_fit(int nvar, int S, int W) {
+    return S <= PIPAMD_SMAX && nvar + S <= PIPAMD_LMAX &&
+           pipk_advance_lds_bytes((even(nvar + S) + 3) & ~3, (S + 3) & ~3, W, 64) <= PIPAMD_LDS_BUDGET;
+  }
+  // Row capacity of the block a job that ran out of rows is re-housed in: geometric growth (a
+  // sub-problem may need thousands of cut rows, and every re-housing copies the whole tableau),
+  // clamped to the largest row count whose LDS image still fits a workgroup -- S+1 when not even
+  // that fits, which alloc_job then refuses with PIPAMD_ST_CAPACITY.
+  static int next_rows(int nvar, int S, int W) {
+    const int want = std::max(S + 32, S * 3 / 2);
+    if (rows_fit(nvar, want, W) || !rows_fit(nvar, S + 1, W)) return rows_fit(nvar, want, W) ? want : S + 1;
+    int lo = S + 1, hi = want;  // lo fits, hi does not
+    while (hi - lo > 1) {
+      const int mid = lo + (hi - lo) / 2;
+      (rows_fit(nvar, mid, W) ? lo : hi) = mid;
+    }
+    return lo;
+  }
 
   HostJob alloc_job(int nvar, int nparm, int ni, int bigparm, int tflags, int S, int W) {
     HostJob j;
@@ -329,10 +365,7 @@ class Tree {
       for (int i = 0; i < n; i++) {
         js[i]->pj = tab[i];
         if (tab[i].status == PIPAMD_ST_CAPACITY) {
-          // geometric growth (as far as the engine's row limit allows): a sub-problem may need
-          // thousands of cut rows, and every re-housing copies the whole tableau
-          grow(*js[i], std::min(std::max(js[i]->pj.S + 32, js[i]->pj.S * 3 / 2), std::max(js[i]->pj.S + 32, (int)PIPAMD_SMAX)),
-               js[i]->pj.W);
+          grow(*js[i], next_rows(js[i]->pj.nvar, js[i]->pj.S, js[i]->pj.W), js[i]->pj.W);
           tab[i] = js[i]->pj;
           Lm = std::max(Lm, (int)tab[i].L);
           Sm = std::max(Sm, (int)tab[i].S);
@@ -717,7 +750,7 @@ class Tree {
           return;
         case PIPAMD_ST_NIL: push(S_NIL, 0, 0); return;
         case PIPAMD_ST_CAPACITY:
-          grow(job, std::min(std::max(job.pj.S + 32, job.pj.S * 3 / 2), std::max(job.pj.S + 32, (int)PIPAMD_SMAX)), job.pj.W);
+          grow(job, next_rows(nvar, job.pj.S, job.pj.W), job.pj.W);
           continue;
         case PIPAMD_ST_NEED_PARMCUT:
           if (!host_cut(job, ctx, nvar, nparm, ni, bigparm)) {
@@ -789,83 +822,6 @@ class Tree {
   }
 };
 
-// ------------------------------------------------------------------ sol_edit
-void print_ent(std::string &o, i64 x) {
-  char b[32];
-  snprintf(b, sizeof b, "%lld", x);
-  o += b;
-}
-void print_frac(std::string &o, i64 N, i64 D) {  // sol.c:343-374
-  const i64 d = gcd(N, D);
-  o += ' ';
-  print_ent(o, cquo(N, d));
-  if (d != D) {
-    o += '/';
-    print_ent(o, cquo(D, d));
-  }
-}
-size_t print_tape(const std::vector<Cell> &t, std::string &o, size_t i) {  // sol.c:291-422
-  for (;;) {
-    if (t[i].kind == S_FREE) {
-      i++;
-      continue;
-    }
-    if (t[i].kind == S_NEW) {
-      char b[48];
-      snprintf(b, sizeof b, "(newparm %d ", (int)t[i].a);
-      o += b;
-      i = print_tape(t, o, i + 1);
-      o += ")\n";
-      continue;
-    }
-    break;
-  }
-  switch (t[i].kind) {
-    case S_NIL:
-      o += "()\n";
-      i++;
-      break;
-    case S_IF:
-      o += "(if ";
-      i = print_tape(t, o, i + 1);
-      i = print_tape(t, o, i);
-      i = print_tape(t, o, i);
-      o += ")\n";
-      break;
-    case S_LIST: {
-      o += "(list ";
-      int n = (int)t[i].a;
-      i++;
-      while (n--) i = print_tape(t, o, i);
-      o += ")\n";
-      break;
-    }
-    case S_FORM: {
-      o += "#[";
-      const int n = (int)t[i].a;
-      for (int j = 0; j < n; j++) {
-        i++;
-        print_frac(o, t[i].a, t[i].b);
-      }
-      o += "]\n";
-      i++;
-      break;
-    }
-    case S_DIV:
-      o += "(div ";
-      i = print_tape(t, o, i + 1);
-      i = print_tape(t, o, i);
-      o += ")\n";
-      break;
-    case S_VAL:
-      print_frac(o, t[i].a, t[i].b);
-      i++;
-      break;
-    default: o += "Inconnu : sol\n"; i++;
-  }
-  return i;
-}
-
 // tab_simplify (tab.c:396-427) on a row-major matrix
 void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) {
   for (int i = 0; i < rows; i++) {
@@ -883,19 +839,45 @@ void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) {
 
 }  // namespace
 
-// one problem on an existing tree (device buffers and stream are reused between problems)
-static int solve_one(Tree &t, int nvar, int nparm, int ni, int nc, int bigparm, int nq, const int64_t *ineq,
-                     const int64_t *ctx, int simplify, int deepest_cut, char **text, int *status, int64_t *pivots) {
-  if (!text || nvar < 0 || nparm < 0 || ni < 0 || nc < 0 || (ni && !ineq) || (nc && !ctx)) {
-    pipamd_set_error("pipamd_solve_tableau: invalid argument");
-    return PIPAMD_E_INVALID;
+// the tape as the C ABI hands it out: (kind, param1, param2) cells, sol.c:52-59
+static int export_tape(const std::vector<Cell> &tape, pipamd_sol_cell **cells, size_t *n_cells) {
+  *n_cells = tape.size();
+  *cells = nullptr;
+  if (tape.empty()) return PIPAMD_OK;
+  pipamd_sol_cell *c = (pipamd_sol_cell *)malloc(tape.size() * sizeof *c);
+  if (!c) return PIPAMD_E_NOMEM;
+  for (size_t i = 0; i < tape.size(); i++) {
+    c[i].kind = tape[i].kind;
+    c[i].reserved = 0;
+    c[i].param1 = tape[i].a;
+    c[i].param2 = tape[i].b;
+  }
+  *cells = c;
+  return PIPAMD_OK;
+}
+
+static bool valid_shape(int nvar, int nparm, int ni, int nc, int bigparm, const void *ineq, const void *ctx) {
+  if (nvar < 0 || nparm < 0 || ni < 0 || nc < 0 || (ni && !ineq) || (nc && !ctx)) {
+    pipamd_set_error("invalid tableau shape or missing rows");
+    return false;
   }
   const int ncol = nvar + nparm + 1;
   if (bigparm >= ncol || (bigparm >= 0 && bigparm <= nvar)) {
     pipamd_set_error("bigparm must be -1 or a parameter column (nvar < bigparm < nvar+nparm+1)");
-    return PIPAMD_E_INVALID;
+    return false;
   }
-  *text = nullptr;
+  return true;
+}
+
+// one problem on an existing tree (device buffers and stream are reused between problems);
+// an empty tape with PIPAMD_OK is the front ends' "void" (empty context)
+static int solve_one(Tree &t, int nvar, int nparm, int ni, int nc, int bigparm, int nq, const int64_t *ineq,
+                     const int64_t *ctx, int simplify, int deepest_cut, pipamd_sol_cell **cells, size_t *n_cells,
+                     int *status, int64_t *pivots) {
+  if (!cells || !n_cells || !valid_shape(nvar, nparm, ni, nc, bigparm, ineq, ctx)) return PIPAMD_E_INVALID;
+  const int ncol = nvar + nparm + 1;
+  *cells = nullptr;
+  *n_cells = 0;
   if (status) *status = 0;
   if (pivots) *pivots = 0;
   std::vector<i64> a((const i64 *)ineq, (const i64 *)ineq + (size_t)ni * ncol);
@@ -905,14 +887,10 @@ static int solve_one(Tree &t, int nvar, int nparm, int ni, int nc, int bigparm, 
     simplify_rows(c, nc, nparm + 1, nparm);
   }
   t.reset(deepest_cut);
-  std::string out;
   int rc = PIPAMD_OK;
+  bool non_void = false;
   try {
-    if (t.front(nvar, nparm, ni, nc, bigparm, nq, a.data(), c.data())) {
-      size_t i = 0;
-      while (i < t.tape.size()) i = print_tape(t.tape, out, i);
-    } else
-      out = "void\n";
+    non_void = t.front(nvar, nparm, ni, nc, bigparm, nq, a.data(), c.data());
   } catch (int code) {
     rc = code;
     if (status) *status = t.fail_status;
@@ -921,44 +899,89 @@ static int solve_one(Tree &t, int nvar, int nparm, int ni, int nc, int bigparm, 
   }
   if (pivots) *pivots = t.pivots;
   if (rc) return rc;
-  *text = (char *)malloc(out.size() + 1);
-  if (!*text) return PIPAMD_E_NOMEM;
-  memcpy(*text, out.c_str(), out.size() + 1);
-  return PIPAMD_OK;
+  return non_void ? export_tape(t.tape, cells, n_cells) : PIPAMD_OK;
 }
 
 extern "C" int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int nq,
-                                    const int64_t *ineq, const int64_t *ctx, int simplify, int deepest_cut, char **text,
-                                    int *status, int64_t *pivots) {
+                                    const int64_t *ineq, const int64_t *ctx, int simplify, int deepest_cut,
+                                    pipamd_sol_cell **cells, size_t *n_cells, int *status, int64_t *pivots) {
   if (!e) return PIPAMD_E_INVALID;
   if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
-  Tree t(e, deepest_cut);
-  return solve_one(t, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify, deepest_cut, text, status, pivots);
+  try {
+    Tree t(e, deepest_cut);
+    return solve_one(t, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify, deepest_cut, cells, n_cells, status, pivots);
+  } catch (int code) {
+    return code;
+  }
+}
+
+// traiter() (traiter.c:628-791) behind the reference's own front ends: see include/piplib_amd.h
+extern "C" int pipamd_traiter(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int flags,
+                              int deepest_cut, const int64_t *tableau, const int64_t *context,
+                              pipamd_sol_cell **cells, size_t *n_cells, int *status, int64_t *pivots) {
+  if (!e || !cells || !n_cells || !valid_shape(nvar, nparm, ni, nc, bigparm, tableau, context)) return PIPAMD_E_INVALID;
+  if ((flags & ~(PIPAMD_T_INT | PIPAMD_T_DUAL)) || ((flags & PIPAMD_T_INT) && (flags & PIPAMD_T_DUAL))) {
+    pipamd_set_error("pipamd_traiter: flags must be 0, PIPAMD_T_INT or PIPAMD_T_DUAL (the dual needs a rational solve)");
+    return PIPAMD_E_INVALID;
+  }
+  if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
+  *cells = nullptr;
+  *n_cells = 0;
+  if (status) *status = 0;
+  if (pivots) *pivots = 0;
+  int rc = PIPAMD_OK;
+  try {
+    Tree t(e, deepest_cut);
+    try {
+      t.traiter_call(nvar, nparm, ni, nc, bigparm, flags, (const i64 *)tableau, (const i64 *)context);
+    } catch (int code) {
+      rc = code;
+      if (status) *status = t.fail_status;
+      if (rc == PIPAMD_E_SOLVER)
+        pipamd_set_error("solver stopped with status %d (5 = the reference's \"Integer overflow\" exit)", t.fail_status);
+    }
+    if (pivots) *pivots = t.pivots;
+    if (!rc) rc = export_tape(t.tape, cells, n_cells);
+  } catch (int code) {
+    rc = code;
+  }
+  return rc;
 }
 
 // Many independent problems: `nthreads` host threads, each with its own tree (device arena and
 // HIP stream), pull problems from a shared counter; their launches overlap on the GPU.
 // rc[i] receives what pipamd_solve_tableau would have returned for problem i.
 extern "C" int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
-                                     int nthreads, char **texts, int *rcs, int *statuses, int64_t *pivots) {
-  if (!e || n < 0 || (n && (!probs || !texts || !rcs))) return PIPAMD_E_INVALID;
+                                     int nthreads, pipamd_sol_cell **cells, size_t *n_cells, int *rcs, int *statuses,
+                                     int64_t *pivots) {
+  if (!e || n < 0 || (n && (!probs || !cells || !n_cells || !rcs))) return PIPAMD_E_INVALID;
   if (nthreads < 1) nthreads = 1;
   if (nthreads > n) nthreads = n > 0 ? n : 1;
+  for (int i = 0; i < n; i++) {  // a worker that cannot even start leaves its problems marked as failed
+    rcs[i] = PIPAMD_E_HIP;
+    cells[i] = nullptr;
+    n_cells[i] = 0;
+    if (statuses) statuses[i] = 0;
+    if (pivots) pivots[i] = 0;
+  }
   std::atomic<int> next(0);
   const int device = e->device;
   auto worker = [&]() {
     if (hipSetDevice(device) != hipSuccess) return;
-    Tree t(e, deepest_cut);
-    for (;;) {
-      const int i = next.fetch_add(1);
-      if (i >= n) break;
-      const pipamd_problem &p = probs[i];
-      int st = 0;
-      int64_t pv = 0;
-      rcs[i] = solve_one(t, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx, simplify, deepest_cut, &texts[i],
-                         &st, &pv);
-      if (statuses) statuses[i] = st;
-      if (pivots) pivots[i] = pv;
+    try {
+      Tree t(e, deepest_cut);
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= n) break;
+        const pipamd_problem &p = probs[i];
+        int st = 0;
+        int64_t pv = 0;
+        rcs[i] = solve_one(t, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx, simplify, deepest_cut,
+                           &cells[i], &n_cells[i], &st, &pv);
+        if (statuses) statuses[i] = st;
+        if (pivots) pivots[i] = pv;
+      }
+    } catch (int) {  // the tree could not be set up (stream creation failed): its problems stay E_HIP
     }
   };
   std::vector<std::thread> th;
@@ -988,7 +1011,12 @@ class Forest {
  public:
   explicit Forest(int device) {
     (void)device;
-    if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) st_ = 0;
+    const hipError_t err = hipStreamCreateWithFlags(&st_, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+      st_ = 0;
+      pipamd_set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(err));
+      throw (int)PIPAMD_E_HIP;
+    }
   }
   ~Forest() {
     void *bufs[] = {d_arena_, d_jobs_, d_off_, d_out_, d_patch_, d_pidx_, d_clone_, d_fresh_, d_fidx_};
@@ -1634,8 +1662,9 @@ class Forest {
 
 // Many problems in lock step (Forest); the few that need a rare path are finished by the Tree.
 extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify,
-                                              int deepest_cut, char **texts, int *rcs, int *statuses, int64_t *pivots) {
-  if (!e || n < 0 || (n && (!probs || !texts || !rcs))) return PIPAMD_E_INVALID;
+                                              int deepest_cut, pipamd_sol_cell **cells, size_t *n_cells, int *rcs,
+                                              int *statuses, int64_t *pivots) {
+  if (!e || n < 0 || (n && (!probs || !cells || !n_cells || !rcs))) return PIPAMD_E_INVALID;
   if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
   std::vector<FResult> res(n);
   if (!deepest_cut) {
@@ -1649,15 +1678,21 @@ extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pip
   } else
     for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;
   Tree *fallback = nullptr;
+  int rc_all = PIPAMD_OK;
   for (int i = 0; i < n; i++) {
-    texts[i] = nullptr;
+    cells[i] = nullptr;
+    n_cells[i] = 0;
     if (res[i].rc == PIPAMD_E_TOOLARGE) {
-      if (!fallback) fallback = new Tree(e, deepest_cut);
       int st = 0;
       int64_t pv = 0;
       const pipamd_problem &p = probs[i];
-      rcs[i] = solve_one(*fallback, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx, simplify, deepest_cut,
-                         &texts[i], &st, &pv);
+      try {
+        if (!fallback) fallback = new Tree(e, deepest_cut);
+        rcs[i] = solve_one(*fallback, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx, simplify, deepest_cut,
+                           &cells[i], &n_cells[i], &st, &pv);
+      } catch (int code) {
+        rcs[i] = code;
+      }
       if (statuses) statuses[i] = st;
       if (pivots) pivots[i] = pv;
       continue;
@@ -1665,477 +1700,9 @@ extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pip
     rcs[i] = res[i].rc;
     if (statuses) statuses[i] = res[i].status;
     if (pivots) pivots[i] = res[i].pivots;
-    if (res[i].rc) continue;
-    std::string out;
-    if (res[i].is_void)
-      out = "void\n";
-    else {
-      size_t k = 0;
-      while (k < res[i].tape.size()) k = print_tape(res[i].tape, out, k);
-    }
-    texts[i] = (char *)malloc(out.size() + 1);
-    if (!texts[i]) {
-      rcs[i] = PIPAMD_E_NOMEM;
-      continue;
-    }
-    memcpy(texts[i], out.c_str(), out.size() + 1);
+    if (res[i].rc || res[i].is_void) continue;
+    rcs[i] = export_tape(res[i].tape, &cells[i], &n_cells[i]);
   }
   delete fallback;
-  return PIPAMD_OK;
-}
-
-// =========================================================================== pip_solve
-// The PolyLib-matrix front end (reference source/piplib.c:722-880) on top of the same tree:
-// tab_Matrix2Tableau (tab.c:292-393) and the tape -> PipQuast conversion (sol.c:435-734) are
-// host-side data conversions; the structures are layout-compatible with the reference's
-// int64 ("dp") PipMatrix / PipVector / PipNewparm / PipList / PipQuast / PipOptions
-// (include/piplib/piplib.h:194-329), every piece malloc'ed separately, so the reference's own
-// pip_quast_free / pip_quast_print work on the result.
-namespace {
-
-enum { SOL_SHIFT = 1, SOL_NEGATE = 2, SOL_REMOVE = 4, SOL_MAX = 3, SOL_DUAL = 8 }; /* sol.h:36-50 */
-
-struct TabArr {
-  int rows = 0, width = 0;
-  std::vector<i64> v;
-};
-
-// tab.c:292-393; returns the real rows only (the n leading unit rows are implicit)
-TabArr matrix_to_tab(const pipamd_matrix *m, int Nineq, int Nv, int n, int Shift, int Bg, int Urs) {
-  const int ctx = (n == -1);
-  unsigned nb_columns = m->NbColumns - 1;
-  const bool bignum_is_new = Shift && (Bg + ctx > 0) && ((unsigned)(Bg + ctx) > (m->NbColumns - 2));
-  if (bignum_is_new) nb_columns++;
-  int cst;
-  if (ctx) {
-    Shift = 0;
-    cst = Nv + Urs;
-  } else
-    cst = Nv;
-  TabArr t;
-  t.rows = Nineq;
-  t.width = (int)nb_columns + Urs;
-  t.v.assign((size_t)t.rows * t.width, 0);
-  unsigned decal = 0;
-  for (unsigned i = 0; i < m->NbRows; i++) {
-    i64 *r = &t.v[(size_t)(i + decal) * t.width];
-    const i64 *src = m->p[i];
-    i64 big = 0;
-    const bool inequality = src[0] != 0;
-    int j, k;
-    for (j = 0; j < Nv; j++) {
-      if (bignum_is_new && j == Bg) continue;
-      if (Shift) big = wadd(big, src[1 + j]);
-      r[j] = Shift > 0 ? wneg(src[1 + j]) : src[1 + j];
-    }
-    for (k = j = Nv + 1; (unsigned)j < nb_columns; j++) {
-      if (bignum_is_new && j == Bg) continue;
-      r[j] = src[k];
-      k++;
-    }
-    for (j = 0; j < Urs; ++j) {
-      int pos_n = (int)nb_columns - ctx + j, pos = pos_n - Urs;
-      if (pos <= Bg) --pos;
-      r[pos_n] = wneg(r[pos]);
-    }
-    r[cst] = src[m->NbColumns - 1];
-    if (Shift) {
-      if (Shift < 0) big = wneg(big);
-      if (bignum_is_new)
-        r[Bg] = big;
-      else
-        r[Bg] = wadd(r[Bg], big);
-    }
-    if (!inequality) {
-      decal++;
-      i64 *r2 = &t.v[(size_t)(i + decal) * t.width];
-      for (j = 0; (unsigned)j < nb_columns + (unsigned)Urs; j++) r2[j] = wneg(r[j]);
-    }
-  }
-  return t;
-}
-
-template <class T>
-T *zalloc() {
-  return (T *)calloc(1, sizeof(T));
-}
-
-// sol.c:435-512 sol_vector_edit
-pipamd_vector *q_vector(const std::vector<Cell> &t, size_t *i, int Bg, int Urs_p, int flags) {
-  const Cell *p = &t[*i];
-  int n = (int)p->a, j, k, unbounded = 0;
-  if (flags & SOL_REMOVE) --n;
-  n -= Urs_p;
-  // sol.c:452-471 walks n kept entries whatever the Form holds.  Some option combinations
-  // (Compute_dual with Urs_parms: one-entry dual Forms minus the "unrestricted" columns) give a
-  // negative length or a walk past the tape: the reference exits ("Memory Overflow") or faults
-  // there; we refuse the call instead.
-  if (n < 0 || *i + (size_t)(int)p->a >= t.size()) throw (int)PIPAMD_E_INVALID;
-  pipamd_vector *v = zalloc<pipamd_vector>();
-  const int first_urs = Urs_p + (Bg >= 0);
-  v->nb_elements = n;
-  v->the_vector = (long long *)calloc((size_t)(n > 0 ? n : 1), sizeof(long long));
-  v->the_deno = (long long *)calloc((size_t)(n > 0 ? n : 1), sizeof(long long));
-  for (j = 0, k = 0; k < n; j++) {
-    (*i)++;
-    p++;
-    if (*i >= t.size()) {
-      free(v->the_vector);
-      free(v->the_deno);
-      free(v);
-      throw (int)PIPAMD_E_INVALID;
-    }
-    i64 N = p->a, D = p->b;
-    const i64 d = gcd(N, D);
-    if ((flags & SOL_SHIFT) && j == Bg) {
-      N = wsub(N, D);
-      if (N != 0) unbounded = 1;
-    }
-    if ((flags & SOL_REMOVE) && j == Bg) continue;
-    if (first_urs <= j && j < first_urs + Urs_p) continue;
-    v->the_vector[k] = cquo(N, d);
-    if (flags & SOL_NEGATE) v->the_vector[k] = wneg(v->the_vector[k]);
-    v->the_deno[k] = (d == D) ? 1 : cquo(D, d);
-    ++k;
-  }
-  if (unbounded)
-    for (k = 0; k < n; k++) v->the_deno[k] = 0;
-  (*i)++;
-  return v;
-}
-// sol.c:525-577
-pipamd_newparm *q_newparm(const std::vector<Cell> &t, size_t *i, int Bg, int Urs_p, int flags) {
-  const Cell *p = &t[*i];
-  pipamd_newparm *first = nullptr, *last = nullptr;
-  do {
-    pipamd_newparm *np = zalloc<pipamd_newparm>();
-    (*i) += 2;
-    np->vector = q_vector(t, i, Bg, Urs_p, flags);
-    np->rank = (int)p->a;
-    p = &t[*i];
-    np->deno = p->a;
-    if (flags & SOL_REMOVE) np->rank--;
-    np->rank -= Urs_p;
-    if (last)
-      last->next = np;
-    else
-      first = np;
-    last = np;
-    (*i)++;
-    p = &t[*i];
-  } while (*i < t.size() && p->kind == S_NEW);
-  return first;
-}
-// sol.c:591-638
-pipamd_list *q_list(const std::vector<Cell> &t, size_t *i, int n, int Bg, int Urs_p, int flags) {
-  pipamd_list *head = zalloc<pipamd_list>(), *cur = head;
-  if (n == 0) return head;
-  head->vector = q_vector(t, i, Bg, Urs_p, flags);
-  while (--n) {
-    pipamd_list *nx = zalloc<pipamd_list>();
-    nx->vector = q_vector(t, i, Bg, Urs_p, flags);
-    cur->next = nx;
-    cur = nx;
-  }
-  return head;
-}
-// sol.c:664-734
-pipamd_quast *q_quast(const std::vector<Cell> &t, size_t *i, pipamd_quast *father, int Bg, int Urs_p, int flags) {
-  pipamd_quast *q = zalloc<pipamd_quast>();
-  q->father = father;
-  while (t[*i].kind == S_FREE) (*i)++;
-  const Cell *p = &t[*i];
-  if (p->kind == S_NEW) {
-    q->newparm = q_newparm(t, i, Bg, Urs_p, flags & SOL_REMOVE);
-    p = &t[*i];
-  }
-  (*i)++;
-  switch (p->kind) {
-    case S_LIST:
-      q->list = q_list(t, i, (int)p->a, Bg, Urs_p, flags);
-      if (flags & SOL_DUAL) q->next_then = q_quast(t, i, q, Bg, Urs_p, 0);
-      break;
-    case S_NIL: break;
-    case S_IF:
-      q->condition = q_vector(t, i, Bg, Urs_p, flags & SOL_REMOVE);
-      q->next_then = q_quast(t, i, q, Bg, Urs_p, flags);
-      q->next_else = q_quast(t, i, q, Bg, Urs_p, flags);
-      break;
-    default: break;
-  }
-  return q;
-}
-
-// sol.c:236-288 skip / sol_simplify on our tape
-size_t t_skip(const std::vector<Cell> &t, size_t i);
-size_t t_skip_new(const std::vector<Cell> &t, size_t i) { return t[i].kind != S_NEW ? i : t_skip(t, i + 1); }
-size_t t_skip(const std::vector<Cell> &t, size_t i) {
-  while (t[i].kind == S_FREE) i++;
-  switch (t[i].kind) {
-    case S_NIL:
-    case S_VAL: i++; break;
-    case S_NEW: i = t_skip_new(t, i); break;
-    case S_IF:
-      i = t_skip(t, i + 1);
-      i = t_skip(t, i);
-      i = t_skip(t, i);
-      break;
-    case S_LIST:
-    case S_FORM: {
-      int n = (int)t[i].a;
-      i++;
-      while (n--) i = t_skip(t, i);
-      break;
-    }
-    case S_DIV:
-      i = t_skip(t, i + 1);
-      i = t_skip(t, i);
-      break;
-    default: break;
-  }
-  return i < t.size() ? t_skip_new(t, i) : i;
-}
-void t_simplify(std::vector<Cell> &t, size_t i) {
-  if (t[i].kind != S_IF) return;
-  const size_t j = t_skip(t, i + 1), k = t_skip(t, j);
-  t_simplify(t, k);
-  t_simplify(t, j);
-  if (t[j].kind == S_NIL && t[k].kind == S_NIL) {
-    t[i].kind = S_NIL;
-    if (k + 1 >= t.size())
-      t.resize(i + 1);
-    else
-      for (size_t l = i + 1; l <= k; l++) t[l].kind = S_FREE;
-  }
-}
-
-void pr_vec(std::string &o, const pipamd_vector *v) {  // piplib.c:198-214
-  if (!v) return;
-  o += "#[";
-  for (int i = 0; i < v->nb_elements; i++) {
-    o += ' ';
-    print_ent(o, v->the_vector[i]);
-    if (v->the_deno[i] != 1) {
-      o += '/';
-      print_ent(o, v->the_deno[i]);
-    }
-  }
-  o += ']';
-}
-void pr_quast(std::string &o, const pipamd_quast *q, int indent) {  // piplib.c:225-317
-  const int ni = indent >= 0 ? indent + 1 : indent;
-  auto ind = [&](int n) {
-    for (int i = 0; i < n; i++) o += ' ';
-  };
-  if (!q) {
-    ind(indent);
-    o += "void\n";
-    return;
-  }
-  for (const pipamd_newparm *np = q->newparm; np; np = np->next) {
-    char b[48];
-    ind(indent);
-    snprintf(b, sizeof b, "(newparm %d (div ", np->rank);
-    o += b;
-    pr_vec(o, np->vector);
-    o += ' ';
-    print_ent(o, np->deno);
-    o += "))\n";
-  }
-  if (!q->condition) {
-    ind(indent);
-    if (!q->list)
-      o += "()\n";
-    else {
-      o += "(list\n";
-      for (const pipamd_list *l = q->list; l; l = l->next)
-        if (l->vector) {
-          ind(indent + 1);
-          pr_vec(o, l->vector);
-          o += '\n';
-        }
-      ind(indent);
-      o += ")\n";
-    }
-    if (q->next_then) pr_quast(o, q->next_then, ni);
-  } else {
-    ind(indent);
-    o += "(if ";
-    pr_vec(o, q->condition);
-    o += '\n';
-    pr_quast(o, q->next_then, ni);
-    pr_quast(o, q->next_else, ni);
-    ind(indent);
-    o += ")\n";
-  }
-}
-
-void free_list_node(pipamd_list *l);
-// piplib.c:651-690 pip_quast_equalities_dual
-void equalities_dual(pipamd_quast *s, const pipamd_matrix *inequnk) {
-  if (!s) return;
-  if (s->condition) {
-    equalities_dual(s->next_then, inequnk);
-    equalities_dual(s->next_else, inequnk);
-  }
-  if (!s->list || !s->next_then || !s->next_then->list) return;
-  pipamd_list **lp = &s->next_then->list, *l;
-  for (unsigned i = 0; i < inequnk->NbRows; ++i) {
-    if (inequnk->p[i][0] == 0) {
-      if ((*lp)->vector->the_vector[0] != 0) {
-        lp = &(*lp)->next;
-        l = *lp;
-        *lp = l->next;
-        free_list_node(l);
-      } else {
-        l = *lp;
-        *lp = l->next;
-        free_list_node(l);
-        (*lp)->vector->the_vector[0] = wneg((*lp)->vector->the_vector[0]);
-        lp = &(*lp)->next;
-      }
-    } else
-      lp = &(*lp)->next;
-  }
-}
-
-void free_vec(pipamd_vector *v) {
-  if (!v) return;
-  free(v->the_vector);
-  free(v->the_deno);
-  free(v);
-}
-
-void free_list_node(pipamd_list *l) {
-  free_vec(l->vector);
-  free(l);
-}
-
-}  // namespace
-
-extern "C" void pipamd_quast_free(pipamd_quast *q) {  // piplib.c:435-447
-  if (!q) return;
-  for (pipamd_newparm *np = q->newparm; np;) {
-    pipamd_newparm *nx = np->next;
-    free_vec(np->vector);
-    free(np);
-    np = nx;
-  }
-  for (pipamd_list *l = q->list; l;) {
-    pipamd_list *nx = l->next;
-    free_vec(l->vector);
-    free(l);
-    l = nx;
-  }
-  free_vec(q->condition);
-  pipamd_quast_free(q->next_then);
-  pipamd_quast_free(q->next_else);
-  free(q);
-}
-
-extern "C" char *pipamd_quast_to_string(const pipamd_quast *q, int indent) {
-  std::string o;
-  pr_quast(o, q, indent);
-  char *r = (char *)malloc(o.size() + 1);
-  if (r) memcpy(r, o.c_str(), o.size() + 1);
-  return r;
-}
-
-// piplib.c:722-880 pip_solve.  *quast is NULL for "void" (empty context or no domain).
-extern "C" int pipamd_pip_solve(pipamd_engine *e, const pipamd_matrix *inequnk, const pipamd_matrix *ineqpar, int Bg,
-                                const pipamd_options *opt, pipamd_quast **quast, int *status, int64_t *pivots) {
-  if (!e || !quast || !opt) return PIPAMD_E_INVALID;
-  *quast = nullptr;
-  if (status) *status = 0;
-  if (pivots) *pivots = 0;
-  if (!inequnk) return PIPAMD_OK;
-  int Np = ineqpar ? (int)ineqpar->NbColumns - 2 : 0;
-  const int Nn = (int)inequnk->NbColumns - Np - 2;
-  unsigned Nl = inequnk->NbRows;
-  for (unsigned i = 0; i < inequnk->NbRows; i++)
-    if (inequnk->p[i][0] == 0) ++Nl;
-  int Shift = 0, Urs_parms = 0, sol_flags = 0, Nm = 0;
-  if (opt->Maximize) {
-    sol_flags |= SOL_MAX;
-    Shift = 1;
-  } else if (opt->Urs_unknowns) {
-    sol_flags |= SOL_SHIFT;
-    Shift = -1;
-  }
-  if (opt->Urs_parms) {
-    Urs_parms = Np - (Bg >= 0);
-    Np += Urs_parms;
-  }
-  if (opt->Maximize || opt->Urs_unknowns) {
-    if (Bg < 0) {
-      Bg = (int)inequnk->NbColumns - 1;
-      Np++;
-      sol_flags |= SOL_REMOVE;
-    }
-  }
-  pipamd_matrix empty;
-  memset(&empty, 0, sizeof empty);
-  empty.NbColumns = 2;
-  TabArr ctx;
-  if (ineqpar) {
-    Nm = (int)ineqpar->NbRows;
-    for (unsigned i = 0; i < ineqpar->NbRows; i++)
-      if (ineqpar->p[i][0] == 0) Nm++;
-    ctx = matrix_to_tab(ineqpar, Nm, Np - Urs_parms, -1, Shift, Bg - Nn - 1, Urs_parms);
-  } else
-    ctx = matrix_to_tab(&empty, 0, Np - Urs_parms, -1, Shift, Bg - Nn - 1, Urs_parms);
-  TabArr ineq = matrix_to_tab(inequnk, (int)Nl, Nn, Nn, Shift, Bg, Urs_parms);
-  if (ctx.width < Np + 1 || ineq.width < Nn + Np + 1) {
-    pipamd_set_error("pipamd_pip_solve: inconsistent matrix shapes");
-    return PIPAMD_E_INVALID;
-  }
-  // our tableaux are exactly (Np+1) resp. (Nn+Np+1) wide
-  auto narrow = [](TabArr &t, int w) {
-    if (t.width == w) return;
-    std::vector<i64> nv((size_t)t.rows * w);
-    for (int r = 0; r < t.rows; r++)
-      for (int c = 0; c < w; c++) nv[(size_t)r * w + c] = t.v[(size_t)r * t.width + c];
-    t.v.swap(nv);
-    t.width = w;
-  };
-  narrow(ctx, Np + 1);
-  narrow(ineq, Nn + Np + 1);
-  if (opt->Nq) {
-    simplify_rows(ctx.v, ctx.rows, ctx.width, Np);
-    simplify_rows(ineq.v, ineq.rows, ineq.width, Nn);
-  }
-  if (Bg >= Nn + Np + 1 || (Bg >= 0 && Bg <= Nn)) {
-    pipamd_set_error("pipamd_pip_solve: bignum column out of range");
-    return PIPAMD_E_INVALID;
-  }
-  if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
-  Tree t(e, opt->Deepest_cut);
-  if (!opt->Nq && opt->Compute_dual) {  // piplib.c:854-857
-    t.dual_ = true;
-    sol_flags |= SOL_DUAL;
-  }
-  int rc = PIPAMD_OK;
-  bool non_vide = false;
-  try {
-    non_vide = t.front(Nn, Np, (int)Nl, Nm, Bg, opt->Nq, ineq.v.data(), ctx.v.data());
-  } catch (int code) {
-    rc = code;
-    if (status) *status = t.fail_status;
-    if (rc == PIPAMD_E_SOLVER) pipamd_set_error("solver stopped with status %d", t.fail_status);
-  }
-  if (pivots) *pivots = t.pivots;
-  if (rc) return rc;
-  if (!non_vide) return PIPAMD_OK;
-  if (opt->Simplify) t_simplify(t.tape, 0);
-  size_t xq = 0;
-  try {
-    *quast = q_quast(t.tape, &xq, nullptr, Bg - Nn - 1, Urs_parms, sol_flags);
-  } catch (int code) {
-    *quast = nullptr;  // (nodes built so far are leaked: an unsupported option combination, not a hot path)
-    pipamd_set_error("pip_solve: this option combination makes the reference read outside its solution tape "
-                     "(e.g. Compute_dual with Urs_parms); refused");
-    return code;
-  }
-  if ((sol_flags & SOL_DUAL) && Nl > inequnk->NbRows) equalities_dual(*quast, inequnk);
-  return PIPAMD_OK;
+  return rc_all;
 }

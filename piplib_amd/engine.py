@@ -51,9 +51,6 @@ def lib():
         L.pipamd_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc)] + [C.c_void_p] * 6
         L.pipamd_batch_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p, C.c_void_p]
         L.pipamd_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
-        L.pipamd_solve_tableau.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int),
-                                                                        C.POINTER(C.c_int64)]
         L.pipamd_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -167,24 +164,126 @@ class Batch:
         return int(lib().pipamd_pivot_bytes(C.byref(self.desc)))
 
 
-def solve_tableau(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify=True, deepest_cut=False):
-    """Layer 3: one problem in .dat form (host arrays) -> (sol_edit text, pivots).
-    Raises SolverError(status) where the reference would have exit()ed."""
+class SolCell(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("param1", C.c_int64), ("param2", C.c_int64)]
+
+
+SOL_NIL, SOL_IF, SOL_LIST, SOL_FORM, SOL_NEW, SOL_DIV, SOL_VAL = range(1, 8)
+
+
+def _frac(n, d):
+    import math
+    g = math.gcd(n, d)
+    return f" {n // g}" if g == abs(d) and d > 0 else (f" {n // g}/{d // g}" if g else f" {n}/{d}")
+
+
+def tape_text(cells):
+    """Test/bench harness only: the text the reference's sol_edit (sol.c:291-422) prints for a tape,
+    cells = [(kind, param1, param2), ...].  An empty tape is the front ends' "void"."""
+    if not cells:
+        return "void\n"
+    out = []
+
+    def item(i):
+        while cells[i][0] == SOL_NEW:
+            out.append("(newparm %d " % cells[i][1])
+            i = item(i + 1)
+            out.append(")\n")
+        k, a, b = cells[i]
+        if k == SOL_NIL:
+            out.append("()\n")
+            return i + 1
+        if k == SOL_IF:
+            out.append("(if ")
+            i = item(item(item(i + 1)))
+            out.append(")\n")
+            return i
+        if k == SOL_LIST:
+            out.append("(list ")
+            i += 1
+            for _ in range(a):
+                i = item(i)
+            out.append(")\n")
+            return i
+        if k == SOL_FORM:
+            out.append("#[")
+            for j in range(a):
+                out.append(_frac(cells[i + 1 + j][1], cells[i + 1 + j][2]))
+            out.append("]\n")
+            return i + 1 + a
+        if k == SOL_DIV:
+            out.append("(div ")
+            i = item(item(i + 1))
+            out.append(")\n")
+            return i
+        if k == SOL_VAL:
+            out.append(_frac(a, b))
+            return i + 1
+        raise ValueError(f"unknown tape cell kind {k}")
+
+    i = 0
+    while i < len(cells):
+        i = item(i)
+    return "".join(out)
+
+
+def _take_cells(ptr, n):
+    if not ptr or not n:
+        return []
+    arr = C.cast(ptr, C.POINTER(SolCell * n)).contents
+    cells = [(c.kind, c.param1, c.param2) for c in arr]
+    lib().pipamd_free(ptr)
+    return cells
+
+
+def _rows(ineq, ctx, ni, nc, nvar, nparm):
     import numpy as np
     a = np.ascontiguousarray(ineq, dtype=np.int64).reshape(ni, nvar + nparm + 1)
     c = np.ascontiguousarray(ctx, dtype=np.int64).reshape(nc, nparm + 1)
-    text = C.c_void_p()
-    status = C.c_int(0)
-    piv = C.c_int64(0)
-    rc = lib().pipamd_solve_tableau(engine._h, nvar, nparm, ni, nc, bigparm, nq,
-                                    C.c_void_p(a.ctypes.data), C.c_void_p(c.ctypes.data), int(bool(simplify)),
-                                    int(bool(deepest_cut)), C.byref(text), C.byref(status), C.byref(piv))
+    return a, c
+
+
+def solve_tableau_cells(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify=True, deepest_cut=False):
+    """Layer 3: one problem in .dat form (host arrays) -> (tape cells, pivots).
+    Raises SolverError(status) where the reference would have exit()ed."""
+    a, c = _rows(ineq, ctx, ni, nc, nvar, nparm)
+    L = lib()
+    L.pipamd_solve_tableau.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                                    C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                                                    C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    cells, n = C.c_void_p(), C.c_size_t(0)
+    status, piv = C.c_int(0), C.c_int64(0)
+    rc = L.pipamd_solve_tableau(engine._h, nvar, nparm, ni, nc, bigparm, nq, C.c_void_p(a.ctypes.data),
+                                C.c_void_p(c.ctypes.data), int(bool(simplify)), int(bool(deepest_cut)),
+                                C.byref(cells), C.byref(n), C.byref(status), C.byref(piv))
     if rc == -5:
         raise SolverError(status.value, piv.value)
     _check(rc)
-    out = C.string_at(text).decode()
-    lib().pipamd_free(text)
-    return out, piv.value
+    return _take_cells(cells, n.value), piv.value
+
+
+def solve_tableau(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify=True, deepest_cut=False):
+    """solve_tableau_cells, with the tape printed as sol_edit would (tests compare texts)."""
+    cells, piv = solve_tableau_cells(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify, deepest_cut)
+    return tape_text(cells), piv
+
+
+def traiter(engine, nvar, nparm, ni, nc, bigparm, flags, tableau, context, deepest_cut=False):
+    """pipamd_traiter: one traiter() call -> (tape cells, pivots)."""
+    a, c = _rows(tableau, context, ni, nc, nvar, nparm)
+    L = lib()
+    L.pipamd_traiter.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                                                C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                                                C.POINTER(C.c_int64)]
+    cells, n = C.c_void_p(), C.c_size_t(0)
+    status, piv = C.c_int(0), C.c_int64(0)
+    rc = L.pipamd_traiter(engine._h, nvar, nparm, ni, nc, bigparm, int(flags), int(bool(deepest_cut)),
+                          C.c_void_p(a.ctypes.data), C.c_void_p(c.ctypes.data), C.byref(cells), C.byref(n),
+                          C.byref(status), C.byref(piv))
+    if rc == -5:
+        raise SolverError(status.value, piv.value)
+    _check(rc)
+    return _take_cells(cells, n.value), piv.value
 
 
 class SolverError(RuntimeError):
@@ -192,60 +291,6 @@ class SolverError(RuntimeError):
         super().__init__(f"solver stopped with PIPAMD_ST status {status}")
         self.status = status
         self.pivots = pivots
-
-
-# ---------------------------------------------------------------- pip_solve (PolyLib matrices)
-class PipMatrix(C.Structure):
-    _fields_ = [("NbRows", C.c_uint), ("NbColumns", C.c_uint), ("p", C.POINTER(C.POINTER(C.c_longlong))),
-                ("p_Init", C.POINTER(C.c_longlong)), ("p_Init_size", C.c_int)]
-
-
-class PipOptions(C.Structure):
-    _fields_ = [(n, C.c_int) for n in
-                ("Nq", "Verbose", "Simplify", "Deepest_cut", "Maximize", "Urs_parms", "Urs_unknowns", "Compute_dual")]
-
-
-def _matrix(a):
-    """numpy (rows, cols) int64 -> (PipMatrix, keep-alive objects); the reference's layout."""
-    import numpy as np
-    a = np.ascontiguousarray(a, dtype=np.int64)
-    rows, cols = a.shape
-    flat = (C.c_longlong * max(1, rows * cols))(*a.reshape(-1).tolist())
-    ptrs = (C.POINTER(C.c_longlong) * max(1, rows))()
-    for i in range(rows):
-        ptrs[i] = C.cast(C.byref(flat, i * cols * 8), C.POINTER(C.c_longlong))
-    m = PipMatrix(rows, cols, ptrs, flat, rows * cols)
-    return m, (flat, ptrs, a)
-
-
-def pip_solve(engine, domain, context, bignum, **options):
-    """pip_solve(domain, context, bignum, options) -> (pip_quast_print text, pivots).
-    `domain`/`context` are PolyLib-format numpy matrices (first column = eq/ineq marker)."""
-    L = lib()
-    L.pipamd_pip_solve.argtypes = [C.c_void_p, C.POINTER(PipMatrix), C.POINTER(PipMatrix), C.c_int,
-                                   C.POINTER(PipOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
-                                   C.POINTER(C.c_int64)]
-    L.pipamd_quast_to_string.restype = C.c_void_p
-    L.pipamd_quast_to_string.argtypes = [C.c_void_p, C.c_int]
-    L.pipamd_quast_free.argtypes = [C.c_void_p]
-    opt = PipOptions(1, 0, 0, 0, 0, 0, 0, 0)
-    for k, v in options.items():
-        setattr(opt, k, int(v))
-    md, keep1 = _matrix(domain)
-    mc, keep2 = _matrix(context)
-    q = C.c_void_p()
-    status = C.c_int(0)
-    piv = C.c_int64(0)
-    rc = L.pipamd_pip_solve(engine._h, C.byref(md), C.byref(mc), int(bignum), C.byref(opt), C.byref(q),
-                            C.byref(status), C.byref(piv))
-    if rc == -5:
-        raise SolverError(status.value, piv.value)
-    _check(rc)
-    s = L.pipamd_quast_to_string(q, 0)
-    text = C.string_at(s).decode()
-    L.pipamd_free(s)
-    L.pipamd_quast_free(q)
-    return text, piv.value
 
 
 class PipProblem(C.Structure):
@@ -265,26 +310,24 @@ def solve_tableaux(engine, problems, simplify=True, deepest_cut=False, nthreads=
         c = np.ascontiguousarray(p.ctx, dtype=np.int64).reshape(p.nc, p.nparm + 1)
         keep += [a, c]
         arr[i] = PipProblem(p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, a.ctypes.data, c.ctypes.data)
-    texts = (C.c_void_p * max(1, n))()
+    cells = (C.c_void_p * max(1, n))()
+    ncell = (C.c_size_t * max(1, n))()
     rcs = (C.c_int * max(1, n))()
     sts = (C.c_int * max(1, n))()
     piv = (C.c_int64 * max(1, n))()
     L = lib()
     L.pipamd_solve_tableaux.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if lockstep:
         L.pipamd_solve_tableaux_lockstep.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
-                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _check(L.pipamd_solve_tableaux_lockstep(engine._h, n, arr, int(bool(simplify)), int(bool(deepest_cut)),
-                                                texts, rcs, sts, piv))
+                                                cells, ncell, rcs, sts, piv))
     else:
         _check(L.pipamd_solve_tableaux(engine._h, n, arr, int(bool(simplify)), int(bool(deepest_cut)), int(nthreads),
-                                       texts, rcs, sts, piv))
+                                       cells, ncell, rcs, sts, piv))
     out = []
     for i in range(n):
-        t = None
-        if rcs[i] == 0 and texts[i]:
-            t = C.string_at(texts[i]).decode()
-            L.pipamd_free(texts[i])
+        t = tape_text(_take_cells(cells[i], ncell[i])) if rcs[i] == 0 else None
         out.append((t, rcs[i], sts[i], piv[i]))
     return out

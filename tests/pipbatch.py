@@ -16,6 +16,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFPIP = os.path.join(ROOT, "oracle", "_ref", "refpip")
+REFPIP_GPU = os.path.join(ROOT, "oracle", "_ref", "refpip_gpu")  # the reference's front ends over the GPU traiter hook
 ORACLEPIP = os.path.join(ROOT, "oracle", "oraclepip")
 ORACLEPIP128 = os.path.join(ROOT, "oracle", "oraclepip128")
 MAGIC = 0x50495042
@@ -53,6 +54,10 @@ class BatchOut:
 
 def have_ref() -> bool:
     return os.access(REFPIP, os.X_OK)
+
+
+def have_ref_gpu() -> bool:
+    return os.access(REFPIP_GPU, os.X_OK)
 
 
 def have_oracle() -> bool:

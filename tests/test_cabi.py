@@ -28,7 +28,7 @@ def declared_functions():
 def test_header_declares_the_three_layers():
     names = declared_functions()
     for must in ("pipamd_engine_create", "pipamd_batch_load", "pipamd_batch_solve", "pipamd_batch_results",
-                 "pipamd_solve_tableau", "pipamd_pivot_bytes", "pipamd_last_solve_ms"):
+                 "pipamd_solve_tableau", "pipamd_traiter", "pipamd_pivot_bytes", "pipamd_last_solve_ms"):
         assert must in names
 
 

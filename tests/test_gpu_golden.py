@@ -1,5 +1,9 @@
-"""-m gpu: PipLib's own test inputs through the host decision tree + HIP engine
-(pipamd_solve_tableau, layer 3 of the C ABI) against the reference's golden .ll files."""
+"""-m gpu: PipLib's own test inputs against the reference's golden .ll files, two ways:
+(1) through pipamd_solve_tableau (layer 3 of the C ABI: host decision tree + HIP engine; the tape
+    cells are printed by the Python harness), and
+(2) through the reference's own front ends -- its parsers, pip_solve, solution tape, sol_edit and
+    pip_quast_print -- with only traiter() bound to the engine (bindings/piplib_traiter_hook.c,
+    built as oracle/_ref/refpip_gpu by oracle/Makefile)."""
 import json
 import os
 
@@ -54,61 +58,92 @@ def test_ref_generated_on_gpu(key):
 
 from test_oracle_golden import PIPTEST_PIP  # noqa: E402
 
+needs_hook = pytest.mark.skipif(not pb.have_ref_gpu(), reason="oracle/_ref/refpip_gpu not built (no /root/reference)")
 
+
+def ref_front_end(args, stdin=None, timeout=300):
+    """oracle/_ref/refpip_gpu: the reference's front end; every traiter() call goes to the GPU."""
+    import subprocess
+    return subprocess.run([pb.REFPIP_GPU] + args, stdin=stdin, capture_output=True, timeout=timeout)
+
+
+@needs_hook
+@pytest.mark.parametrize("name", PIPTEST_DAT)
+def test_dat_golden_through_reference_front_end(name):
+    """test/*.dat: the reference's tab_get, tape and sol_edit around the GPU traiter vs test/*.ll."""
+    p = ref_front_end(["dat", os.path.join(G, "test", name + ".dat")])
+    assert p.returncode == 0, p.stderr.decode()[-300:]
+    want = open(os.path.join(G, "test", name + ".ll"), encoding="latin-1").read()
+    assert pb.squash(p.stdout.decode("latin-1")) == pb.squash(want)
+
+
+@needs_hook
+@pytest.mark.parametrize("key", sorted(MANIFEST))
+def test_ref_generated_through_reference_front_end(key):
+    """inputs without a usable .ll in the reference tree (both "Integer overflow" inputs among them)"""
+    m = MANIFEST[key]
+    p = ref_front_end(["dat"] + m.get("args", []) + [os.path.join(G, key)])
+    want = open(os.path.join(G, "ref_dp", m["ll"]), encoding="latin-1").read()
+    if m["rc"] != 0:
+        assert p.returncode != 0 and m["stderr"] in p.stderr.decode()
+    else:
+        assert p.returncode == 0, p.stderr.decode()[-300:]
+    assert pb.squash(p.stdout.decode("latin-1")) == pb.squash(want)
+
+
+@needs_hook
 @pytest.mark.parametrize("name", PIPTEST_PIP)
 def test_pip_solve_golden_on_gpu(name):
-    """example/*.pip through pipamd_pip_solve (PolyLib matrices in, PipQuast out) vs example/*.ll."""
-    from datfile import read_pip, matrix_text
-    from piplib_amd import engine as eng
-    context, bignum, domain, opts = read_pip(os.path.join(G, "example", name + ".pip"))
-    e = eng.Engine(0)
-    bg = bignum + (domain.shape[1] - context.shape[1]) if bignum > 0 else bignum
-    text, _ = eng.pip_solve(e, domain, context, bg, **opts)
-    got = ("[PIP2-like future input] Please enter:\n- the context matrix,\n" + matrix_text(context) +
-           "- the bignum column (start at 0, -1 if no bignum),\n" + f"{bignum}\n" +
-           "- the constraint matrix.\n" + matrix_text(domain) + "\n" + text)
+    """example/*.pip through the reference's pip_solve (piplib.c:722-880, unchanged) with its two
+    traiter calls bound to the engine; printed by the reference's pip_quast_print; vs example/*.ll."""
+    with open(os.path.join(G, "example", name + ".pip")) as f:
+        p = ref_front_end(["pip"], stdin=f)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
     want = open(os.path.join(G, "example", name + ".ll"), encoding="latin-1").read()
-    assert pb.squash(got) == pb.squash(want)
+    assert pb.squash(p.stdout.decode("latin-1")) == pb.squash(want)
 
 
+@needs_hook
 @pytest.mark.parametrize("name", ["small", "square", "max", "big", "cg1", "sven"])
 def test_compute_dual_on_gpu(name):
-    """pip_solve with Nq = 0 and Compute_dual = 1 vs reference-generated fixtures."""
-    from datfile import read_pip, matrix_text
-    from piplib_amd import engine as eng
+    """pip_solve with Nq = 0 and Compute_dual = 1 (TRAITER_DUAL through the hook) vs reference-generated fixtures."""
     d = os.path.join(G, "ref_dp")
-    context, bignum, domain, opts = read_pip(os.path.join(d, f"dual__{name}.pip"))
-    assert opts.get("Nq") == 0 and opts.get("Compute_dual") == 1
-    e = eng.Engine(0)
-    bg = bignum + (domain.shape[1] - context.shape[1]) if bignum > 0 else bignum
-    text, _ = eng.pip_solve(e, domain, context, bg, **opts)
-    got = ("[PIP2-like future input] Please enter:\n- the context matrix,\n" + matrix_text(context) +
-           "- the bignum column (start at 0, -1 if no bignum),\n" + f"{bignum}\n" +
-           "- the constraint matrix.\n" + matrix_text(domain) + "\n" + text)
+    with open(os.path.join(d, f"dual__{name}.pip")) as f:
+        p = ref_front_end(["pip"], stdin=f)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
     want = open(os.path.join(d, f"dual__{name}.ll"), encoding="latin-1").read()
-    assert pb.squash(got) == pb.squash(want)
+    assert pb.squash(p.stdout.decode("latin-1")) == pb.squash(want)
 
 
 def test_plain_c_example():
-    """examples/solve_small.c (built by __graft_entry__.build()): the C ABI from plain C --
-    pip_solve drop-in output equals the reference's example/small.ll quast, the tableau-form
-    call equals the oracle."""
+    """examples/solve_small.c (built by __graft_entry__.build()): the C ABI from plain C -- a
+    traiter() call and a maind.c-style call; the cells it prints, formatted as sol_edit would,
+    equal the oracle's text."""
     import subprocess
     import numpy as np
-    from piplib_amd import synth
+    from piplib_amd import engine as eng, synth
     exe = os.path.join(pb.ROOT, "examples", "solve_small")
     if not os.access(exe, os.X_OK):
         import __graft_entry__
         __graft_entry__.build()
     p = subprocess.run([exe], capture_output=True, timeout=120)
     assert p.returncode == 0, p.stderr.decode()
-    out = pb.squash(p.stdout.decode())
-    want_quast = pb.squash(open(os.path.join(G, "example", "small.ll")).read()).split("3")[-1]  # "(list#[0]#[0])"
-    assert out.startswith(want_quast) or want_quast in out
+    tapes, cur = [], None
+    for ln in p.stdout.decode().splitlines():
+        if ln.startswith("tape"):
+            cur = []
+            tapes.append(cur)
+        elif ln.startswith("cell"):
+            cur.append(tuple(int(x) for x in ln.split()[1:4]))
+    assert len(tapes) == 2
+    # 1. lexmin of (i, j): i - 3j + 12 >= 0, -2i + j + 3 >= 0 (the reference's example/small.pip as a tableau)
+    small = synth.Problem(2, 0, 2, 0, -1, 1, np.array([[1, -3, 12], [-2, 1, 3]], dtype=np.int64), np.zeros((0, 1), np.int64))
+    # 2. one parametric problem with a context row
     prob = synth.Problem(2, 1, 3, 1, -1, 1, np.array([[1, 1, 0, -1], [-1, 0, 5, 0], [0, -1, 7, 0]], dtype=np.int64),
                          np.array([[-1, 12]], dtype=np.int64))
-    o = pb.run_batch(pb.ORACLEPIP, [prob])
-    assert out.endswith(pb.squash(o.results[0].text))
+    o = pb.run_batch(pb.ORACLEPIP, [small, prob])
+    assert pb.squash(eng.tape_text(tapes[0])) == pb.squash(o.results[0].text)
+    assert pb.squash(eng.tape_text(tapes[1])) == pb.squash(o.results[1].text)
 
 
 @pytest.mark.parametrize("name,dom,ctx,opts", [
@@ -129,32 +164,18 @@ def test_plain_c_example():
       [0, 3, 1, 2, -1, -1, 3, 3, 5], [1, 3, 1, 3, -2, 2, -1, 2, 6], [1, -1, -3, -3, -1, -3, -3, 0, -5]],
      [[1, 2, -2, 0, 1], [1, 2, -1, 0, 4]], {"Urs_parms": 1}),
 ])
+@needs_hook
 def test_pip_solve_fuzz_regressions(name, dom, ctx, opts):
-    """pipamd_pip_solve vs the oracle's `pip` mode on inputs that once failed with PIPAMD_ST_CAPACITY."""
+    """The reference's pip_solve over the GPU traiter vs the oracle's `pip` mode on inputs that once
+    failed with PIPAMD_ST_CAPACITY."""
     import subprocess
     import numpy as np
     from datfile import matrix_text
-    from piplib_amd import engine as eng
     dom, ctx = np.array(dom, dtype=np.int64), np.array(ctx, dtype=np.int64)
     words = "".join(k + "\n" for k in opts)
     txt = (matrix_text(ctx) + "\n-1\n\n" + matrix_text(dom) + "\n" + words).encode()
     o = subprocess.run([pb.ORACLEPIP, "pip"], input=txt, capture_output=True, timeout=120)
     assert o.returncode == 0
-    text, _ = eng.pip_solve(eng.Engine(0), dom, ctx, -1, **opts)
-    got = ("[PIP2-like future input] Please enter:\n- the context matrix,\n" + matrix_text(ctx) +
-           "- the bignum column (start at 0, -1 if no bignum),\n-1\n- the constraint matrix.\n" +
-           matrix_text(dom) + "\n" + text)
-    assert pb.squash(got) == pb.squash(o.stdout.decode("latin-1"))
-
-
-def test_pip_solve_refuses_dual_with_urs_parms():
-    """Compute_dual + Urs_parms makes the reference's sol_vector_edit take a negative-length vector
-    (it exits with "Memory Overflow" or faults); the library must refuse the call, not crash."""
-    import numpy as np
-    from piplib_amd import engine as eng
-    dom = np.array([[1, 3, -3, -3, 2, -2, -2, 4], [1, -3, 1, -3, 0, 1, -3, 10], [1, 1, 0, 2, -1, 2, -1, -5],
-                    [1, 2, 3, 2, -2, -1, 3, 10], [1, 0, 3, 1, -1, -2, 0, -5], [1, -3, 0, 2, -3, -2, 0, -3]], dtype=np.int64)
-    for npar in (1, 2, 3):
-        ctx = np.zeros((0, npar + 2), dtype=np.int64)
-        with pytest.raises(RuntimeError):
-            eng.pip_solve(eng.Engine(0), dom, ctx, -1, Urs_unknowns=1, Urs_parms=1, Nq=0, Compute_dual=1)
+    g = subprocess.run([pb.REFPIP_GPU, "pip"], input=txt, capture_output=True, timeout=600)
+    assert g.returncode == 0, g.stderr.decode()[-300:]
+    assert pb.squash(g.stdout.decode("latin-1")) == pb.squash(o.stdout.decode("latin-1"))
