@@ -14,8 +14,11 @@ each lane with its own batch (own seed), engine and workspace (each step is a co
 solve of its batch); ms_per_step is total time / steps.  `pipeline1_value` is the same workload
 with one batch at a time.  `other_configs` carries BASELINE configs[1] and configs[4] measured the
 same way (shorter runs).
-Multi-GPU: independent problems, so each rank owns its own batches (weak scaling, no data-path
-collective; --scaling strong shards one 10k batch, BASELINE configs[3]); RCCL only sums totals.
+Multi-GPU (--gpus N > 1): BASELINE configs[3] -- every 10k-tableau batch is sharded over the ranks
+(strong scaling; world x as many batches in flight so that a GPU holds as many tableaux as in the
+1-GPU run), no data-path collective; RCCL only sums the totals here (the results gather is
+piplib_amd.dist.gather_results).  The weak-scaling figure (10k tableaux per GPU and batch) is
+measured as well and reported as `other_scaling`.
 
 Prints ONE JSON line (rank 0).
 """
@@ -123,6 +126,9 @@ class Lanes:
                 e.set_round_pivots(args.round)
             if args.round_rows:
                 e.set_round_rows(args.round_rows)
+            bulk_min = args.bulk_min if args.bulk_min > 0 else (256 if depth > 1 else 0)
+            if bulk_min:
+                e.set_bulk_min(bulk_min)
             b = eng.Batch(e, torch.as_tensor(gen(seeds[i]), dtype=torch.int64).to(dev), cfg["nvar"], 0,
                           tflags=eng.T_INT if cfg["integer"] else 0, entier_bits=cfg["ebits"])
             self.lanes.append((e, b, torch.cuda.Stream(dev)))
@@ -233,8 +239,13 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="waves per tableau (0 = engine default)")
     ap.add_argument("--round", type=int, default=0, help="pivot budget per tableau in the bulk launch (0 = engine default)")
     ap.add_argument("--round-rows", type=int, default=0, help="spare rows in the bulk launch's LDS image (0 = engine default)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --batch tableaux per GPU (default); strong: --batch tableaux in all, sharded over the ranks")
+    ap.add_argument("--bulk-min", type=int, default=-1,
+                    help="smallest batch that starts with the one-wave bulk launch (-1 = 256 when several batches are "
+                         "in flight, the engine default of 2048 otherwise)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="strong (default for --gpus > 1, BASELINE configs[3]): every --batch-tableau batch is sharded "
+                         "over the ranks; weak (default for one GPU): --batch tableaux per GPU and batch.  The other "
+                         "mode is measured too and reported as `other_scaling`.")
     ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (streams/threads)")
     ap.add_argument("--stagger", type=float, default=-1.0,
                     help="ms between the lanes' starts (0 = none, <0 = step latency / lanes, measured in warm-up)")
@@ -270,20 +281,31 @@ def main():
         pdist.barrier()
         torch.cuda.synchronize(dev)
 
-    cfg = dict(MAIN)
-    cfg["batch"] = args.batch
-    depth = lane_count(args.pipeline, args.steps)
-    # lane i of rank r draws its own batch: seed 1000 + r + 7919 * i
-    seeds = [pdist.shard_seed(1000, rank) + 7919 * i for i in range(depth)]
-    gen = None
-    if args.scaling == "strong":  # BASELINE configs[3]: every 10k-tableau batch is sharded over the GPUs
-        lo, hi = pdist.shard_range(args.batch, rank, world)
-        cfg["batch"] = hi - lo
-        seeds = [1000 + 7919 * i for i in range(depth)]
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
 
-        def gen(seed):
-            return synth.lexmin_batch(seed, args.batch, cfg["nvar"], cfg["ni"])[lo:hi]
-    lanes = Lanes(cfg, depth, dev, local, seeds, args, gen)
+    def build_lanes(scaling):
+        """the lanes of one measurement: (cfg, lanes, depth, seeds, gen)"""
+        cfg = dict(MAIN)
+        cfg["batch"] = args.batch
+        if scaling == "strong":
+            # BASELINE configs[3]: every 10k-tableau batch is sharded over the GPUs.  A GPU then holds
+            # 1/world of every batch in flight, so world x as many batches are kept in flight
+            depth = lane_count(args.pipeline * world, args.steps)
+            lo, hi = pdist.shard_range(args.batch, rank, world)
+            cfg["batch"] = hi - lo
+            seeds = [1000 + 7919 * i for i in range(depth)]
+
+            def gen(seed):
+                return synth.lexmin_batch(seed, args.batch, cfg["nvar"], cfg["ni"])[lo:hi]
+        else:
+            depth = lane_count(args.pipeline, args.steps)
+            # lane i of rank r draws its own batch: seed 1000 + r + 7919 * i
+            seeds = [pdist.shard_seed(1000, rank) + 7919 * i for i in range(depth)]
+            gen = None
+        return cfg, Lanes(cfg, depth, dev, local, seeds, args, gen), depth, seeds, gen
+
+    cfg, lanes, depth, seeds, gen = build_lanes(args.scaling)
     my_batch = cfg["batch"]
     e, b, _ = lanes.lanes[0]
 
@@ -294,6 +316,21 @@ def main():
     k_ms = kernel_ms_of(b)
     torch.cuda.synchronize(dev)
     gt, dt_max = pdist.gather_totals(tot, dt, dev)
+
+    other = None
+    if world > 1:  # the other scaling mode, same steps (every rank takes part)
+        mode2 = "weak" if args.scaling == "strong" else "strong"
+        rows_keep = b.rows
+        del lanes
+        torch.cuda.empty_cache()
+        cfg2, lanes2, depth2, _, _ = build_lanes(mode2)
+        dt2, share2 = timed(lanes2, args.steps, args.warmup, barrier, args.stagger)
+        gt2, dt2_max = pdist.gather_totals(lanes2.totals(share2), dt2, dev)
+        other = {"scaling": mode2, "value": gt2[0] / dt2_max, "unit": "pivots/s", "ms_per_step": dt2_max / args.steps * 1e3,
+                 "batch_per_gpu": cfg2["batch"], "pipeline_depth": depth2, "problems_per_sec": gt2[3] / dt2_max}
+        del lanes2
+        torch.cuda.empty_cache()
+        lanes = None
 
     if rank != 0:
         # ranks other than 0 only take part in the headline measurement
@@ -325,6 +362,8 @@ def main():
         "finished_fraction": gt[4] / max(1.0, gt[3]),
         "rows_rewritten_per_pivot": gt[2] / max(1.0, gt[0]),
     }
+    if other:
+        out["other_scaling"] = other
     traffic = None
     for tp in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
         tp = os.path.join(ROOT, "profiles", tp)
@@ -341,7 +380,7 @@ def main():
         "traffic": traffic,
         "measured": "HIP events around each launch, 2 un-pipelined steps after the timed region "
                     "(= `bench.py --pipeline 1`, the command of profiles/r02_kernel_stats.csv)",
-        "timed_region_GBps": 8.0 * (cfg["nvar"] + 1) * (2.0 * gt[2] + 2.0 * gt[0]) / world / dt_max / 1e9,
+        "timed_region_GBps_per_gpu": 8.0 * (cfg["nvar"] + 1) * (2.0 * gt[2] + 2.0 * gt[0]) / world / dt_max / 1e9,
         "dense_equivalent_GBps": b.pivot_bytes() * c0["pivots"] / (k_ms * 1e-3) / 1e9,
         "note": "sparse workload: ~2.7 of ~80 rows change per pivot, so the pivot loop is latency/issue-bound, "
                 "not HBM-bound; see roofline_dense_mode for the HBM-bound regime of the same kernel"})

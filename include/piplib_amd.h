@@ -143,6 +143,10 @@ int pipamd_last_solve_launches(pipamd_engine *e);
  * with four waves per tableau. */
 int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots);
 int pipamd_engine_set_round_rows(pipamd_engine *e, int rows);
+/* Smaller batches skip the bulk launch (few tableaux fill the GPU better with four waves each).
+ * A caller that keeps several small batches in flight on separate streams -- together they do fill
+ * the GPU -- lowers the threshold (default 2048 tableaux). */
+int pipamd_engine_set_bulk_min(pipamd_engine *e, int tableaux);
 
 /* ------------------------------------------------------------------ layer 3 */
 /* The solution tape.  traiter() does not return a value: it pushes cells onto the tape of

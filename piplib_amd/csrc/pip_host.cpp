@@ -133,7 +133,7 @@ extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batc
 
 // traiter() for the whole batch, as a short sequence of launches without a host round trip in
 // between (each launch writes the list of tableaux it left unfinished, the next one reads it):
-//   bulk  (batches of >= 2048 tableaux): one wave per tableau; a tableau's workgroup ends when the
+//   bulk  (batches of >= `bulk_min` tableaux, default 2048): one wave per tableau; a tableau's workgroup ends when the
 //         tableau is finished, has spent `round_pivots` pivots or has filled the LDS image (sized
 //         for the rows it has plus `round_rows` Gomory cuts, so that 24 tableaux fit a CU).  The
 //         workgroup dispatcher starts the next tableau in its place, so every CU stays busy until
@@ -197,7 +197,7 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
     return PIPAMD_OK;
   };
   const int tail_waves = e->waves_per_job ? e->waves_per_job : 4;
-  if (lay.batch >= 2048 && e->waves_per_job != 4 && !e->single_launch) {
+  if (lay.batch >= (e->bulk_min > 0 ? e->bulk_min : 2048) && e->waves_per_job != 4 && !e->single_launch) {
     const int budget = e->iter_limit < K1 ? e->iter_limit : K1;
     rc = launch(1, budget, lay.ni + (KA < budget ? KA : budget), lay.batch);
     if (rc) return rc;
@@ -243,6 +243,12 @@ extern "C" int pipamd_last_launch_ms(pipamd_engine *e, int i, float *ms) {
 extern "C" int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots) {
   if (!e || pivots < 1) return PIPAMD_E_INVALID;
   e->round_pivots = pivots;
+  return PIPAMD_OK;
+}
+
+extern "C" int pipamd_engine_set_bulk_min(pipamd_engine *e, int tableaux) {
+  if (!e || tableaux < 1) return PIPAMD_E_INVALID;
+  e->bulk_min = tableaux;
   return PIPAMD_OK;
 }
 

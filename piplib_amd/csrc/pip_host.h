@@ -14,6 +14,7 @@ struct pipamd_engine {
   int timed;
   int round_pivots;  /* pivot budget per tableau in the bulk launch (0 = default) */
   int round_rows;    /* spare rows (Gomory cuts) in the bulk launch's LDS image (0 = default) */
+  int bulk_min;      /* batches of at least this many tableaux start with the one-wave bulk launch (0 = default 2048) */
   int single_launch; /* debug: stop after one launch */
   int *h_run;        /* pinned: {jobs still running, their largest row count} */
   int *d_q;          /* work-queue control words and the two job lists of pipamd_batch_solve */

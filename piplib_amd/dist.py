@@ -1,5 +1,13 @@
-"""Multi-GPU plumbing: one process per GPU, independent tableaux per rank (no data-path
-collective); torch.distributed (RCCL on GPUs, gloo in CPU tests) only gathers the totals."""
+"""Multi-GPU plumbing: one process per GPU, independent tableaux per rank -- the pivot path has no
+collective.  torch.distributed (backend "nccl" = RCCL over xGMI on GPUs, gloo in CPU tests) is used
+for exactly one exchange: the final gather of the results to rank 0 (`solve_sharded`), plus the
+sums bench.py reports (`gather_totals`).
+
+    rows (one 10k-tableau batch, the same on every rank or only its own slice)
+      -> shard_range(total, rank, world)          contiguous slice per rank, sizes differ by <= 1
+      -> the rank's own GPU: load + traiter() for its slice (piplib_amd.engine.Batch)
+      -> gather_results(...)                      status / pivots / cuts / solutions, input order, on rank 0
+"""
 import os
 
 
@@ -43,6 +51,73 @@ def gather_totals(counts, seconds, device="cpu"):
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return tot.cpu().tolist(), float(tmax.item())
+
+
+def gather_results(parts, total, device="cpu", dst=0):
+    """The final gather (BASELINE configs[3]: "RCCL over xGMI only for the final gather").
+
+    `parts`: this rank's results for its shard_range slice, a dict of tensors whose first dimension
+    is the slice length (status, pivots, cuts int32; sol_num, sol_den int64 with any trailing
+    shape).  Returns, on rank `dst`, the dict of full-length tensors in input order (None on the
+    other ranks).  Slices differ in length by at most one tableau, so every rank pads its tensors
+    to the longest slice and a single all_gather per tensor moves them; a 1-rank job returns its
+    parts unchanged."""
+    import torch
+    if not _active():
+        return parts
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    spans = [shard_range(total, r, world) for r in range(world)]
+    longest = max(hi - lo for lo, hi in spans)
+    out = {} if rank == dst else None
+    for key in sorted(parts):
+        t = parts[key].to(device)
+        lo, hi = spans[rank]
+        assert t.shape[0] == hi - lo, (key, t.shape, lo, hi)
+        pad = torch.zeros((longest,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:hi - lo] = t
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)
+        if rank == dst:
+            out[key] = torch.cat([bufs[r][:spans[r][1] - spans[r][0]] for r in range(world)], dim=0)
+    return out
+
+
+def solve_sharded(rows, nvar, nparm=0, tflags=1, entier_bits=64, device=None, engine_device=None):
+    """One batch over all ranks: every rank holds `rows` (the whole batch, host or device), solves its
+    shard_range slice on its own GPU (HIP path, no CPU fallback) and rank 0 receives every
+    tableau's status, pivot and cut counts and solution in input order.  Returns that dict on rank
+    0, None elsewhere."""
+    import torch
+    from piplib_amd import engine as eng
+    rank, world, local = env_rank()
+    if engine_device is None:
+        engine_device = local % max(1, torch.cuda.device_count())
+    total = int(rows.shape[0])
+    lo, hi = shard_range(total, rank, world)
+    dev = torch.device("cuda", engine_device)
+    mine = torch.as_tensor(rows[lo:hi], dtype=torch.int64).to(dev)
+    parts = None
+    with torch.cuda.device(dev):
+        if hi > lo:
+            e = eng.Engine(engine_device)
+            b = eng.Batch(e, mine, nvar, nparm, tflags=tflags, entier_bits=entier_bits)
+            b.load()
+            b.solve()
+            b.fetch()
+            torch.cuda.synchronize(dev)
+            parts = {"status": b.status, "pivots": b.pivots, "cuts": b.cuts, "sol_num": b.sol_num, "sol_den": b.sol_den}
+        else:  # more ranks than tableaux: an empty slice still takes part in the gather
+            ew = (2,) if entier_bits == 128 else ()
+            parts = {"status": torch.zeros(0, dtype=torch.int32, device=dev),
+                     "pivots": torch.zeros(0, dtype=torch.int32, device=dev),
+                     "cuts": torch.zeros(0, dtype=torch.int32, device=dev),
+                     "sol_num": torch.zeros((0, nvar, nparm + 1) + ew, dtype=torch.int64, device=dev),
+                     "sol_den": torch.zeros((0, nvar) + ew, dtype=torch.int64, device=dev)}
+    # RCCL gathers device tensors; a gloo group (CPU rehearsal with ranks sharing a GPU) host copies
+    import torch.distributed as dist
+    gdev = dev if (device is None and _active() and dist.get_backend() == "nccl") else (device or "cpu")
+    return gather_results(parts, total, gdev)
 
 
 def _active():

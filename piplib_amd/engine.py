@@ -78,6 +78,10 @@ class Engine:
     def set_round_pivots(self, n):
         _check(lib().pipamd_engine_set_round_pivots(self._h, int(n)))
 
+    def set_bulk_min(self, n):
+        lib().pipamd_engine_set_bulk_min.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().pipamd_engine_set_bulk_min(self._h, int(n)))
+
     def set_round_rows(self, n):
         _check(lib().pipamd_engine_set_round_rows(self._h, int(n)))
 

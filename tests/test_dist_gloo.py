@@ -1,6 +1,8 @@
-"""N > 1 path on CPU: two gloo ranks, each owning its own shard of tableaux (no data-path
-collective), totals gathered with all_reduce -- the same piplib_amd.dist code bench.py runs
-over RCCL.  The per-rank "solve" here is the CPU oracle (test infrastructure)."""
+"""N > 1 path on CPU: two gloo ranks.  (1) the final gather of piplib_amd.dist.gather_results on
+the real shapes of BASELINE configs[3] (10,000 tableaux, 127 unknowns; uneven slices; the per-rank
+payload is a deterministic function of the tableau index, so order and padding are checked
+exactly); (2) the totals bench.py sums with all_reduce.  The HIP path cannot run here: the same
+code with the engine behind it runs under -m gpu (tests/test_gpu_dist.py)."""
 import os
 import socket
 
@@ -19,12 +21,9 @@ def _free_port():
     return p
 
 
-def _solve_shard(seed, n):
-    from piplib_amd import synth
-    rows = synth.lexmin_batch(seed, n, 6, 8, nnz=3, cmax=3, x0max=5)
-    probs = [synth.Problem(6, 0, 8, 0, -1, 1, rows[b], np.zeros((0, 1), np.int64)) for b in range(n)]
-    out = pb.run_batch(pb.ORACLEPIP, probs, pb.F_NOSIMPLIFY)
-    return out.total_pivots, sum(1 for r in out.results if r.status == pb.ST_OK)
+def _shard_totals(seed, n):
+    """stand-in for a rank's (pivots, finished tableaux): the sums are what is under test here"""
+    return 1000 * seed + n, n - seed % 3
 
 
 def _worker(rank, world, port, q):
@@ -33,7 +32,7 @@ def _worker(rank, world, port, q):
     from piplib_amd import dist as pdist
     r, w, _ = pdist.init("gloo")
     assert (r, w) == (rank, world)
-    piv, ok = _solve_shard(pdist.shard_seed(500, rank), 12)
+    piv, ok = _shard_totals(pdist.shard_seed(500, rank), 12)
     pdist.barrier()
     tot, tmax = pdist.gather_totals([piv, 12, ok], 1.0 + rank)
     if rank == 0:
@@ -53,7 +52,7 @@ def test_two_rank_weak_scaling_totals():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    want = [_solve_shard(500 + r, 12) for r in range(2)]
+    want = [_shard_totals(500 + r, 12) for r in range(2)]
     assert tot[0] == sum(w[0] for w in want)      # pivots summed over ranks
     assert tot[1] == 24                           # tableaux
     assert tot[2] == sum(w[1] for w in want)
@@ -69,3 +68,44 @@ def test_shard_range_partitions():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _gather_worker(rank, world, port, total, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from piplib_amd import dist as pdist
+    pdist.init("gloo")
+    lo, hi = pdist.shard_range(total, rank, world)
+    idx = torch.arange(lo, hi, dtype=torch.int64)
+    parts = {"status": (idx % 3 + 1).to(torch.int32), "pivots": (idx * 7 % 251).to(torch.int32),
+             "cuts": (idx % 17).to(torch.int32),
+             "sol_num": (idx[:, None, None] * 1000 + torch.arange(127)[None, :, None]).to(torch.int64),
+             "sol_den": (idx[:, None] + torch.arange(127)[None, :] + 1).to(torch.int64)}
+    full = pdist.gather_results(parts, total)
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in full.items()})
+    else:
+        assert full is None
+    pdist.finish()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("total,world", [(10000, 2), (10001, 2), (5, 3)])
+def test_final_gather_real_shapes(total, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    idx = np.arange(total, dtype=np.int64)
+    assert (full["status"] == idx % 3 + 1).all() and (full["pivots"] == idx * 7 % 251).all()
+    assert (full["cuts"] == idx % 17).all()
+    assert full["sol_num"].shape == (total, 127, 1) and full["sol_den"].shape == (total, 127)
+    assert (full["sol_num"][:, :, 0] == idx[:, None] * 1000 + np.arange(127)[None, :]).all()
+    assert (full["sol_den"] == idx[:, None] + np.arange(127)[None, :] + 1).all()
