@@ -80,8 +80,9 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
   lay->S = d->ni + d->cap_cuts;
   lay->L = round_even(d->nvar + lay->S);
   lay->W = ebits == 128 ? ncol + d->cap_newparm : round_even(ncol + d->cap_newparm);
+  // 64-bit tableaux whose row tables outgrow LDS run with the tables in HBM; 128-bit ones must fit
   if (lay->L > PIPAMD_LMAX || lay->S > PIPAMD_SMAX || lay->W > PIPAMD_MAXCOL || lay->S < 1 ||
-      pipk_advance_lds_bytes((lay->L + 3) & ~3, (lay->S + 3) & ~3, lay->W, ebits) > PIPAMD_LDS_BUDGET) {
+      (ebits == 128 && pipk_advance_lds_bytes((lay->L + 3) & ~3, (lay->S + 3) & ~3, lay->W, ebits) > PIPAMD_LDS_BUDGET)) {
     pipamd_set_error("batch shape exceeds engine limits (L=%d<=%d, S=%d<=%d, W=%d<=%d, LDS image %zu<=%d bytes)", lay->L,
                      PIPAMD_LMAX, lay->S, PIPAMD_SMAX, lay->W, PIPAMD_MAXCOL,
                      pipk_advance_lds_bytes((lay->L + 3) & ~3, (lay->S + 3) & ~3, lay->W, ebits), PIPAMD_LDS_BUDGET);
@@ -188,8 +189,9 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
       e->nev++;
     }
     HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch], st));
+    void *big[2] = {&e->d_scratch, &e->scratch_bytes};
     HIPCHK(pipk_launch_advance_q(jobs, arena, lay.batch, lay.nvar + smax, smax, lay.W, budget, waves, lay.ebits, q5, upper,
-                                 e->d_prof, st));
+                                 big, e->d_prof, st));
     HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
     e->nlaunch++;
     stage++;

@@ -8,8 +8,12 @@
 #define PIPAMD_MAXDET 4   /* reference tab.h:67 MAX_DETERMINANT */
 #define PIPAMD_MAXCOL 512 /* reference type.h:44 */
 #define PIPAMD_MAXPARM 50 /* reference type.h:45 */
-#define PIPAMD_LMAX 4096  /* logical rows the engine can stage in LDS (pipamd_lds_fits has the last word) */
-#define PIPAMD_SMAX 3584  /* real rows (slots) per job */
+/* Row tables are indexed with 16-bit codes (slot < 0x4000, logical row < 0xffff).  A job whose row
+ * tables fit a workgroup's LDS (about 3,400 rows of <= 128 int64 columns) is staged there; a larger
+ * 64-bit job runs with the same tables in HBM (the kernel's GM instantiation), so that a tableau
+ * can grow as with the reference's expanser (traiter.c:55-88) up to these limits. */
+#define PIPAMD_SMAX 16000 /* real rows (slots) per job */
+#define PIPAMD_LMAX (PIPAMD_SMAX + PIPAMD_MAXCOL) /* logical rows */
 #define PIPAMD_LDS_BUDGET (160 * 1024 - 1024) /* dynamic LDS a workgroup can get */
 
 /* One problem ("job") in the device arena.  All offsets are in int64 units from the

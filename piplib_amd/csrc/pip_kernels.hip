@@ -1021,9 +1021,14 @@ struct PipQueue {
   int *out_maxni;
 };
 
-template <class T, int NCH, int NW>
+// GM: the job's row tables (the "LDS image": Shared<T>) live in HBM instead of LDS -- one block of
+// `gimg_bytes` per workgroup at `gimg` -- for jobs whose tables outgrow the 159 KiB a workgroup can
+// get.  Same code, every table access becomes a global access (cached in this CU's L1/L2); only
+// the handful of workgroup scalars stay in LDS.
+template <class T, int NCH, int NW, bool GM>
 __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? PIP_MINWAVES : 1) void pip_advance_kernel(
-    PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit, PipQueue q, u64 *prof) {
+    PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit, PipQueue q, unsigned char *gimg,
+    size_t gimg_bytes, u64 *prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Scalars sc;
   // Determinant limbs (traiter.c:413-446).  64-bit entries: scalar registers.  128-bit entries:
@@ -1050,6 +1055,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   Shared<T> S;
   {
     unsigned char *p = smem;
+    if constexpr (GM) p = gimg + (size_t)blockIdx.x * gimg_bytes;
     S.den = (T *)p;      p += sizeof(T) * Smax;
     // the sort keys are dead once the rows are sorted (before the first pivot row is staged):
     // they share prow's storage, which is sized for the larger of the two
@@ -2054,19 +2060,20 @@ struct AdvanceLaunch {
   int grid;  // workgroups = upper bound on the entries of the input list (0: njobs)
   unsigned long long *prof;
   size_t shm;
+  unsigned char *gimg;  // HBM blocks for the row tables when they do not fit LDS (GM instantiation), else NULL
   hipStream_t stream;
 };
 
 // hipFuncSetAttribute applies to the current device only: remember per (instantiation, device)
 // whether the opt-in to more than 48 KiB of dynamic LDS was made.
-template <class T, int NCH, int NW>
+template <class T, int NCH, int NW, bool GM>
 static hipError_t launch_advance_t(const AdvanceLaunch &a) {
-  const void *fn = (const void *)pip_advance_kernel<T, NCH, NW>;
+  const void *fn = (const void *)pip_advance_kernel<T, NCH, NW, GM>;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  if (a.shm > 48 * 1024) {  // large tableaux: opt in to more than the default dynamic LDS (160 KiB per CU)
+  if (!GM && a.shm > 48 * 1024) {  // large tableaux: opt in to more than the default dynamic LDS (160 KiB per CU)
     static std::atomic<unsigned long long> raised{0};
     if (!((raised.load(std::memory_order_acquire) >> dev) & 1)) {
       e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PIPAMD_LDS_BUDGET);
@@ -2074,14 +2081,17 @@ static hipError_t launch_advance_t(const AdvanceLaunch &a) {
       raised.fetch_or(1ull << dev, std::memory_order_release);
     }
   }
-  int grid = a.grid > 0 && a.grid < a.njobs ? a.grid : a.njobs;
-  hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW>), dim3(grid), dim3(64 * NW), a.shm, a.stream, a.jobs, a.arena, a.njobs,
-                     a.Lmax, a.Smax, a.Wmax, a.iter_limit, a.q, a.prof);
+  const int grid = a.grid > 0 && a.grid < a.njobs ? a.grid : a.njobs;
+  hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW, GM>), dim3(grid), dim3(64 * NW), GM ? 0 : a.shm, a.stream, a.jobs,
+                     a.arena, a.njobs, a.Lmax, a.Smax, a.Wmax, a.iter_limit, a.q, a.gimg, a.shm, a.prof);
   return hipGetLastError();
 }
 template <class T, int NCH>
 static hipError_t launch_advance_w(bool one, const AdvanceLaunch &a) {
-  return one ? launch_advance_t<T, NCH, 1>(a) : launch_advance_t<T, NCH, 4>(a);
+  if constexpr (sizeof(T) == 8) {
+    if (a.gimg) return launch_advance_t<T, NCH, 4, true>(a);  // tables in HBM: four waves per job
+  }
+  return one ? launch_advance_t<T, NCH, 1, false>(a) : launch_advance_t<T, NCH, 4, false>(a);
 }
 
 // waves_per_job: 1 = one wave64 per tableau (latency-bound sparse batches: more tableaux in
@@ -2090,9 +2100,12 @@ static hipError_t launch_advance_w(bool one, const AdvanceLaunch &a) {
 // q5: NULL = job b is workgroup b's; else five device pointers {in_list, in_count, out_list,
 // out_count, out_maxni} (see PipQueue; the in_ pair and the out_ triple may each be NULL) and
 // `grid` = an upper bound on *in_count (0: njobs).
+// big: NULL, or {void **buffer, size_t *bytes} of the caller -- a device buffer this function
+// (re)allocates when the row tables of the launch do not fit LDS (64-bit entries only): the launch
+// then keeps them there, `grid` blocks of the image size.  Without it such a launch is refused.
 extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
                                             int iter_limit, int waves_per_job, int ebits, void *const *q5, int grid,
-                                            unsigned long long *prof, hipStream_t stream) {
+                                            void **big, unsigned long long *prof, hipStream_t stream) {
   if (njobs <= 0) return hipSuccess;
   // LDS arrays are carved at 16/8/4/2/1-byte granularity in that order: keep Lmax, Smax multiples of 4
   Lmax = (Lmax + 3) & ~3;
@@ -2114,12 +2127,30 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
   }
   a.prof = prof;
   a.shm = pipk_advance_lds_bytes(Lmax, Smax, Wmax, ebits);
-  if (a.shm > PIPAMD_LDS_BUDGET) return hipErrorInvalidConfiguration;  // the image of this job mix does not fit a CU
+  a.gimg = nullptr;
+  if (a.shm > PIPAMD_LDS_BUDGET) {  // the row tables of this job mix do not fit a CU's LDS
+    if (ebits != 64 || !big) return hipErrorInvalidConfiguration;
+    void **buf = (void **)big[0];
+    size_t *cap = (size_t *)big[1];
+    const size_t need = (size_t)(a.grid > 0 && a.grid < njobs ? a.grid : njobs) * a.shm;
+    if (*cap < need) {
+      if (*buf) {
+        hipError_t fe = hipFree(*buf);  // waits for the launches that may still use it
+        if (fe != hipSuccess) return fe;
+      }
+      *buf = nullptr;
+      *cap = 0;
+      hipError_t me = hipMalloc(buf, need);
+      if (me != hipSuccess) return me;
+      *cap = need;
+    }
+    a.gimg = (unsigned char *)*buf;
+  }
   a.stream = stream;
   const bool one = waves_per_job == 1;
   const int wp = wp_of(Wmax, ebits);
 #ifdef PIP_ONLY_MAIN  // diagnostic builds (tools/isa_lines.sh): only the 64-bit, <= 128-column, one-wave kernel
-  return (ebits == 64 && wp == 128 && one) ? launch_advance_t<i64, 1, 1>(a) : hipErrorInvalidValue;
+  return (ebits == 64 && wp == 128 && one && !a.gimg) ? launch_advance_t<i64, 1, 1, false>(a) : hipErrorInvalidValue;
 #else
   if (ebits == 128) {
     switch (wp) {
@@ -2140,8 +2171,8 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
 extern "C" hipError_t pipk_launch_advance(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
                                           int iter_limit, int waves_per_job, int ebits, unsigned long long *prof,
                                           hipStream_t stream) {
-  return pipk_launch_advance_q(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, waves_per_job, ebits, nullptr, 0, prof,
-                               stream);
+  return pipk_launch_advance_q(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, waves_per_job, ebits, nullptr, 0, nullptr,
+                               prof, stream);
 }
 
 extern "C" hipError_t pipk_launch_batch_load(PipJob *jobs, i64 *arena, const i64 *rows, PipBatchLayout lay,

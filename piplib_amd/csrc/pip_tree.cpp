@@ -116,6 +116,7 @@ class Tree {
   ~Tree() {
     if (d_arena_) hipFree(d_arena_);
     if (d_jobs_) hipFree(d_jobs_);
+    if (d_big_) hipFree(d_big_);
     if (st_) hipStreamDestroy(st_);
   }
   // reuse the device buffers for another problem
@@ -176,6 +177,10 @@ class Tree {
   i64 *d_arena_ = nullptr;
   size_t arena_words_ = 0, top_ = 0;
   PipJob *d_jobs_ = nullptr;
+  // row tables of jobs that outgrow LDS (the launcher sizes it): {buffer, bytes}
+  void *d_big_ = nullptr;
+  size_t big_bytes_ = 0;
+  void *big_[2] = {&d_big_, &big_bytes_};
   int d_jobs_cap_ = 0;
 
   void fail(int st) {
@@ -208,13 +213,13 @@ class Tree {
   }
   static int even(int x) { return (x + 1) & ~1; }
   static bool rows_fit(int nvar, int S, int W) {
-    return S <= PIPAMD_SMAX && nvar + S <= PIPAMD_LMAX &&
-           pipk_advance_lds_bytes((even(nvar + S) + 3) & ~3, (S + 3) & ~3, W, 64) <= PIPAMD_LDS_BUDGET;
+    (void)W;  // row tables that outgrow LDS live in HBM: only the 16-bit row codes bound a job
+    return S <= PIPAMD_SMAX && even(nvar + S) <= PIPAMD_LMAX;
   }
   // Row capacity of the block a job that ran out of rows is re-housed in: geometric growth (a
   // sub-problem may need thousands of cut rows, and every re-housing copies the whole tableau),
-  // clamped to the largest row count whose LDS image still fits a workgroup -- S+1 when not even
-  // that fits, which alloc_job then refuses with PIPAMD_ST_CAPACITY.
+  // clamped to the engine's row limit -- S+1 when not even that fits, which alloc_job then
+  // refuses with PIPAMD_ST_CAPACITY.
   static int next_rows(int nvar, int S, int W) {
     const int want = std::max(S + 32, S * 3 / 2);
     if (rows_fit(nvar, want, W) || !rows_fit(nvar, S + 1, W)) return rows_fit(nvar, want, W) ? want : S + 1;
@@ -231,8 +236,7 @@ class Tree {
     memset(&j.pj, 0, sizeof j.pj);
     S = std::max(S, ni + 1);
     W = even(std::max(W, nvar + nparm + 1));
-    if (W > PIPAMD_MAXCOL || S > PIPAMD_SMAX || nvar + S > PIPAMD_LMAX ||
-        pipk_advance_lds_bytes((even(nvar + S) + 3) & ~3, (S + 3) & ~3, W, 64) > PIPAMD_LDS_BUDGET) {
+    if (W > PIPAMD_MAXCOL || !rows_fit(nvar, S, W)) {
       if (getenv("PIPAMD_TREE_TRACE"))
         fprintf(stderr, "[tree] job beyond the engine's limits: nvar %d nparm %d ni %d S %d W %d\n", nvar, nparm, ni, S, W);
       fail(PIPAMD_ST_CAPACITY);
@@ -345,7 +349,8 @@ class Tree {
       // bounded effort: one launch of at most SPEC_PIVOTS pivots per job, no re-housing; jobs
       // that are not done stay PIPAMD_ST_RUN / PIPAMD_ST_CAPACITY for a later, unbounded run
       copy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice);
-      HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, SPEC_PIVOTS, n >= 2048 ? 1 : 4, 64, nullptr, st_));
+      HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, SPEC_PIVOTS, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_,
+                                     nullptr, st_));
       copy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost);
       for (int i = 0; i < n; i++) js[i]->pj = tab[i];
       return;
@@ -353,7 +358,8 @@ class Tree {
     for (int pass = 0; pass < 64; pass++) {
       copy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice);
       for (int guard = 0; guard < 4096; guard++) {
-        HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, st_));
+        HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_,
+                                       nullptr, st_));
         copy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost);
         bool again = false;
         for (int i = 0; i < n; i++)
@@ -1019,7 +1025,7 @@ class Forest {
     }
   }
   ~Forest() {
-    void *bufs[] = {d_arena_, d_jobs_, d_off_, d_out_, d_patch_, d_pidx_, d_clone_, d_fresh_, d_fidx_};
+    void *bufs[] = {d_arena_, d_jobs_, d_off_, d_out_, d_patch_, d_pidx_, d_clone_, d_fresh_, d_fidx_, d_big_};
     for (void *b : bufs)
       if (b) hipFree(b);
     if (st_) hipStreamDestroy(st_);
@@ -1148,6 +1154,10 @@ class Forest {
   i64 *d_fresh_ = nullptr, *d_fidx_ = nullptr;
   size_t fresh_cap_ = 0, fidx_cap_ = 0;
   PipJob *d_jobs_ = nullptr;
+  // a launch whose combined row tables outgrow LDS (a tall and a wide job in one step) keeps them in HBM
+  void *d_big_ = nullptr;
+  size_t big_bytes_ = 0;
+  void *big_[2] = {&d_big_, &big_bytes_};
   int *d_patch_ = nullptr;
   size_t arena_cap_ = 0, jobs_cap_ = 0, off_cap_ = 0, out_cap_ = 0, patch_cap_ = 0, pidx_cap_ = 0, clone_cap_ = 0;
   // staging of the current step
@@ -1338,7 +1348,8 @@ class Forest {
     HIPTHROW(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice, st_));
     // the staging vectors must stay alive until the copies are done: sync once before reuse
     for (int guard = 0; guard < 64; guard++) {
-      HIPTHROW(pipk_launch_advance(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, st_));
+      HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_,
+                                     nullptr, st_));
       HIPTHROW(hipMemcpyAsync(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost, st_));
       HIPTHROW(hipStreamSynchronize(st_));
       bool again = false;

@@ -440,3 +440,35 @@ def test_degenerate_shapes(nvar, ni):
     for nq in (0, 1):
         n, _ = compare(rows, nvar, 0, nq, cap_cuts=64)
         assert n == 24
+
+
+@pytest.mark.parametrize("nvar,ni,nq,cap", [(20, 5000, 0, 8), (20, 4200, 1, 600), (200, 3000, 0, 8)])
+def test_rows_beyond_lds(nvar, ni, nq, cap):
+    """Tableaux whose row tables do not fit a workgroup's LDS (more than ~3,400 rows of <= 128
+    columns, ~2,500 of <= 256): the engine keeps the tables in HBM (the kernel's GM instantiation),
+    as the reference's expanser has no row bound (traiter.c:55-88); bit-exact vs the oracle."""
+    from gpu_common import compare
+    from piplib_amd import synth
+    rows = synth.lexmin_batch(5, 3, nvar, ni)
+    n, piv = compare(rows, nvar, 0, nq, cap_cuts=cap)
+    assert n == 3 and piv > 0
+
+
+@pytest.mark.parametrize("ni", [3300, 4500])
+def test_tree_path_many_rows(ni):
+    """The host tree (pipamd_solve_tableau) on a parametric problem with thousands of rows: ~3,300
+    rows is just inside what LDS holds for <= 128 columns (the re-housing clamp of round 1 stopped
+    short of it), 4,500 needs the tables in HBM; text equals the oracle's."""
+    import numpy as np
+    import pipbatch as pb
+    from piplib_amd import engine as eng, synth
+    rows = synth.lexmin_batch(9, 1, 12, ni, nnz=3, cmax=4)[0]          # 12 unknowns | constant
+    rng = np.random.default_rng(ni)
+    par = rng.integers(-1, 2, size=(ni, 1)).astype(np.int64)           # one parameter column
+    ineq = np.concatenate([rows, par], axis=1)
+    ctx = np.array([[1, 0], [-1, 6]], dtype=np.int64)                  # 0 <= p <= 6
+    prob = synth.Problem(12, 1, ni, 2, -1, 1, ineq, ctx)
+    o = pb.run_batch(pb.ORACLEPIP, [prob], timeout=600).results[0]
+    assert o.status == pb.ST_OK
+    text, piv = eng.solve_tableau(eng.Engine(0), 12, 1, ni, 2, -1, 1, ineq, ctx)
+    assert pb.squash(text) == pb.squash(o.text) and piv == o.pivots
