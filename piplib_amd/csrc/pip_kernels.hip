@@ -1025,10 +1025,17 @@ struct PipQueue {
 // `gimg_bytes` per workgroup at `gimg` -- for jobs whose tables outgrow the 159 KiB a workgroup can
 // get.  Same code, every table access becomes a global access (cached in this CU's L1/L2); only
 // the handful of workgroup scalars stay in LDS.
-template <class T, int NCH, int NW, bool GM>
+// SC > 0: the row capacity of the LDS image is the compile-time constant SC (and SC + WP logical
+// rows) instead of the launch parameters Smax / Lmax.  Every table of the image then sits at a
+// constant LDS address: the thirteen base pointers need no scalar registers and no address
+// arithmetic per access (the offsets fold into the ds_ instructions).  Used for the bulk launches
+// of the common shapes (launch_advance_w picks the smallest class that holds the launch).
+template <class T, int NCH, int NW, bool GM, int SC>
 __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? PIP_MINWAVES : 1) void pip_advance_kernel(
-    PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit, PipQueue q, unsigned char *gimg,
+    PipJob *jobs, i64 *arena, int njobs, int Lmax_, int Smax_, int Wmax, int iter_limit, PipQueue q, unsigned char *gimg,
     size_t gimg_bytes, u64 *prof) {
+  const int Smax = SC > 0 ? SC : Smax_;
+  const int Lmax = SC > 0 ? SC + NCH * 64 * ET<T>::CPL : Lmax_;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Scalars sc;
   // Determinant limbs (traiter.c:413-446).  64-bit entries: scalar registers.  128-bit entries:
@@ -2066,9 +2073,9 @@ struct AdvanceLaunch {
 
 // hipFuncSetAttribute applies to the current device only: remember per (instantiation, device)
 // whether the opt-in to more than 48 KiB of dynamic LDS was made.
-template <class T, int NCH, int NW, bool GM>
+template <class T, int NCH, int NW, bool GM, int SC>
 static hipError_t launch_advance_t(const AdvanceLaunch &a) {
-  const void *fn = (const void *)pip_advance_kernel<T, NCH, NW, GM>;
+  const void *fn = (const void *)pip_advance_kernel<T, NCH, NW, GM, SC>;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -2082,16 +2089,38 @@ static hipError_t launch_advance_t(const AdvanceLaunch &a) {
     }
   }
   const int grid = a.grid > 0 && a.grid < a.njobs ? a.grid : a.njobs;
-  hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW, GM>), dim3(grid), dim3(64 * NW), GM ? 0 : a.shm, a.stream, a.jobs,
+  hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW, GM, SC>), dim3(grid), dim3(64 * NW), GM ? 0 : a.shm, a.stream, a.jobs,
                      a.arena, a.njobs, a.Lmax, a.Smax, a.Wmax, a.iter_limit, a.q, a.gimg, a.shm, a.prof);
   return hipGetLastError();
+}
+// the one-wave kernel of <= 128 int64 columns with a compile-time row capacity (see SC above)
+template <int SC>
+static hipError_t launch_static(AdvanceLaunch a, int ebits) {
+  a.Smax = SC;
+  a.Lmax = SC + 128;
+  a.shm = pipk_advance_lds_bytes(a.Lmax, a.Smax, 128, ebits);
+  return launch_advance_t<i64, 1, 1, false, SC>(a);
 }
 template <class T, int NCH>
 static hipError_t launch_advance_w(bool one, const AdvanceLaunch &a) {
   if constexpr (sizeof(T) == 8) {
-    if (a.gimg) return launch_advance_t<T, NCH, 4, true>(a);  // tables in HBM: four waves per job
+    if (a.gimg) return launch_advance_t<T, NCH, 4, true, 0>(a);  // tables in HBM: four waves per job
+#if !defined(PIP_NO_STATIC_IMAGE)
+    if constexpr (NCH == 1) {
+      // row-capacity classes; a launch goes to the smallest class that holds it if that costs at most
+      // an eighth more LDS than its exact size (occupancy is LDS-bound at 24 tableaux per CU)
+      if (one && a.Lmax - a.Smax <= 128) {
+        const int s = a.Smax;
+        if (s <= 64) return launch_static<64>(a, 64);
+        if (s > 84 && s <= 96) return launch_static<96>(a, 64);
+        if (s > 98 && s <= 112) return launch_static<112>(a, 64);
+        if (s > 112 && s <= 128) return launch_static<128>(a, 64);
+        if (s > 140 && s <= 160) return launch_static<160>(a, 64);
+      }
+    }
+#endif
   }
-  return one ? launch_advance_t<T, NCH, 1, false>(a) : launch_advance_t<T, NCH, 4, false>(a);
+  return one ? launch_advance_t<T, NCH, 1, false, 0>(a) : launch_advance_t<T, NCH, 4, false, 0>(a);
 }
 
 // waves_per_job: 1 = one wave64 per tableau (latency-bound sparse batches: more tableaux in
@@ -2150,7 +2179,7 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
   const bool one = waves_per_job == 1;
   const int wp = wp_of(Wmax, ebits);
 #ifdef PIP_ONLY_MAIN  // diagnostic builds (tools/isa_lines.sh): only the 64-bit, <= 128-column, one-wave kernel
-  return (ebits == 64 && wp == 128 && one && !a.gimg) ? launch_advance_t<i64, 1, 1, false>(a) : hipErrorInvalidValue;
+  return (ebits == 64 && wp == 128 && one && !a.gimg) ? launch_advance_w<i64, 1>(true, a) : hipErrorInvalidValue;
 #else
   if (ebits == 128) {
     switch (wp) {
