@@ -96,7 +96,8 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
   const int wp = ebits == 128 ? (lay->W <= 64 ? 64 : (lay->W <= 128 ? 128 : (lay->W <= 256 ? 256 : 512)))
                               : (lay->W <= 128 ? 128 : (lay->W <= 256 ? 256 : 512));
   const int nm = wp / 64;
-  const int64_t state = round_even(lay->S * nm + (3 * lay->L + 7) / 8);
+  // saved summaries, then the determinant log of the last launch (64-bit jobs)
+  const int64_t state = round_even(lay->S * nm + (3 * lay->L + 7) / 8) + 2 * PIPAMD_DETLOG;
   lay->sol_words = (int32_t)sol;
   lay->state_words = (int32_t)state;
   // rows: den[L] (entry type) | flag[L] | ref[L];  then S x W entries;  solution;  saved summaries

@@ -15,6 +15,12 @@
 #define PIPAMD_SMAX 16000 /* real rows (slots) per job */
 #define PIPAMD_LMAX (PIPAMD_SMAX + PIPAMD_MAXCOL) /* logical rows */
 #define PIPAMD_LDS_BUDGET (160 * 1024 - 1024) /* dynamic LDS a workgroup can get */
+/* 64-bit jobs: the pivot kernel does not run the determinant bookkeeping of traiter.c:412-446
+ * itself (wave-uniform scalar work, ~12 % of its instructions); it logs (pivot, denominator of
+ * the pivot row) per pivot -- at most this many per launch -- and pip_det_replay_kernel replays
+ * the log right after the launch, one wave per job: the gcds of 64 pivots at a time on the lanes,
+ * only the walk over the limbs sequentially. */
+#define PIPAMD_DETLOG 256
 
 /* One problem ("job") in the device arena.  All offsets are in int64 units from the
  * arena base and are even (rows are 16-byte aligned).
@@ -25,6 +31,7 @@
  * Mirrors the reference's struct T / struct L (tab.h:36-85) without pointers. */
 typedef struct PipJob {
   int64_t vals_off, rows_off, sol_off, state_off;
+  int64_t log_off; /* 2 * PIPAMD_DETLOG int64: the determinant log of the last launch (64-bit jobs) */
   int32_t nvar, nparm, ni, bigparm;
   int32_t tflags;
   int32_t L, S, W;
@@ -33,6 +40,7 @@ typedef struct PipJob {
   int64_t det[2 * PIPAMD_MAXDET]; /* multi-limb determinant, tab.h:76-81: det[i] (64-bit entries) or
                                      det[2i] | det[2i+1] << 64 (128-bit entries) */
   uint64_t maxabs;
+  int32_t nlog, pad_; /* entries of the determinant log not replayed yet */
   int32_t state_nch, ebits; /* ebits: 64 or 128 (0 = 64) */ /* row-chunk count (NCH) of the launch that saved the state block */
 } PipJob;
 

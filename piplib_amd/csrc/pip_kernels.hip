@@ -1095,10 +1095,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   int nligne = nvar + ni;
   int npiv = J->npiv, ncut = J->ncut, nupd = J->nupd;
   int ldet = J->ldet;
-  T det[DET_LDS ? 1 : PIPAMD_MAXDET];
-  if constexpr (!DET_LDS) {
-    for (int i = 0; i < PIPAMD_MAXDET; i++) det[i] = J->det[i];
-  }
+  // 64-bit entries: the determinant limbs (traiter.c:412-446) are not updated here -- every pivot
+  // appends (pivot, denominator of the pivot row) to the job's log, pip_det_replay_kernel runs the
+  // bookkeeping and its "Integer overflow" tests after the launch, one lane per job
+  i64 *g_log = arena + J->log_off;
+  int nlog = DET_LDS ? 0 : J->nlog;
   if (ni > Smax || nligne > Lmax) {  // this launch's LDS image is too small: stay RUN for a larger one
     if (tid == 0 && q.out_count) {
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
@@ -1240,6 +1241,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   PROF(0);
   for (int iter = 0;; iter++) {
     if (iter >= iter_limit) break;  // status stays RUN: the host relaunches
+    if (!DET_LDS && nlog >= PIPAMD_DETLOG) break;  // determinant log full: likewise
     int pivi = sc.pivi;
     if (pivi == BIG_I) {
       // -------------- exam_coef, then (if nothing is negative) integrer ---------
@@ -1527,41 +1529,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         break;
       }
     } else {
-      T d = gcd_i64(pivot, dpiv);
-      T ppivot = pivot, dppiv = dpiv;
-      if (d != 1) {
-        ppivot = exact_quo(pivot, d);
-        dppiv = exact_quo(dpiv, d);
+      if (tid == 0) {
+        g_log[2 * nlog] = (i64)pivot;
+        g_log[2 * nlog + 1] = (i64)dpiv;
       }
-      // once dppiv is 1 the remaining limbs would be divided by gcd(limb, 1) = 1
-      for (int i = 0; i < ldet && dppiv != 1; i++) {
-        d = gcd_i64(det[i], dppiv);
-        if (d != 1) {
-          det[i] = exact_quo(det[i], d);
-          dppiv = exact_quo(dppiv, d);
-        }
-      }
-      bool ovf = dppiv != 1;
-      // ppivot == 1 with room in the first limb: det[0] *= 1
-      if (!ovf && !(ppivot == 1 && log2_64(det[0]) + 1 < ET<T>::BITS)) {
-        int i = 0;
-        for (; i < ldet; i++)
-          if (log2_64(det[i]) + log2_64(ppivot) < ET<T>::BITS) {
-            det[i] = wmul(det[i], ppivot);
-            break;
-          }
-        if (i >= ldet) {
-          ldet++;
-          if (ldet >= PIPAMD_MAXDET)
-            ovf = true;
-          else
-            det[i] = ppivot;
-        }
-      }
-      if (ovf) {
-        status = PIPAMD_ST_OVERFLOW;
-        break;
-      }
+      nlog++;
     }
     const int ku = S.urow[pivj];  // unit row of the entering column
     const int pred = psig_v & SIG_RED;
@@ -1769,8 +1741,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         J->det[2 * i + 1] = (i64)(u64)((u128)sdet[i] >> 64);
       }
     } else {
-      J->ldet = ldet;
-      for (int i = 0; i < PIPAMD_MAXDET; i++) J->det[i] = det[i];
+      (void)ldet;
+      J->nlog = nlog;
     }
     J->tflags = tflags;
     J->state_nch = NCH;
@@ -1784,6 +1756,169 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   }
   PROF(8);
   PROF_FLUSH(prof);
+}
+
+// ------------------------------------------------------------- determinant replay
+// traiter.c:394-446 for the pivots a launch logged, one WAVE per job: d = gcd(pivot, dpiv); the
+// limbs lose the factors of dpiv / d (if some factor is left: "Integer overflow"); the first limb
+// with room takes pivot / d (a fourth limb: "Integer overflow").  The bookkeeping never feeds
+// back into the pivot loop, so it can trail it; an overflow found here overrides whatever the
+// job's status became and sets the pivot count to the pivot that overflowed.
+// Two steps per block of 64 log entries: gcd(pivot, dpiv) and the two quotients do not depend on
+// the limbs, so the lanes compute them for 64 pivots at once; only the walk over the limbs (a
+// division pass when dpiv / d != 1, then the first-fit multiplication) is sequential, on the
+// scalar unit.  In the pivot loop itself this bookkeeping was ~12 % of all instructions.
+__global__ __launch_bounds__(64) void pip_det_replay_kernel(PipJob *jobs, i64 *arena, int njobs, PipQueue q) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int nq = q.in_count ? *q.in_count : njobs;
+  if (t >= nq) return;
+  PipJob *J = &jobs[q.in_list ? q.in_list[t] : t];
+  const int nlog = J->nlog;
+  if (nlog <= 0 || J->ebits == 128) return;
+  const i64 *lg = arena + J->log_off;
+  i64 det0 = uni64((i64)J->det[0]), det1 = uni64((i64)J->det[1]), det2 = uni64((i64)J->det[2]), det3 = uni64((i64)J->det[3]);
+  int ldet = __builtin_amdgcn_readfirstlane(J->ldet);
+  int bad = -1;
+  for (int base = 0; base < nlog && bad < 0; base += 64) {
+    const int k = base + lane;
+    i64 pp = 1, dp = 1;
+    if (k < nlog) {
+      const longlong2 e = *reinterpret_cast<const longlong2 *>(lg + 2 * k);
+      pp = e.x;
+      dp = e.y;
+      if (dp != 1) {
+        const i64 d = gcd_i64(pp, dp);
+        if (d != 1) {
+          pp = exact_quo(pp, d);
+          dp = exact_quo(dp, d);
+        }
+      }
+    }
+    const int n = nlog - base < 64 ? nlog - base : 64;
+    for (int j = 0; j < n; j++) {
+      const i64 ppivot = readlane64(pp, j);
+      i64 dppiv = readlane64(dp, j);
+      // once dppiv is 1 the remaining limbs would be divided by gcd(limb, 1) = 1
+#define PIP_DET_DIVIDE(limb, i)                    \
+  if ((i) < ldet && dppiv != 1) {                  \
+    const i64 d_ = gcd_i64(limb, dppiv);           \
+    if (d_ != 1) {                                 \
+      limb = exact_quo(limb, d_);                  \
+      dppiv = exact_quo(dppiv, d_);                \
+    }                                              \
+  }
+      PIP_DET_DIVIDE(det0, 0)
+      PIP_DET_DIVIDE(det1, 1)
+      PIP_DET_DIVIDE(det2, 2)
+      PIP_DET_DIVIDE(det3, 3)
+#undef PIP_DET_DIVIDE
+      bool ovf = dppiv != 1;
+      if (!ovf) {
+        const int lp = log2_64(ppivot);
+        if (0 < ldet && log2_64(det0) + lp < 64)
+          det0 = wmul(det0, ppivot);
+        else if (1 < ldet && log2_64(det1) + lp < 64)
+          det1 = wmul(det1, ppivot);
+        else if (2 < ldet && log2_64(det2) + lp < 64)
+          det2 = wmul(det2, ppivot);
+        else if (3 < ldet && log2_64(det3) + lp < 64)
+          det3 = wmul(det3, ppivot);
+        else {
+          ldet++;
+          if (ldet >= PIPAMD_MAXDET)
+            ovf = true;
+          else if (ldet == 1)
+            det0 = ppivot;
+          else if (ldet == 2)
+            det1 = ppivot;
+          else
+            det2 = ppivot;
+        }
+      }
+      if (ovf) {  // traiter.c:424,442: the reference exits inside this call of pivoter
+        bad = base + j;
+        break;
+      }
+    }
+  }
+  if (lane == 0) {
+    if (bad >= 0) {
+      J->status = PIPAMD_ST_OVERFLOW;
+      J->npiv = J->npiv - nlog + bad + 1;
+    }
+    J->det[0] = det0;
+    J->det[1] = det1;
+    J->det[2] = det2;
+    J->det[3] = det3;
+    J->ldet = ldet;
+    J->nlog = 0;
+  }
+}
+
+// The same with one LANE per job (64 jobs per wave): far fewer instructions issued in all -- what
+// counts behind a bulk launch, when the GPU is kept busy by other batches -- at the price of a
+// longer latency per job (a lane walks its log alone).
+__global__ __launch_bounds__(64) void pip_det_replay_lanes_kernel(PipJob *jobs, i64 *arena, int njobs, PipQueue q) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nq = q.in_count ? *q.in_count : njobs;
+  if (t >= nq) return;
+  PipJob *J = &jobs[q.in_list ? q.in_list[t] : t];
+  const int nlog = J->nlog;
+  if (nlog <= 0 || J->ebits == 128) return;
+  const i64 *lg = arena + J->log_off;
+  i64 det[PIPAMD_MAXDET];
+  for (int i = 0; i < PIPAMD_MAXDET; i++) det[i] = J->det[i];
+  int ldet = J->ldet;
+  for (int k = 0; k < nlog; k++) {
+    const longlong2 e = *reinterpret_cast<const longlong2 *>(lg + 2 * k);
+    i64 ppivot = e.x, dppiv = e.y;
+    if (dppiv != 1) {
+      i64 d = gcd_i64(ppivot, dppiv);
+      if (d != 1) {
+        ppivot = exact_quo(ppivot, d);
+        dppiv = exact_quo(dppiv, d);
+      }
+      // once dppiv is 1 the remaining limbs would be divided by gcd(limb, 1) = 1
+      for (int i = 0; i < PIPAMD_MAXDET; i++) {
+        if (i >= ldet || dppiv == 1) break;
+        d = gcd_i64(det[i], dppiv);
+        if (d != 1) {
+          det[i] = exact_quo(det[i], d);
+          dppiv = exact_quo(dppiv, d);
+        }
+      }
+    }
+    bool ovf = dppiv != 1;
+    // ppivot == 1 with room in the first limb: det[0] *= 1
+    if (!ovf && !(ppivot == 1 && log2_64(det[0]) + 1 < 64)) {
+      bool placed = false;
+      const int lp = log2_64(ppivot);
+      for (int i = 0; i < PIPAMD_MAXDET; i++) {
+        if (i >= ldet || placed) break;
+        if (log2_64(det[i]) + lp < 64) {
+          det[i] = wmul(det[i], ppivot);
+          placed = true;
+        }
+      }
+      if (!placed) {
+        ldet++;
+        if (ldet >= PIPAMD_MAXDET)
+          ovf = true;
+        else {
+          for (int i = 0; i < PIPAMD_MAXDET; i++)  // det[ldet - 1] without a dynamic register index
+            if (i == ldet - 1) det[i] = ppivot;
+        }
+      }
+    }
+    if (ovf) {
+      J->status = PIPAMD_ST_OVERFLOW;
+      J->npiv = J->npiv - nlog + k + 1;
+      break;
+    }
+  }
+  for (int i = 0; i < PIPAMD_MAXDET; i++) J->det[i] = det[i];
+  J->ldet = ldet;
+  J->nlog = 0;
 }
 
 // ---------------------------------------------------------------- batch load
@@ -1835,6 +1970,8 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
     J->vals_off = base + rows_words;
     J->sol_off = J->vals_off + (int64_t)lay.S * lay.W * EW;
     J->state_off = J->sol_off + lay.sol_words;
+    J->log_off = J->state_off + lay.state_words - 2 * PIPAMD_DETLOG;
+    J->nlog = 0;
     J->nvar = lay.nvar;
     J->nparm = lay.nparm;
     J->ni = lay.ni;
@@ -2126,6 +2263,8 @@ static hipError_t launch_advance_w(bool one, const AdvanceLaunch &a) {
 // waves_per_job: 1 = one wave64 per tableau (latency-bound sparse batches: more tableaux in
 // flight per CU), 4 = four waves share a tableau's rows (few, large tableaux).
 // ebits: 64 or 128 -- every job of the launch must have that entry width.
+static hipError_t launch_by_shape(const AdvanceLaunch &a, bool one, int wp, int ebits);
+
 // q5: NULL = job b is workgroup b's; else five device pointers {in_list, in_count, out_list,
 // out_count, out_maxni} (see PipQueue; the in_ pair and the out_ triple may each be NULL) and
 // `grid` = an upper bound on *in_count (0: njobs).
@@ -2178,6 +2317,18 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
   a.stream = stream;
   const bool one = waves_per_job == 1;
   const int wp = wp_of(Wmax, ebits);
+  hipError_t le = launch_by_shape(a, one, wp, ebits);
+  if (le != hipSuccess || ebits != 64) return le;
+  // the determinant bookkeeping of the pivots just logged, one wave per job
+  const int nrep = a.grid > 0 && a.grid < njobs ? a.grid : njobs;
+  if (one)  // behind a bulk launch: fewest instructions
+    hipLaunchKernelGGL(pip_det_replay_lanes_kernel, dim3((nrep + 63) / 64), dim3(64), 0, stream, jobs, arena, njobs, a.q);
+  else  // few jobs, someone is waiting for them: shortest latency
+    hipLaunchKernelGGL(pip_det_replay_kernel, dim3(nrep), dim3(64), 0, stream, jobs, arena, njobs, a.q);
+  return hipGetLastError();
+}
+
+static hipError_t launch_by_shape(const AdvanceLaunch &a, bool one, int wp, int ebits) {
 #ifdef PIP_ONLY_MAIN  // diagnostic builds (tools/isa_lines.sh): only the 64-bit, <= 128-column, one-wave kernel
   return (ebits == 64 && wp == 128 && one && !a.gimg) ? launch_advance_w<i64, 1>(true, a) : hipErrorInvalidValue;
 #else

@@ -244,7 +244,7 @@ class Tree {
     const int L = even(nvar + S);
     const int nm = 8;  // room for the bitmaps of any launch geometry (jobs of mixed widths share launches)
     const size_t sol = (size_t)even(nvar * (W - nvar) + nvar);
-    const size_t state = (size_t)even(S * nm + (3 * L + 7) / 8);
+    const size_t state = (size_t)even(S * nm + (3 * L + 7) / 8) + 2 * PIPAMD_DETLOG;  // summaries | determinant log
     j.block_words = 2 * (size_t)L + (size_t)S * W + sol + state;
     ensure_arena(top_ + j.block_words);
     j.block_off = (i64)top_;
@@ -253,6 +253,7 @@ class Tree {
     j.pj.vals_off = j.block_off + 2 * (i64)L;
     j.pj.sol_off = j.pj.vals_off + (i64)S * W;
     j.pj.state_off = j.pj.sol_off + (i64)sol;
+    j.pj.log_off = j.pj.state_off + (i64)state - 2 * PIPAMD_DETLOG;
     j.pj.nvar = nvar;
     j.pj.nparm = nparm;
     j.pj.ni = ni;
@@ -1168,7 +1169,8 @@ class Forest {
   static size_t block_words(int nvar, int S, int W) {
     W = even(W);
     const int L = even(nvar + S);
-    return 2 * (size_t)L + (size_t)S * W + (size_t)even(nvar * (W - nvar) + nvar) + (size_t)even(S * 8 + (3 * L + 7) / 8);
+    return 2 * (size_t)L + (size_t)S * W + (size_t)even(nvar * (W - nvar) + nvar) + (size_t)even(S * 8 + (3 * L + 7) / 8) +
+           2 * PIPAMD_DETLOG;
   }
   template <class T>
   void ensure(T *&buf, size_t &cap, size_t bytes) {
@@ -1222,6 +1224,7 @@ class Forest {
     pj.vals_off = off + 2 * (i64)L;
     pj.sol_off = pj.vals_off + (i64)S * W;
     pj.state_off = pj.sol_off + even(nvar * (W - nvar) + nvar);
+    pj.log_off = off + (i64)words - 2 * PIPAMD_DETLOG;
     pj.nvar = nvar;
     pj.nparm = nparm;
     pj.ni = ni;
@@ -1347,7 +1350,7 @@ class Forest {
     }
     HIPTHROW(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice, st_));
     // the staging vectors must stay alive until the copies are done: sync once before reuse
-    for (int guard = 0; guard < 64; guard++) {
+    for (int guard = 0; guard < 4096; guard++) {
       HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_,
                                      nullptr, st_));
       HIPTHROW(hipMemcpyAsync(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost, st_));
