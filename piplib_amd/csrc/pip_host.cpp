@@ -191,8 +191,10 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
     }
     HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch], st));
     void *big[2] = {&e->d_scratch, &e->scratch_bytes};
+    // a uniform batch without parameters whose rows fill a wave's 128 columns exactly: FULL kernels
+    const int hints = (lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 && lay.W == 128) ? 1 : 0;
     HIPCHK(pipk_launch_advance_q(jobs, arena, lay.batch, lay.nvar + smax, smax, lay.W, budget, waves, lay.ebits, q5, upper,
-                                 big, e->d_prof, st));
+                                 big, hints, e->d_prof, st));
     HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
     e->nlaunch++;
     stage++;

@@ -36,7 +36,8 @@ size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax, int ebits);
 hipError_t pipk_launch_advance(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
                                int waves_per_job, int ebits, unsigned long long *prof, hipStream_t stream);
 hipError_t pipk_launch_advance_q(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
-                                 int waves_per_job, int ebits, void *const *q5, int grid, void **big, unsigned long long *prof,
+                                 int waves_per_job, int ebits, void *const *q5, int grid, void **big, int hints,
+                                 unsigned long long *prof,
                                  hipStream_t stream);
 hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long long *rows, PipBatchLayout lay,
                                   hipStream_t stream);

@@ -1030,7 +1030,11 @@ struct PipQueue {
 // constant LDS address: the thirteen base pointers need no scalar registers and no address
 // arithmetic per access (the offsets fold into the ds_ instructions).  Used for the bulk launches
 // of the common shapes (launch_advance_w picks the smallest class that holds the launch).
-template <class T, int NCH, int NW, bool GM, int SC>
+// FULL: every job of the launch has no parameters, no big parameter and rows that fill the wave's
+// registers exactly (nvar + 1 == W == the columns a wave covers, e.g. 127 unknowns + constant):
+// column counts and the row stride are compile-time constants, so the per-column range checks, the
+// parameter-sign bookkeeping of the row summaries and the stride multiplications disappear.
+template <class T, int NCH, int NW, bool GM, int SC, bool FULL>
 __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? PIP_MINWAVES : 1) void pip_advance_kernel(
     PipJob *jobs, i64 *arena, int njobs, int Lmax_, int Smax_, int Wmax, int iter_limit, PipQueue q, unsigned char *gimg,
     size_t gimg_bytes, u64 *prof) {
@@ -1081,11 +1085,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     S.rcls = (u8 *)p;    p += Smax;
   }
 
-  const int nvar = J->nvar, nparm = J->nparm, bigparm = J->bigparm;
+  if constexpr (FULL) {
+    if (J->nvar != WP - 1 || J->nparm != 0 || J->bigparm >= 0 || J->W != WP) {  // the launcher's promise does not hold
+      if (tid == 0) J->status = PIPAMD_ST_INTERNAL;
+      return;
+    }
+  }
+  const int nvar = FULL ? WP - 1 : J->nvar, nparm = FULL ? 0 : J->nparm, bigparm = FULL ? -1 : J->bigparm;
   const bool has_parm = nparm > 0;
   int tflags = J->tflags;
   int ni = J->ni;
-  const int L = J->L, Sl = J->S, W = J->W;
+  const int L = J->L, Sl = J->S, W = FULL ? WP : J->W;
   const int ncol = nvar + nparm + 1;
   const int ncolp = ET<T>::CPL == 2 ? ((ncol + 1) & ~1) : ncol;  // rows are whole 16-byte units
   T *vals = (T *)(arena + J->vals_off);
@@ -2202,6 +2212,7 @@ struct AdvanceLaunch {
   int njobs, Lmax, Smax, Wmax, iter_limit;
   PipQueue q;
   int grid;  // workgroups = upper bound on the entries of the input list (0: njobs)
+  bool full; // every job: no parameters, no big parameter, nvar + 1 == W == 128 (see FULL)
   unsigned long long *prof;
   size_t shm;
   unsigned char *gimg;  // HBM blocks for the row tables when they do not fit LDS (GM instantiation), else NULL
@@ -2210,9 +2221,9 @@ struct AdvanceLaunch {
 
 // hipFuncSetAttribute applies to the current device only: remember per (instantiation, device)
 // whether the opt-in to more than 48 KiB of dynamic LDS was made.
-template <class T, int NCH, int NW, bool GM, int SC>
+template <class T, int NCH, int NW, bool GM, int SC, bool FULL = false>
 static hipError_t launch_advance_t(const AdvanceLaunch &a) {
-  const void *fn = (const void *)pip_advance_kernel<T, NCH, NW, GM, SC>;
+  const void *fn = (const void *)pip_advance_kernel<T, NCH, NW, GM, SC, FULL>;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -2226,7 +2237,7 @@ static hipError_t launch_advance_t(const AdvanceLaunch &a) {
     }
   }
   const int grid = a.grid > 0 && a.grid < a.njobs ? a.grid : a.njobs;
-  hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW, GM, SC>), dim3(grid), dim3(64 * NW), GM ? 0 : a.shm, a.stream, a.jobs,
+  hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW, GM, SC, FULL>), dim3(grid), dim3(64 * NW), GM ? 0 : a.shm, a.stream, a.jobs,
                      a.arena, a.njobs, a.Lmax, a.Smax, a.Wmax, a.iter_limit, a.q, a.gimg, a.shm, a.prof);
   return hipGetLastError();
 }
@@ -2236,7 +2247,7 @@ static hipError_t launch_static(AdvanceLaunch a, int ebits) {
   a.Smax = SC;
   a.Lmax = SC + 128;
   a.shm = pipk_advance_lds_bytes(a.Lmax, a.Smax, 128, ebits);
-  return launch_advance_t<i64, 1, 1, false, SC>(a);
+  return a.full ? launch_advance_t<i64, 1, 1, false, SC, true>(a) : launch_advance_t<i64, 1, 1, false, SC, false>(a);
 }
 template <class T, int NCH>
 static hipError_t launch_advance_w(bool one, const AdvanceLaunch &a) {
@@ -2271,9 +2282,11 @@ static hipError_t launch_by_shape(const AdvanceLaunch &a, bool one, int wp, int 
 // big: NULL, or {void **buffer, size_t *bytes} of the caller -- a device buffer this function
 // (re)allocates when the row tables of the launch do not fit LDS (64-bit entries only): the launch
 // then keeps them there, `grid` blocks of the image size.  Without it such a launch is refused.
+// hints: bit 0 = every job of the launch has no parameters, no big parameter and nvar + 1 == W ==
+// the wave's column coverage (the caller knows its batch is uniform): see FULL.
 extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
                                             int iter_limit, int waves_per_job, int ebits, void *const *q5, int grid,
-                                            void **big, unsigned long long *prof, hipStream_t stream) {
+                                            void **big, int hints, unsigned long long *prof, hipStream_t stream) {
   if (njobs <= 0) return hipSuccess;
   // LDS arrays are carved at 16/8/4/2/1-byte granularity in that order: keep Lmax, Smax multiples of 4
   Lmax = (Lmax + 3) & ~3;
@@ -2294,6 +2307,7 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
     a.grid = grid;
   }
   a.prof = prof;
+  a.full = (hints & 1) != 0;
   a.shm = pipk_advance_lds_bytes(Lmax, Smax, Wmax, ebits);
   a.gimg = nullptr;
   if (a.shm > PIPAMD_LDS_BUDGET) {  // the row tables of this job mix do not fit a CU's LDS
@@ -2352,7 +2366,7 @@ extern "C" hipError_t pipk_launch_advance(PipJob *jobs, i64 *arena, int njobs, i
                                           int iter_limit, int waves_per_job, int ebits, unsigned long long *prof,
                                           hipStream_t stream) {
   return pipk_launch_advance_q(jobs, arena, njobs, Lmax, Smax, Wmax, iter_limit, waves_per_job, ebits, nullptr, 0, nullptr,
-                               prof, stream);
+                               0, prof, stream);
 }
 
 extern "C" hipError_t pipk_launch_batch_load(PipJob *jobs, i64 *arena, const i64 *rows, PipBatchLayout lay,

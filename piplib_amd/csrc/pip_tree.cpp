@@ -350,7 +350,7 @@ class Tree {
       // bounded effort: one launch of at most SPEC_PIVOTS pivots per job, no re-housing; jobs
       // that are not done stay PIPAMD_ST_RUN / PIPAMD_ST_CAPACITY for a later, unbounded run
       copy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice);
-      HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, SPEC_PIVOTS, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_,
+      HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, SPEC_PIVOTS, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_, 0,
                                      nullptr, st_));
       copy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost);
       for (int i = 0; i < n; i++) js[i]->pj = tab[i];
@@ -359,7 +359,7 @@ class Tree {
     for (int pass = 0; pass < 64; pass++) {
       copy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice);
       for (int guard = 0; guard < 4096; guard++) {
-        HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_,
+        HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_, 0,
                                        nullptr, st_));
         copy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost);
         bool again = false;
@@ -1351,7 +1351,7 @@ class Forest {
     HIPTHROW(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice, st_));
     // the staging vectors must stay alive until the copies are done: sync once before reuse
     for (int guard = 0; guard < 4096; guard++) {
-      HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_,
+      HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_, 0,
                                      nullptr, st_));
       HIPTHROW(hipMemcpyAsync(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost, st_));
       HIPTHROW(hipStreamSynchronize(st_));
