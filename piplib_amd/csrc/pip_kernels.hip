@@ -626,6 +626,127 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
   return true;
 }
 
+// The same row update when every operand is small: the row's and the pivot row's entries below
+// 2^15 (magnitude class 0) and |lpiv|, |foo|, |dpiv| < 2^15.  Then every product is below 2^30 and
+// every z below 2^31: 24-bit multiplies (full rate, unlike the 64-bit product's three quarter-rate
+// multiplies) and 32-bit registers all the way through the gcd refinement and the division give
+// the same bits as the 64-bit code above.  64-bit entries only.
+template <int NCH>
+__device__ __forceinline__ bool update_row_small(RowRegs<i64, NCH> &r, const i64 *prow, int pivj, int lp, int foo, int dpiv,
+                                                 i64 g0, int lane, i64 &newden) {
+  int z[NCH][2];
+  unsigned mx = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int j = colof<i64>(c, lane, h);
+      const int p = (int)r.v[c][h], q = (int)prow[j];
+      int v = __mul24(p, lp) - __mul24(q, foo);
+      if (j == pivj) v = __mul24(dpiv, foo);
+      z[c][h] = v;
+      mx |= (unsigned)(v < 0 ? -v : v);
+    }
+  newden = g0;
+  bool ok = true;
+  if (g0 != 1) {
+    u64 g64 = (u64)uni64((i64)uabs64(g0));
+    if ((g64 >> 32) == 0) {
+      unsigned g = (unsigned)g64;
+      for (;;) {
+        unsigned rr = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const unsigned a = (unsigned)(z[c][h] < 0 ? -z[c][h] : z[c][h]);
+            const unsigned m = g == 0 ? a : a % g;
+            rr = rr ? rr : m;
+          }
+        const u64 nz = __ballot(rr != 0);
+        if (!nz) break;
+        const unsigned r0 = __builtin_amdgcn_readlane(rr, __ffsll((long long)nz) - 1);
+        g = gcd_u32(g, r0);
+        if (g == 1) break;
+      }
+      if (g == 0) ok = false;  // the reference would divide by zero here
+      if (g > 1) {
+        const int sh = __builtin_ctz(g);
+        const unsigned m = g >> sh;
+        unsigned inv = m;  // 3 correct bits, doubled by every step
+        inv *= 2u - m * inv;
+        inv *= 2u - m * inv;
+        inv *= 2u - m * inv;
+        inv *= 2u - m * inv;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int v = z[c][h];
+            const unsigned qq = ((unsigned)(v < 0 ? -v : v) >> sh) * inv;
+            z[c][h] = v < 0 ? -(int)qq : (int)qq;
+          }
+        const unsigned qd = ((unsigned)uabs64(g0) >> sh) * inv;
+        newden = g0 < 0 ? wneg((i64)qd) : (i64)qd;
+      }
+    } else if (__ballot(mx != 0) == 0) {
+      // a zero row under a denominator beyond 32 bits: gcd(g0, 0, ..., 0) = |g0|
+      newden = g0 < 0 ? -1 : 1;
+    } else {
+      // a denominator beyond 32 bits with 31-bit entries: the gcd is that of the entries (found by
+      // the same refinement, starting from the first non-zero one) with the denominator -- gcd is
+      // associative and commutative, so this is the reference's left fold
+      unsigned first = 0;
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const unsigned a = (unsigned)(z[c][h] < 0 ? -z[c][h] : z[c][h]);
+          first = first ? first : a;
+        }
+      unsigned g = __builtin_amdgcn_readlane(first, __ffsll((long long)__ballot(first != 0)) - 1);
+      while (g != 1) {
+        unsigned rr = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const unsigned a = (unsigned)(z[c][h] < 0 ? -z[c][h] : z[c][h]);
+            const unsigned m = a % g;
+            rr = rr ? rr : m;
+          }
+        const u64 nz = __ballot(rr != 0);
+        if (!nz) break;
+        g = gcd_u32(g, __builtin_amdgcn_readlane(rr, __ffsll((long long)nz) - 1));
+      }
+      const unsigned g32 = (unsigned)gcd_mag(g64, (u64)g);  // divides the entries: fits 32 bits
+      if (g32 > 1) {
+        const int sh = __builtin_ctz(g32);
+        const unsigned m = g32 >> sh;
+        unsigned inv = m;
+        inv *= 2u - m * inv;
+        inv *= 2u - m * inv;
+        inv *= 2u - m * inv;
+        inv *= 2u - m * inv;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int v = z[c][h];
+            const unsigned qq = ((unsigned)(v < 0 ? -v : v) >> sh) * inv;
+            z[c][h] = v < 0 ? -(int)qq : (int)qq;
+          }
+        newden = cquo(g0, (i64)g32);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) r.v[c][h] = (i64)z[c][h];
+  return ok;
+}
+
 // integrer.c:98-150 bezout: z with z*y == x (mod delta) when gcd(y, delta) == 1, else 0.
 // Wave-uniform scalar work (deepest-cut option only).
 template <class T>
@@ -1508,6 +1629,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     const int wq0 = S.work[wave], wq1 = S.work[wave + NW < Smax ? wave + NW : 0];
     const T dpiv_v = S.den[pslot];
     const int psig_v = S.sig[pslot];
+    const int prow_cls = S.rcls[pslot];  // magnitude class of the pivot row (as last published)
     if (pivj == -1) {  // traiter.c:782-785
       status = PIPAMD_ST_NIL;
       break;
@@ -1624,7 +1746,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
               g0 = wmul(lp, den_s);
             }
             PROF(10);
-            if (!update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
+            bool done_small = false;
+            if constexpr (sizeof(T) == 8) {
+              // both rows in magnitude class 0 (entries below 2^15) and small multipliers: 32-bit path
+              const T lim = (T)1 << 15;
+              if (S.rcls[s] == 0 && prow_cls == 0 && lp < lim && foo < lim && foo > -lim && dpiv < lim && dpiv > -lim) {
+                if (!update_row_small<NCH>(r, S.prow, pivj, (int)lp, (int)foo, (int)dpiv, g0, lane, nd)) {
+                  if (lane == 0) sc.bad = 1;
+                }
+                done_small = true;
+              }
+            }
+            if (!done_small && !update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
               if (lane == 0) sc.bad = 1;
             }
             PROF(11);
