@@ -69,11 +69,19 @@ def cpu_baseline(rows, nvar, ni):
     else:
         return None
     cores = max(1, len(os.sched_getaffinity(0)))
+    quota = None
+    try:  # a container's CPU share (cgroup v2): more processes than that only take turns
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+            cores = min(cores, quota)
+    except (OSError, ValueError):
+        pass
     # ~25k pivots per process (about 0.3-0.7 s each); all of the batch at most
     per = max(1, min(320, rows.shape[0] // cores))
     # on a many-core host a process's share of the batch is small: solve it `reps` times over, so
-    # that every process runs for a few tenths of a second (about 10-30 s of CPU work in all)
-    reps = max(1, min(8, 160 // per))
+    # that every process runs for about a second (about 10-30 s of CPU work in all)
+    reps = max(1, min(8, 1280 // per))
     chunks = [np.concatenate([rows[c * per:(c + 1) * per]] * reps) for c in range(cores)]
 
     def run_with(x):
@@ -99,6 +107,7 @@ def cpu_baseline(rows, nvar, ni):
     except OSError:
         pass
     return {"value": piv / tmax, "unit": "pivots/s", "cores": cores, "kind": kind, "cpu": model,
+            "cpus_in_affinity_mask": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota,
             "build": "gcc -O3 -fomit-frame-pointer, one executable (oracle/Makefile refpip_fast)" if exe == fast else "see oracle/Makefile",
             "sample": f"first {per * cores} tableaux of rank 0's first batch, {cores} processes x {per} tableaux x "
                       f"{reps} repeats ({piv} pivots), slowest process {tmax:.2f} s of traiter() time "
@@ -126,7 +135,7 @@ class Lanes:
                 e.set_round_pivots(args.round)
             if args.round_rows:
                 e.set_round_rows(args.round_rows)
-            bulk_min = args.bulk_min if args.bulk_min > 0 else (256 if depth > 1 else 0)
+            bulk_min = args.bulk_min if args.bulk_min > 0 else (256 if depth > 1 else 0)  # depth = this Lanes' lane count
             if bulk_min:
                 e.set_bulk_min(bulk_min)
             b = eng.Batch(e, torch.as_tensor(gen(seeds[i]), dtype=torch.int64).to(dev), cfg["nvar"], 0,
@@ -410,15 +419,15 @@ def main():
 
     if not args.no_others and world == 1:
         # one batch at a time (what a caller gets from a single pipamd_batch_load + pipamd_batch_solve)
-        one = Lanes.__new__(Lanes)
-        one.torch, one.eng, one.cfg, one.dev, one.depth = torch, eng, cfg, dev, 1
-        one.lanes, one.stagger, one.done = [lanes.lanes[0]], 0.0, [0]
+        del lanes
+        torch.cuda.empty_cache()
+        one = Lanes(cfg, 1, dev, local, seeds[:1], args, gen)  # a fresh engine with its defaults for a lone batch
         n1 = max(8, min(24, args.steps))
         dt1, sh1 = timed(one, n1, 2, barrier, 0)
         t1 = one.totals(sh1)
         out["pipeline1_value"] = t1[0] / dt1
         out["pipeline1_ms_per_step"] = dt1 / n1 * 1e3
-        del lanes
+        del one
         torch.cuda.empty_cache()
         others = []
         for oc in OTHERS:
@@ -429,9 +438,7 @@ def main():
             ot = ol.totals(osh)
             oe, ob, _ = ol.lanes[0]
             okm = kernel_ms_of(ob)
-            o1 = Lanes.__new__(Lanes)
-            o1.torch, o1.eng, o1.cfg, o1.dev, o1.depth = torch, eng, oc, dev, 1
-            o1.lanes, o1.stagger, o1.done = [ol.lanes[0]], 0.0, [0]
+            o1 = Lanes(oc, 1, dev, local, [2000], args)
             odt1, osh1 = timed(o1, 16, 2, barrier, 0)
             ot1 = o1.totals(osh1)
             others.append({

@@ -2012,9 +2012,18 @@ __global__ __launch_bounds__(64) void pip_det_replay_lanes_kernel(PipJob *jobs, 
   i64 det[PIPAMD_MAXDET];
   for (int i = 0; i < PIPAMD_MAXDET; i++) det[i] = J->det[i];
   int ldet = J->ldet;
-  for (int k = 0; k < nlog; k++) {
-    const longlong2 e = *reinterpret_cast<const longlong2 *>(lg + 2 * k);
-    i64 ppivot = e.x, dppiv = e.y;
+  bool stop = false;
+  for (int k0 = 0; k0 < nlog && !stop; k0 += 8) {
+    // eight log entries (one 128-byte line of this lane's log) per round trip to memory
+    longlong2 ev[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      ev[u] = k0 + u < nlog ? *reinterpret_cast<const longlong2 *>(lg + 2 * (k0 + u)) : longlong2{1, 1};
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+    const int k = k0 + u;
+    if (k >= nlog || stop) break;
+    i64 ppivot = ev[u].x, dppiv = ev[u].y;
     if (dppiv != 1) {
       i64 d = gcd_i64(ppivot, dppiv);
       if (d != 1) {
@@ -2056,7 +2065,8 @@ __global__ __launch_bounds__(64) void pip_det_replay_lanes_kernel(PipJob *jobs, 
     if (ovf) {
       J->status = PIPAMD_ST_OVERFLOW;
       J->npiv = J->npiv - nlog + k + 1;
-      break;
+      stop = true;
+    }
     }
   }
   for (int i = 0; i < PIPAMD_MAXDET; i++) J->det[i] = det[i];
