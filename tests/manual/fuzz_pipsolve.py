@@ -1,6 +1,7 @@
-"""Manual GPU fuzz (not a test): pipamd_pip_solve (PolyLib matrices in, PipQuast out) with random
-option sets (Maximize / Urs_unknowns / Urs_parms / Rational / bignum) against the CPU oracle's
-`pip` mode, which prints what the reference's example.c prints.
+"""Manual GPU fuzz (not a test): the reference's pip_solve with traiter() bound to the GPU engine
+(oracle/_ref/refpip_gpu, bindings/piplib_traiter_hook.c) with random option sets (Maximize /
+Urs_unknowns / Urs_parms / Rational / Dual / bignum) against the CPU oracle's `pip` mode, which
+prints what the reference's example.c prints.
 Usage: python tests/manual/fuzz_pipsolve.py [seconds] [seed] [big]"""
 import os, sys, time, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,6 @@ from datfile import matrix_text
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 BIG = len(sys.argv) > 3  # larger shapes and coefficients: more aborts and skips, deeper trees
-e = eng.Engine(0)
 t0 = time.time(); n = nskip = nabort = nsplit = 0
 while time.time() - t0 < budget:
     nn, npar = int(rng.integers(1, 9 if BIG else 6)), int(rng.integers(0, 5 if BIG else 4))
@@ -56,27 +56,22 @@ while time.time() - t0 < budget:
     if os.environ.get("FUZZ_LAST_CASE"):  # a crash in the library leaves the input behind
         with open(os.environ["FUZZ_LAST_CASE"], "w") as f:
             f.write(tag + "\n")
-    try:
-        text, _ = eng.pip_solve(e, dom, ctx, bg, **opts)
-    except eng.SolverError as ex:
-        if o.returncode == 0 and ex.status == eng.ST_CAPACITY:
-            # documented limitation: a job of this problem outgrows the ~3,400 rows an
-            # LDS image can hold; the reference's expanser has no bound
-            print("skipped (PIPAMD_ST_CAPACITY: more rows than the engine can stage):", tag, flush=True)
+    g = subprocess.run([pb.REFPIP_GPU, "pip"], input=txt, capture_output=True, timeout=600)
+    if g.returncode != 0:
+        if o.returncode == 0 and b"status 6" in g.stderr:
+            print("skipped (PIPAMD_ST_CAPACITY: more than 16,000 rows):", tag, flush=True)
             nskip += 1
             continue
         if o.returncode == 0:
-            print("MISMATCH: engine aborted, oracle did not:", tag, ex, flush=True); sys.exit(1)
+            print("MISMATCH: engine aborted, oracle did not:", tag, g.stderr.decode()[-200:], flush=True); sys.exit(1)
         nabort += 1
         continue
     if o.returncode != 0:
         print("MISMATCH: oracle aborted, engine did not:", tag, flush=True); sys.exit(1)
-    got = ("[PIP2-like future input] Please enter:\n- the context matrix,\n" + matrix_text(ctx) +
-           "- the bignum column (start at 0, -1 if no bignum),\n" + f"{bignum}\n" +
-           "- the constraint matrix.\n" + matrix_text(dom) + "\n" + text)
+    text = g.stdout.decode("latin-1")
     want = o.stdout.decode("latin-1")
-    if pb.squash(got) != pb.squash(want):
-        print("MISMATCH:", tag, "\n got ", text[:400], "\n want", want[-400:], flush=True); sys.exit(1)
+    if pb.squash(text) != pb.squash(want):
+        print("MISMATCH:", tag, "\n got ", text[-400:], "\n want", want[-400:], flush=True); sys.exit(1)
     n += 1; nsplit += "(if" in text
     if n % 200 == 0:
         print(f"{n} problems ({nsplit} with splits, {nabort} aborts, {nskip} skipped), {time.time()-t0:.0f} s", flush=True)
