@@ -127,9 +127,12 @@ int pipamd_batch_results(pipamd_engine *e, const void *d_workspace, const pipamd
 int pipamd_batch_counters(pipamd_engine *e, const void *d_workspace, const pipamd_batch_desc *d,
                           uint64_t *d_out4, void *stream);
 
-/* Algorithmic HBM bytes of ONE pivot of one tableau of this shape (read+write of every
- * real row): the per-unit figure bench.py's roofline uses (DESIGN.md section "Roofline"). */
-size_t pipamd_pivot_bytes(const pipamd_batch_desc *d);
+/* Bytes ONE pivot of one tableau of this shape moves when every real row is read and written,
+ * as the reference's loop does (traiter.c:467-502): 2 * ni * ncol * sizeof(Entier).  The engine
+ * itself only touches the rows that change; bench.py's `roofline` uses that smaller figure --
+ * 8 * ncol * (2 * rows_rewritten + 2 * pivots) from pipamd_batch_counters -- and reports this one
+ * as `dense_equivalent_GBps` and for `roofline_dense_mode` (PIPAMD_T_NOSKIP). */
+size_t pipamd_dense_pivot_bytes(const pipamd_batch_desc *d);
 
 /* Sum of the pivot-kernel launch durations of the last pipamd_batch_solve in milliseconds,
  * measured with HIP events on the launch stream, and the number of those launches. */

@@ -114,7 +114,7 @@ extern "C" size_t pipamd_batch_workspace_bytes(const pipamd_batch_desc *d) {
   return jb + (size_t)lay.per_job * (size_t)d->batch * sizeof(int64_t);
 }
 
-extern "C" size_t pipamd_pivot_bytes(const pipamd_batch_desc *d) {
+extern "C" size_t pipamd_dense_pivot_bytes(const pipamd_batch_desc *d) {
   // one pivot reads and writes every real row once: 2 * ni * ncol * sizeof(Entier)
   return 2ull * (size_t)d->ni * (size_t)(d->nvar + d->nparm + 1) * (d->entier_bits == 128 ? 16 : 8);
 }

@@ -1045,14 +1045,18 @@ class Forest {
       Prob &q = P_[i];
       q.nvar = p.nvar;
       q.nparm0 = p.nparm;
-      const size_t mainb = block_words(p.nvar, p.ni + 24, p.nvar + p.nparm + 1 + 6);
-      const size_t subb = block_words(p.nparm + 8, p.nc + 48, p.nparm + 8 + 1);
-      q.region_words = 24 * mainb + (size_t)(2 * (p.nvar + p.ni + 24) + 4) * subb;
+      q.region_words = region_words(p);
       q.region_off = total;
       q.top = 0;
       total += q.region_words;
     }
-    ensure(d_arena_, arena_cap_, total * sizeof(i64));
+    if (total * sizeof(i64) > arena_cap_) {  // exact size: the arena is the one large buffer (no doubling)
+      if (d_arena_) hipFree(d_arena_);
+      d_arena_ = nullptr;
+      arena_cap_ = 0;
+      HIPTHROW(hipMalloc((void **)&d_arena_, total * sizeof(i64)));
+      arena_cap_ = total * sizeof(i64);
+    }
     // ---- start every problem
     for (int i = 0; i < n; i++) {
       try {
@@ -1166,6 +1170,16 @@ class Forest {
   std::vector<i64> pidx_, clones_, fresh_, fidx_;
 
   static int even(int x) { return (x + 1) & ~1; }
+ public:
+  // device words reserved for one problem: 24 tableaux of the main shape (tree depth) and the
+  // sub-problems of one compa_test round
+  static size_t region_words(const pipamd_problem &p) {
+    const size_t mainb = block_words(p.nvar, p.ni + 24, p.nvar + p.nparm + 1 + 6);
+    const size_t subb = block_words(p.nparm + 8, p.nc + 48, p.nparm + 8 + 1);
+    return 24 * mainb + (size_t)(2 * (p.nvar + p.ni + 24) + 4) * subb;
+  }
+
+ private:
   static size_t block_words(int nvar, int S, int W) {
     W = even(W);
     const int L = even(nvar + S);
@@ -1681,16 +1695,34 @@ extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pip
   if (!e || n < 0 || (n && (!probs || !cells || !n_cells || !rcs))) return PIPAMD_E_INVALID;
   if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
   std::vector<FResult> res(n);
+  for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;  // until the forest has served it: "use the Tree path"
   if (!deepest_cut) {
+    // The forest reserves a worst-case region per problem; batches whose regions add up to more
+    // than the arena budget go through it in chunks (PIPAMD_FOREST_ARENA_MB, default 8192).
+    size_t budget = (size_t)8192 << 20;
+    if (const char *mb = getenv("PIPAMD_FOREST_ARENA_MB")) budget = (size_t)strtoull(mb, nullptr, 10) << 20;
     try {
       Forest f(e->device);
-      f.solve(n, probs, simplify, res);
+      for (int lo = 0; lo < n;) {
+        size_t bytes = 0;
+        int hi = lo;
+        while (hi < n && (hi == lo || bytes + Forest::region_words(probs[hi]) * sizeof(i64) <= budget))
+          bytes += Forest::region_words(probs[hi++]) * sizeof(i64);
+        std::vector<FResult> part;
+        try {
+          f.solve(hi - lo, probs + lo, simplify, part);
+          for (int i = lo; i < hi; i++) res[i] = std::move(part[i - lo]);
+        } catch (int code) {
+          if (code != PIPAMD_E_HIP) code = PIPAMD_E_TOOLARGE;
+          // an allocation or launch failure of this chunk: its problems go to the per-problem tree
+          (void)hipGetLastError();
+        }
+        lo = hi;
+      }
     } catch (int code) {
-      if (code == PIPAMD_E_HIP) return code;
-      for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;
+      if (code == PIPAMD_E_HIP) return code;  // not even a stream
     }
-  } else
-    for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;
+  }
   Tree *fallback = nullptr;
   int rc_all = PIPAMD_OK;
   for (int i = 0; i < n; i++) {

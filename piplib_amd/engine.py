@@ -36,8 +36,8 @@ def lib():
         L.pipamd_last_error.restype = C.c_char_p
         L.pipamd_batch_workspace_bytes.restype = C.c_size_t
         L.pipamd_batch_workspace_bytes.argtypes = [C.POINTER(BatchDesc)]
-        L.pipamd_pivot_bytes.restype = C.c_size_t
-        L.pipamd_pivot_bytes.argtypes = [C.POINTER(BatchDesc)]
+        L.pipamd_dense_pivot_bytes.restype = C.c_size_t
+        L.pipamd_dense_pivot_bytes.argtypes = [C.POINTER(BatchDesc)]
         L.pipamd_engine_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         L.pipamd_engine_destroy.argtypes = [C.c_void_p]
         L.pipamd_engine_set_iter_limit.argtypes = [C.c_void_p, C.c_int]
@@ -165,7 +165,7 @@ class Batch:
         return float(ms.value)
 
     def pivot_bytes(self):
-        return int(lib().pipamd_pivot_bytes(C.byref(self.desc)))
+        return int(lib().pipamd_dense_pivot_bytes(C.byref(self.desc)))
 
 
 class SolCell(C.Structure):

@@ -28,7 +28,7 @@ def declared_functions():
 def test_header_declares_the_three_layers():
     names = declared_functions()
     for must in ("pipamd_engine_create", "pipamd_batch_load", "pipamd_batch_solve", "pipamd_batch_results",
-                 "pipamd_solve_tableau", "pipamd_traiter", "pipamd_pivot_bytes", "pipamd_last_solve_ms"):
+                 "pipamd_solve_tableau", "pipamd_traiter", "pipamd_dense_pivot_bytes", "pipamd_last_solve_ms"):
         assert must in names
 
 
@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_workspace_and_pivot_bytes_host_only(lib):
     from piplib_amd.engine import BatchDesc
     d = BatchDesc(10000, 127, 0, 64, -1, 1, 128, 0)
-    assert lib.pipamd_pivot_bytes(C.byref(d)) == 2 * 64 * 128 * 8
+    assert lib.pipamd_dense_pivot_bytes(C.byref(d)) == 2 * 64 * 128 * 8
     n = lib.pipamd_batch_workspace_bytes(C.byref(d))
     assert n > 10000 * 64 * 128 * 8          # at least the tableaux themselves
     assert n < 10000 * 4 * (64 + 128) * 128 * 8  # and not absurdly more
