@@ -135,6 +135,7 @@ class Lanes:
                 e.set_round_pivots(args.round)
             if args.round_rows:
                 e.set_round_rows(args.round_rows)
+            e.set_timing(False)  # no HIP events in the timed region (kernel_ms_of switches them on)
             bulk_min = args.bulk_min if args.bulk_min > 0 else (256 if depth > 1 else 0)  # depth = this Lanes' lane count
             if bulk_min:
                 e.set_bulk_min(bulk_min)
@@ -231,6 +232,7 @@ def roofline_of(b, e, k_ms, cfg, extra=None):
 
 
 def kernel_ms_of(b, reps=2):
+    b.e.set_timing(True)
     ms = []
     for _ in range(reps):
         b.load()
@@ -431,9 +433,10 @@ def main():
         torch.cuda.empty_cache()
         others = []
         for oc in OTHERS:
-            od = lane_count(args.pipeline, 4 * args.pipeline)
+            # a 1k-tableau batch is a fraction of a millisecond of GPU work: twice the lanes keep the GPU fed
+            od = args.pipeline * (2 if oc["batch"] < 4096 else 1)
             ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args)
-            osteps = 8 * od
+            osteps = 16 * od
             odt, osh = timed(ol, osteps, od, barrier, args.stagger)
             ot = ol.totals(osh)
             oe, ob, _ = ol.lanes[0]

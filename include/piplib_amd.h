@@ -137,6 +137,9 @@ size_t pipamd_dense_pivot_bytes(const pipamd_batch_desc *d);
 /* Sum of the pivot-kernel launch durations of the last pipamd_batch_solve in milliseconds,
  * measured with HIP events on the launch stream, and the number of those launches. */
 int pipamd_last_solve_ms(pipamd_engine *e, float *ms);
+/* The events cost four runtime calls per solve, which shows on batches of a few hundred small
+ * tableaux: off = pipamd_batch_solve records none (pipamd_last_solve_ms then fails).  Default on. */
+int pipamd_engine_set_timing(pipamd_engine *e, int on);
 int pipamd_last_solve_launches(pipamd_engine *e);
 /* pipamd_batch_solve serves a batch of >= 2048 tableaux with two queue-fed launches and no host
  * round trip in between: a bulk launch of persistent one-wave workgroups that draw tableaux from

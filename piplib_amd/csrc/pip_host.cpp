@@ -157,15 +157,29 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
   long long *arena = (long long *)((char *)d_ws + jb);
   hipStream_t st = (hipStream_t)stream;
   if (!e->h_run) HIPCHK(hipHostMalloc((void **)&e->h_run, 2 * sizeof(int), hipHostMallocDefault));
-  const int nctrl = Q_CTRL * PIPAMD_MAX_ROUNDS;
+  // Control words (out_count, out_maxni per launch) must be zero when a launch starts.  They come
+  // from a pool of Q_POOL solves x Q_FAST launches that one memset zeroes every Q_POOL solves (a
+  // solve of a small batch is a handful of runtime calls: this was a fifth of them); the rare
+  // launches beyond Q_FAST of one solve use an overflow area zeroed on demand.
+  enum { Q_POOL = 64, Q_FAST = 8 };
+  const int npool = Q_CTRL * Q_FAST * Q_POOL, nctrl = npool + Q_CTRL * PIPAMD_MAX_ROUNDS;
   if (!e->d_q || e->q_cap < lay.batch) {
     if (e->d_q) HIPCHK(hipFree(e->d_q));
     e->d_q = nullptr;
     HIPCHK(hipMalloc((void **)&e->d_q, ((size_t)nctrl + 2 * (size_t)lay.batch) * sizeof(int)));
     e->q_cap = lay.batch;
+    e->solve_seq = 0;
   }
-  int *ctrl = e->d_q, *list[2] = {e->d_q + nctrl, e->d_q + nctrl + e->q_cap};
-  HIPCHK(hipMemsetAsync(ctrl, 0, (size_t)nctrl * sizeof(int), st));
+  if (e->solve_seq % Q_POOL == 0 || e->pool_stream != st) {
+    HIPCHK(hipMemsetAsync(e->d_q, 0, (size_t)npool * sizeof(int), st));
+    e->solve_seq = 0;
+    e->pool_stream = st;
+  }
+  int *const pool = e->d_q + Q_CTRL * Q_FAST * (e->solve_seq % Q_POOL), *const over = e->d_q + npool;
+  e->solve_seq++;
+  bool over_zeroed = false;
+  auto ctrl_of = [&](int stage) -> int * { return stage < Q_FAST ? pool + Q_CTRL * stage : over + Q_CTRL * (stage - Q_FAST); };
+  int *list[2] = {e->d_q + nctrl, e->d_q + nctrl + e->q_cap};
   e->nlaunch = 0;
   const bool integer = (lay.tflags & PIPAMD_T_INT) != 0;
   const int K1 = e->round_pivots > 0 ? e->round_pivots : 96;
@@ -178,24 +192,30 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
       return PIPAMD_E_SOLVER;
     }
     if (smax > lay.S) smax = lay.S;
-    int *c = ctrl + Q_CTRL * stage;
+    if (stage >= Q_FAST && !over_zeroed) {
+      HIPCHK(hipMemsetAsync(over, 0, (size_t)Q_CTRL * PIPAMD_MAX_ROUNDS * sizeof(int), st));
+      over_zeroed = true;
+    }
+    int *c = ctrl_of(stage);
     void *q5[5] = {nullptr, nullptr, list[stage & 1], c, c + 1};
     if (have_list) {
       q5[0] = list[(stage - 1) & 1];
-      q5[1] = ctrl + Q_CTRL * (stage - 1);
+      q5[1] = ctrl_of(stage - 1);
     }
-    if (e->nlaunch >= e->nev) {
-      HIPCHK(hipEventCreate(&e->ev[2 * e->nev]));
-      HIPCHK(hipEventCreate(&e->ev[2 * e->nev + 1]));
-      e->nev++;
+    if (!e->no_timing) {
+      if (e->nlaunch >= e->nev) {
+        HIPCHK(hipEventCreate(&e->ev[2 * e->nev]));
+        HIPCHK(hipEventCreate(&e->ev[2 * e->nev + 1]));
+        e->nev++;
+      }
+      HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch], st));
     }
-    HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch], st));
     void *big[2] = {&e->d_scratch, &e->scratch_bytes};
     // a uniform batch without parameters whose rows fill a wave's 128 columns exactly: FULL kernels
     const int hints = (lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 && lay.W == 128) ? 1 : 0;
     HIPCHK(pipk_launch_advance_q(jobs, arena, lay.batch, lay.nvar + smax, smax, lay.W, budget, waves, lay.ebits, q5, upper,
                                  big, hints, e->d_prof, st));
-    HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
+    if (!e->no_timing) HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
     e->nlaunch++;
     stage++;
     have_list = true;
@@ -211,12 +231,18 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
   for (;;) {
     rc = launch(tail_waves, e->iter_limit, lay.S, upper);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(e->h_run, ctrl + Q_CTRL * (stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (e->h_run[0] <= 0 || e->single_launch) break;
     upper = e->h_run[0];
   }
-  e->timed = 1;
+  e->timed = !e->no_timing;
+  return PIPAMD_OK;
+}
+
+extern "C" int pipamd_engine_set_timing(pipamd_engine *e, int on) {
+  if (!e) return PIPAMD_E_INVALID;
+  e->no_timing = !on;
   return PIPAMD_OK;
 }
 

@@ -17,7 +17,10 @@ struct pipamd_engine {
   int bulk_min;      /* batches of at least this many tableaux start with the one-wave bulk launch (0 = default 2048) */
   int single_launch; /* debug: stop after one launch */
   int *h_run;        /* pinned: {jobs still running, their largest row count} */
-  int *d_q;          /* work-queue control words and the two job lists of pipamd_batch_solve */
+  int *d_q;          /* launch-list control words (a pool, see pipamd_batch_solve) and the two job lists */
+  unsigned solve_seq; /* solves since the control pool was last zeroed */
+  hipStream_t pool_stream; /* the stream that zeroing was ordered on */
+  int no_timing;     /* 1: no HIP events around the launches */
   int q_cap;         /* jobs the lists hold */
   int iter_limit;
   int waves_per_job; /* 0 = choose by batch size */
