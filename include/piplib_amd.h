@@ -188,6 +188,22 @@ int pipamd_traiter(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bi
                    const int64_t *tableau, const int64_t *context, pipamd_sol_cell **cells, size_t *n_cells,
                    int *status, int64_t *pivots);
 
+/* The same on 128-bit entries -- the reference's overflow-safe flavour is a whole-library build
+ * with a wider Entier (include/piplib/piplib.h:42-88): device tableaux, context, parametric cuts
+ * and tape all carry __int128 here; the input rows are int64, the cells' parameters come back as
+ * (low, high) int64 pairs.  Tableaux must fit a workgroup's LDS (about 1,600 rows of <= 128
+ * columns); the lock-step scheduler stays 64-bit. */
+typedef struct pipamd_sol_cell128 {
+  int32_t kind, reserved;
+  int64_t param1_lo, param1_hi, param2_lo, param2_hi;
+} pipamd_sol_cell128;
+int pipamd_traiter128(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int flags, int deepest_cut,
+                      const int64_t *tableau, const int64_t *context, pipamd_sol_cell128 **cells, size_t *n_cells,
+                      int *status, int64_t *pivots);
+int pipamd_solve_tableau128(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int nq,
+                            const int64_t *ineq, const int64_t *ctx, int simplify, int deepest_cut,
+                            pipamd_sol_cell128 **cells, size_t *n_cells, int *status, int64_t *pivots);
+
 /* One problem in PIP's native tableau form (what maind.c reads from a .dat file): the whole of
  * maind.c:190-231 -- tab_simplify (tab.c:396) first when nq != 0 and `simplify`, the
  * empty-context test, then traiter.  An empty tape (*n_cells == 0) with PIPAMD_OK is maind.c's

@@ -42,44 +42,50 @@ typedef unsigned long long u64;
     }                                                                                               \
   } while (0)
 
-// ---- wrap-around integer helpers (piplib.h:128-169, integrer.c:43-74), host side ----
-inline i64 wadd(i64 a, i64 b) { return (i64)((u64)a + (u64)b); }
-inline i64 wsub(i64 a, i64 b) { return (i64)((u64)a - (u64)b); }
-inline i64 wneg(i64 a) { return (i64)(0ull - (u64)a); }
-inline i64 wabs(i64 a) { return a < 0 ? wneg(a) : a; }
-inline i64 crem(i64 a, i64 b) { return (b == 0 || b == -1) ? 0 : a % b; }
-inline i64 cquo(i64 a, i64 b) { return b == 0 ? 0 : (b == -1 ? wneg(a) : a / b); }
-i64 gcd(i64 a, i64 b) {
+// ---- wrap-around integer helpers (piplib.h:128-169, integrer.c:43-74), host side, for both
+// entry widths: E = long long (the reference's int64 build) or __int128 (the overflow-safe one)
+typedef __int128 i128;
+template <class E> struct UT;
+template <> struct UT<i64> { typedef u64 type; };
+template <> struct UT<i128> { typedef unsigned __int128 type; };
+template <class E> inline E wadd(E a, E b) { return (E)((typename UT<E>::type)a + (typename UT<E>::type)b); }
+template <class E> inline E wsub(E a, E b) { return (E)((typename UT<E>::type)a - (typename UT<E>::type)b); }
+template <class E> inline E wneg(E a) { return (E)((typename UT<E>::type)0 - (typename UT<E>::type)a); }
+template <class E> inline E wabs(E a) { return a < 0 ? wneg(a) : a; }
+template <class E> inline E crem(E a, E b) { return (b == 0 || b == -1) ? (E)0 : a % b; }
+template <class E> inline E cquo(E a, E b) { return b == 0 ? (E)0 : (b == -1 ? wneg(a) : a / b); }
+template <class E> E gcd(E a, E b) {
   while (b) {
-    i64 t = crem(a, b);
+    E t = crem(a, b);
     a = b;
     b = t;
   }
   return wabs(a);
 }
-inline i64 fmod_(i64 a, i64 b) {
-  i64 m = crem(a, b);
+template <class E> inline E fmod_(E a, E b) {
+  E m = crem(a, b);
   if (m < 0) m = wadd(m, wabs(b));
   return m;
 }
-inline i64 floordiv(i64 a, i64 b) { return cquo(wsub(a, fmod_(a, b)), b); }
-inline i64 wmul(i64 a, i64 b) { return (i64)((u64)a * (u64)b); }
+template <class E> inline E floordiv(E a, E b) { return cquo(wsub(a, fmod_(a, b)), b); }
+template <class E> inline E wmul(E a, E b) { return (E)((typename UT<E>::type)a * (typename UT<E>::type)b); }
 
 enum { S_FREE = 0, S_NIL, S_IF, S_LIST, S_FORM, S_NEW, S_DIV, S_VAL }; /* sol.c:42-50 */
-struct Cell {
+template <class E> struct CellT {
   int kind;
-  i64 a, b;
+  E a, b;
 };
+typedef CellT<i64> Cell;
 
 // context: rows of (parameters | constant), traiter.c keeps it as a Tableau
-struct Ctx {
+template <class E> struct CtxT {
   int nc = 0, width = 0;  // rows in use, columns allocated per row
-  std::vector<i64> v;
-  i64 &at(int r, int c) { return v[(size_t)r * width + c]; }
-  i64 at(int r, int c) const { return v[(size_t)r * width + c]; }
+  std::vector<E> v;
+  E &at(int r, int c) { return v[(size_t)r * width + c]; }
+  E at(int r, int c) const { return v[(size_t)r * width + c]; }
   void reserve(int rows, int cols) {
     if (cols > width) {
-      std::vector<i64> nv((size_t)std::max(rows, nc + 4) * cols, 0);
+      std::vector<E> nv((size_t)std::max(rows, nc + 4) * cols, 0);
       for (int r = 0; r < nc; r++)
         for (int c = 0; c < width; c++) nv[(size_t)r * cols + c] = v[(size_t)r * width + c];
       v.swap(nv);
@@ -88,6 +94,7 @@ struct Ctx {
     if ((size_t)rows * width > v.size()) v.resize((size_t)(rows + 8) * width, 0);
   }
 };
+typedef CtxT<i64> Ctx;
 
 struct HostJob {
   PipJob pj;
@@ -95,16 +102,22 @@ struct HostJob {
   size_t block_words = 0;
 };
 
-struct Snap {  // host copy of a job's row tables and rows
+template <class E> struct SnapT {  // host copy of a job's row tables and rows
   int L = 0, S = 0, W = 0;
-  std::vector<i64> den, vals;
+  std::vector<E> den, vals;
   std::vector<int> flag, ref;
-  const i64 *row(int k) const { return &vals[(size_t)ref[k] * W]; }
+  const E *row(int k) const { return &vals[(size_t)ref[k] * W]; }
 };
 
-class Tree {
+template <class E>
+class TreeT {
  public:
-  Tree(pipamd_engine *e, int deepest) : deepest_(deepest) {
+  typedef CtxT<E> Ctx;
+  typedef CellT<E> Cell;
+  typedef SnapT<E> Snap;
+  static constexpr int EW = (int)(sizeof(E) / 8);   // int64 words per entry
+  static constexpr int EBITS = (int)(sizeof(E) * 8);
+  TreeT(pipamd_engine *e, int deepest) : deepest_(deepest) {
     (void)e;
     const hipError_t err = hipStreamCreateWithFlags(&st_, hipStreamNonBlocking);
     if (err != hipSuccess) {  // never fall back to the null stream: it would serialise every tree of the process
@@ -113,7 +126,7 @@ class Tree {
       throw (int)PIPAMD_E_HIP;
     }
   }
-  ~Tree() {
+  ~TreeT() {
     if (d_arena_) hipFree(d_arena_);
     if (d_jobs_) hipFree(d_jobs_);
     if (d_big_) hipFree(d_big_);
@@ -140,7 +153,7 @@ class Tree {
     ctx.reserve(nc + 4, nparm + 2);
     ctx.nc = nc;
     for (int r = 0; r < nc; r++)
-      for (int c = 0; c <= nparm; c++) ctx.at(r, c) = ctxrows[(size_t)r * (nparm + 1) + c];
+      for (int c = 0; c <= nparm; c++) ctx.at(r, c) = (E)ctxrows[(size_t)r * (nparm + 1) + c];
     dual_ = (tfl & PIPAMD_T_DUAL) != 0;
     HostJob job = make_job(nvar, nparm, ni, bigparm, tfl, ineq);
     node(job, ctx, nvar, nparm, ni, bigparm, tfl);
@@ -152,7 +165,7 @@ class Tree {
     ctx.reserve(nc + 4, nparm + 2);
     ctx.nc = nc;
     for (int r = 0; r < nc; r++)
-      for (int c = 0; c <= nparm; c++) ctx.at(r, c) = ctxrows[(size_t)r * (nparm + 1) + c];
+      for (int c = 0; c <= nparm; c++) ctx.at(r, c) = (E)ctxrows[(size_t)r * (nparm + 1) + c];
     if (nc) {
       size_t mark = top_;
       HostJob cj = make_context_job(ctx, nparm, nc, nullptr);
@@ -193,7 +206,7 @@ class Tree {
     HIPTHROW(hipMemcpyAsync(dst, src, bytes, kind, st_));
     HIPTHROW(hipStreamSynchronize(st_));
   }
-  void push(int kind, i64 a, i64 b) {
+  void push(int kind, E a, E b) {
     tape.push_back(Cell{kind, a, b});
     if (tape.size() >= 4096) fail(PIPAMD_ST_INTERNAL);  // "The solution is too complex", sol.c:97
   }
@@ -213,8 +226,10 @@ class Tree {
   }
   static int even(int x) { return (x + 1) & ~1; }
   static bool rows_fit(int nvar, int S, int W) {
-    (void)W;  // row tables that outgrow LDS live in HBM: only the 16-bit row codes bound a job
-    return S <= PIPAMD_SMAX && even(nvar + S) <= PIPAMD_LMAX;
+    if (S > PIPAMD_SMAX || even(nvar + S) > PIPAMD_LMAX) return false;
+    // 64-bit: row tables that outgrow LDS live in HBM, only the 16-bit row codes bound a job;
+    // 128-bit: the tables must fit a workgroup's LDS
+    return EW == 1 || pipk_advance_lds_bytes((even(nvar + S) + 3) & ~3, (S + 3) & ~3, W, EBITS) <= PIPAMD_LDS_BUDGET;
   }
   // Row capacity of the block a job that ran out of rows is re-housed in: geometric growth (a
   // sub-problem may need thousands of cut rows, and every re-housing copies the whole tableau),
@@ -243,15 +258,16 @@ class Tree {
     }
     const int L = even(nvar + S);
     const int nm = 8;  // room for the bitmaps of any launch geometry (jobs of mixed widths share launches)
-    const size_t sol = (size_t)even(nvar * (W - nvar) + nvar);
+    const size_t sol = (size_t)even(nvar * (W - nvar) + nvar) * EW;
     const size_t state = (size_t)even(S * nm + (3 * L + 7) / 8) + 2 * PIPAMD_DETLOG;  // summaries | determinant log
-    j.block_words = 2 * (size_t)L + (size_t)S * W + sol + state;
+    // den[L] (entries) | flag[L] | ref[L], then S x W entries, the solution, the saved summaries
+    j.block_words = (size_t)(EW + 1) * L + (size_t)S * W * EW + sol + state;
     ensure_arena(top_ + j.block_words);
     j.block_off = (i64)top_;
     top_ += j.block_words;
     j.pj.rows_off = j.block_off;
-    j.pj.vals_off = j.block_off + 2 * (i64)L;
-    j.pj.sol_off = j.pj.vals_off + (i64)S * W;
+    j.pj.vals_off = j.block_off + (i64)(EW + 1) * L;
+    j.pj.sol_off = j.pj.vals_off + (i64)S * W * EW;
     j.pj.state_off = j.pj.sol_off + (i64)sol;
     j.pj.log_off = j.pj.state_off + (i64)state - 2 * PIPAMD_DETLOG;
     j.pj.nvar = nvar;
@@ -265,16 +281,22 @@ class Tree {
     j.pj.status = PIPAMD_ST_RUN;
     j.pj.ldet = 1;
     j.pj.det[0] = 1;
-    j.pj.ebits = 64;
+    j.pj.ebits = EBITS;
     return j;
   }
 
+  // bytes of a job's row tables + rows, and typed views into a host copy of them
+  static size_t tab_words(int L, int S, int W) { return (size_t)(EW + 1) * L + (size_t)S * W * EW; }
+  static E *blk_den(std::vector<i64> &blk) { return (E *)blk.data(); }
+  static int *blk_flag(std::vector<i64> &blk, int L) { return (int *)(blk_den(blk) + L); }
+  static E *blk_vals(std::vector<i64> &blk, int L) { return (E *)(blk.data() + (size_t)(EW + 1) * L); }
+
   // tab_alloc + tab_get (tab.c:158-248): nvar unit rows, ni Unknown rows with denominator 1
-  void upload_fresh(HostJob &j, const std::vector<i64> &rows /* ni x ncol */) {
+  void upload_fresh(HostJob &j, const std::vector<E> &rows /* ni x ncol */) {
     const int nvar = j.pj.nvar, ni = j.pj.ni, ncol = nvar + j.pj.nparm + 1, L = j.pj.L, S = j.pj.S, W = j.pj.W;
-    std::vector<i64> blk(2 * (size_t)L + (size_t)S * W, 0);
-    i64 *den = blk.data();
-    int *flag = (int *)(den + L), *ref = flag + L;
+    std::vector<i64> blk(tab_words(L, S, W), 0);
+    E *den = blk_den(blk), *vals = blk_vals(blk, L);
+    int *flag = blk_flag(blk, L), *ref = flag + L;
     for (int i = 0; i < nvar; i++) {
       den[i] = 1;
       flag[i] = PIPAMD_F_UNIT;
@@ -284,7 +306,7 @@ class Tree {
       den[nvar + i] = 1;
       flag[nvar + i] = PIPAMD_F_UNKNOWN;
       ref[nvar + i] = i;
-      for (int c = 0; c < ncol; c++) blk[2 * (size_t)L + (size_t)i * W + c] = rows[(size_t)i * ncol + c];
+      for (int c = 0; c < ncol; c++) vals[(size_t)i * W + c] = rows[(size_t)i * ncol + c];
     }
     copy(d_arena_ + j.block_off, blk.data(), blk.size() * sizeof(i64), hipMemcpyHostToDevice);
   }
@@ -292,16 +314,17 @@ class Tree {
   HostJob make_job(int nvar, int nparm, int ni, int bigparm, int tflags, const i64 *rows) {
     const int ncol = nvar + nparm + 1;
     HostJob j = alloc_job(nvar, nparm, ni, bigparm, tflags, ni + 24, ncol + (nparm ? 6 : 0));
-    std::vector<i64> r(rows, rows + (size_t)ni * ncol);
+    std::vector<E> r((size_t)ni * ncol);
+    for (size_t k = 0; k < r.size(); k++) r[k] = (E)rows[k];
     upload_fresh(j, r);
     return j;
   }
   // expanser(context, nparm, nc, nparm+1, nparm, extra?1:0, 0) (traiter.c:191,211,
   // maind.c:198): the context as a problem in the parameters, optionally one more row
-  HostJob make_context_job(const Ctx &ctx, int nparm, int nc, const std::vector<i64> *extra) {
+  HostJob make_context_job(const Ctx &ctx, int nparm, int nc, const std::vector<E> *extra) {
     const int ni = nc + (extra ? 1 : 0), ncol = nparm + 1;
     HostJob j = alloc_job(nparm, 0, ni, -1, PIPAMD_T_INT, ni + 16, ncol);
-    std::vector<i64> r((size_t)ni * ncol);
+    std::vector<E> r((size_t)ni * ncol);
     for (int i = 0; i < nc; i++)
       for (int c = 0; c < ncol; c++) r[(size_t)i * ncol + c] = ctx.at(i, c);
     if (extra)
@@ -315,17 +338,18 @@ class Tree {
     s.L = j.pj.L;
     s.S = j.pj.S;
     s.W = j.pj.W;
-    std::vector<i64> blk(2 * (size_t)s.L + (size_t)s.S * s.W);
+    std::vector<i64> blk(tab_words(s.L, s.S, s.W));
     copy(blk.data(), d_arena_ + j.block_off, blk.size() * sizeof(i64), hipMemcpyDeviceToHost);
-    s.den.assign(blk.begin(), blk.begin() + s.L);
-    const int *flag = (const int *)(blk.data() + s.L);
+    const E *den = blk_den(blk), *vals = blk_vals(blk, s.L);
+    s.den.assign(den, den + s.L);
+    const int *flag = blk_flag(blk, s.L);
     s.flag.assign(flag, flag + s.L);
     s.ref.assign(flag + s.L, flag + 2 * s.L);
-    s.vals.assign(blk.begin() + 2 * s.L, blk.end());
+    s.vals.assign(vals, vals + (size_t)s.S * s.W);
     return s;
   }
   void set_flag(const HostJob &j, int row, int f) {
-    int *g_flag = (int *)(d_arena_ + j.pj.rows_off + j.pj.L);
+    int *g_flag = (int *)((E *)(d_arena_ + j.pj.rows_off) + j.pj.L);
     copy(g_flag + row, &f, sizeof(int), hipMemcpyHostToDevice);
   }
 
@@ -350,7 +374,7 @@ class Tree {
       // bounded effort: one launch of at most SPEC_PIVOTS pivots per job, no re-housing; jobs
       // that are not done stay PIPAMD_ST_RUN / PIPAMD_ST_CAPACITY for a later, unbounded run
       copy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice);
-      HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, SPEC_PIVOTS, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_, 0,
+      HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, SPEC_PIVOTS, n >= 2048 ? 1 : 4, EBITS, nullptr, 0, big_, 0,
                                      nullptr, st_));
       copy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost);
       for (int i = 0; i < n; i++) js[i]->pj = tab[i];
@@ -359,7 +383,7 @@ class Tree {
     for (int pass = 0; pass < 64; pass++) {
       copy(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice);
       for (int guard = 0; guard < 4096; guard++) {
-        HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_, 0,
+        HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, EBITS, nullptr, 0, big_, 0,
                                        nullptr, st_));
         copy(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost);
         bool again = false;
@@ -415,15 +439,15 @@ class Tree {
     Snap s = download(j);
     HostJob n = alloc_job(j.pj.nvar, j.pj.nparm, j.pj.ni, j.pj.bigparm, 0, newS, newW);
     const int L = n.pj.L, W = n.pj.W, nl = j.pj.nvar + j.pj.ni;
-    std::vector<i64> blk(2 * (size_t)L + (size_t)n.pj.S * W, 0);
-    i64 *den = blk.data();
-    int *flag = (int *)(den + L), *ref = flag + L;
+    std::vector<i64> blk(tab_words(L, n.pj.S, W), 0);
+    E *den = blk_den(blk), *vals = blk_vals(blk, L);
+    int *flag = blk_flag(blk, L), *ref = flag + L;
     for (int k = 0; k < nl; k++) {
       den[k] = s.den[k];
       flag[k] = s.flag[k];
       ref[k] = s.ref[k];
       if (!(s.flag[k] & PIPAMD_F_UNIT))
-        for (int c = 0; c < s.W; c++) blk[2 * (size_t)L + (size_t)s.ref[k] * W + c] = s.vals[(size_t)s.ref[k] * s.W + c];
+        for (int c = 0; c < s.W; c++) vals[(size_t)s.ref[k] * W + c] = s.vals[(size_t)s.ref[k] * s.W + c];
     }
     copy(d_arena_ + n.block_off, blk.data(), blk.size() * sizeof(i64), hipMemcpyHostToDevice);
     PipJob keep = j.pj;
@@ -454,7 +478,7 @@ class Tree {
     std::vector<int> critic(rows.size());
     sub.reserve(2 * rows.size());
     for (size_t t = 0; t < rows.size(); t++) {
-      const i64 *r = s.row(rows[t]);
+      const E *r = s.row(rows[t]);
       int cr = 1;
       for (int j = 0; j < nvar; j++)
         if (r[j] > 0) {
@@ -462,12 +486,12 @@ class Tree {
           break;
         }
       critic[t] = cr;
-      std::vector<i64> ex(nparm + 1);
+      std::vector<E> ex(nparm + 1);
       for (int j = 0; j < nparm; j++) ex[j] = r[j + nvar + 1];  // "row >= 1" (>= 0 if critical)
-      ex[nparm] = cr ? r[nvar] : wsub(r[nvar], 1);
+      ex[nparm] = cr ? r[nvar] : wsub(r[nvar], (E)1);
       sub.push_back(make_context_job(ctx, nparm, nc, &ex));
       for (int j = 0; j < nparm; j++) ex[j] = wneg(r[j + nvar + 1]);  // "-row >= 1"
-      ex[nparm] = wsub(wneg(r[nvar]), 1);
+      ex[nparm] = wsub(wneg(r[nvar]), (E)1);
       sub.push_back(make_context_job(ctx, nparm, nc, &ex));
     }
     std::vector<HostJob *> ptr;
@@ -506,7 +530,7 @@ class Tree {
   }
 
   // --------------------------------------------------- find_parm / add_parm
-  static bool has_cut(const Ctx &cx, int nr, int nparm, int p, const std::vector<i64> &cut) {
+  static bool has_cut(const Ctx &cx, int nr, int nparm, int p, const std::vector<E> &cut) {
     for (int row = 0; row < nr; row++) {
       if (cx.at(row, p) != cut[1 + nparm]) continue;
       if (cx.at(row, nparm) != cut[0]) continue;
@@ -521,27 +545,27 @@ class Tree {
     }
     return false;
   }
-  static int find_parm(const Ctx &cx, int nr, int nparm, std::vector<i64> &cut) {  // integrer.c:258-291
+  static int find_parm(const Ctx &cx, int nr, int nparm, std::vector<E> &cut) {  // integrer.c:258-291
     if (cut[1 + nparm - 1] != 0) return -1;
-    cut[0] = wsub(wadd(cut[0], cut[1 + nparm]), 1);
+    cut[0] = wsub(wadd(cut[0], cut[1 + nparm]), (E)1);
     for (int p = nparm - 1; p >= 0; --p) {
       if (cut[1 + p] != 0) break;
       if (!has_cut(cx, nr, nparm, p, cut)) continue;
-      cut[0] = wsub(wadd(cut[0], 1), cut[1 + nparm]);
+      cut[0] = wsub(wadd(cut[0], (E)1), cut[1 + nparm]);
       for (auto &x : cut) x = wneg(x);
       const bool found = has_cut(cx, nr, nparm, p, cut);
       for (auto &x : cut) x = wneg(x);
       if (found) return p;
-      cut[0] = wsub(wadd(cut[0], cut[1 + nparm]), 1);
+      cut[0] = wsub(wadd(cut[0], cut[1 + nparm]), (E)1);
     }
-    cut[0] = wsub(wadd(cut[0], 1), cut[1 + nparm]);
+    cut[0] = wsub(wadd(cut[0], (E)1), cut[1 + nparm]);
     return -1;
   }
-  void add_parm(Ctx &cx, int &nparm, const std::vector<i64> &cut) {  // integrer.c:156-227
+  void add_parm(Ctx &cx, int &nparm, const std::vector<E> &cut) {  // integrer.c:156-227
     const int nr = cx.nc;
-    push(S_NEW, nparm, 0);
+    push(S_NEW, (E)nparm, 0);
     push(S_DIV, 0, 0);
-    push(S_FORM, nparm + 1, 0);
+    push(S_FORM, (E)(nparm + 1), 0);
     for (int j = 0; j < nparm; j++) push(S_VAL, wneg(cut[1 + j]), 1);
     push(S_VAL, wneg(cut[0]), 1);
     push(S_VAL, cut[1 + nparm], 1);
@@ -556,21 +580,21 @@ class Tree {
     }
     cx.at(nr, nparm) = wneg(cut[1 + nparm]);
     cx.at(nr + 1, nparm) = cut[1 + nparm];
-    i64 x = cut[0];
+    E x = cut[0];
     cx.at(nr, nparm + 1) = wneg(x);
-    x = wsub(x, 1);
+    x = wsub(x, (E)1);
     cx.at(nr + 1, nparm + 1) = wadd(x, cut[1 + nparm]);
     nparm++;
     cx.nc += 2;
   }
-  static i64 bezout(i64 x, i64 y, i64 delta) {  // integrer.c:98-150
-    i64 a = 1, b = 0, c = 0, d = 1, u = y, v = delta;
+  static E bezout(E x, E y, E delta) {  // integrer.c:98-150
+    E a = 1, b = 0, c = 0, d = 1, u = y, v = delta;
     for (;;) {
-      i64 q = floordiv(u, v), r = fmod_(u, v);
+      E q = floordiv(u, v), r = fmod_(u, v);
       if (r == 0) break;
       u = v;
       v = r;
-      i64 e = wsub(a, wmul(q, c)), f = wsub(b, wmul(q, d));
+      E e = wsub(a, wmul(q, c)), f = wsub(b, wmul(q, d));
       a = c;
       b = d;
       c = e;
@@ -588,9 +612,9 @@ class Tree {
     Snap s = download(job);
     const int ncol = nvar + nparm + 1, nligne = nvar + ni;
     if (ncol >= PIPAMD_MAXCOL) fail(PIPAMD_ST_MAXCOL);
-    const i64 *r = s.row(ci);
-    const i64 D = s.den[ci];
-    std::vector<i64> cut(ncol + 1);
+    const E *r = s.row(ci);
+    const E D = s.den[ci];
+    std::vector<E> cut(ncol + 1);
     bool ok_var = false, ok_parm = false;
     for (int j = 0; j < nvar; j++) {
       cut[j] = fmod_(r[j], D);
@@ -610,9 +634,9 @@ class Tree {
     if (!ok_parm) {
       if (!ok_var) return false;
       if (deepest_) {  // integrer.c:417-438
-        i64 t = wneg(cut[nvar]), delta = gcd(t, D), tau = cquo(t, delta), dd = cquo(D, delta);
-        t = wsub(dd, 1);
-        i64 lambda = bezout(t, tau, dd);
+        E t = wneg(cut[nvar]), delta = gcd(t, D), tau = cquo(t, delta), dd = cquo(D, delta);
+        t = wsub(dd, (E)1);
+        E lambda = bezout(t, tau, dd);
         t = gcd(lambda, D);
         while (t != 1) {
           lambda = wadd(lambda, dd);
@@ -624,7 +648,7 @@ class Tree {
         cut[nvar] = wneg(t);
       }
     } else {
-      std::vector<i64> pc(cut.begin() + nvar, cut.end());  // constant | parameters | divisor
+      std::vector<E> pc(cut.begin() + nvar, cut.end());  // constant | parameters | divisor
       int parm = find_parm(ctx, ctx.nc, nparm, pc);
       std::copy(pc.begin(), pc.end(), cut.begin() + nvar);
       if (parm == -1) {
@@ -639,14 +663,14 @@ class Tree {
     if (ni >= job.pj.S || nligne >= job.pj.L || need_w > job.pj.W)
       grow(job, std::max((int)job.pj.S, ni + 1) + 16, std::max((int)job.pj.W, need_w) + 4);
     const int W = job.pj.W, L = job.pj.L;
-    std::vector<i64> row(W, 0);
+    std::vector<E> row(W, 0);
     for (int j = 0; j < ncol; j++) row[j] = cut[j];
     if (newcol >= 0) row[newcol] = wadd(row[newcol], cut[ncol]);
-    copy(d_arena_ + job.pj.vals_off + (size_t)ni * W, row.data(), W * sizeof(i64), hipMemcpyHostToDevice);
-    i64 *g_den = d_arena_ + job.pj.rows_off;
+    copy((E *)(d_arena_ + job.pj.vals_off) + (size_t)ni * W, row.data(), W * sizeof(E), hipMemcpyHostToDevice);
+    E *g_den = (E *)(d_arena_ + job.pj.rows_off);
     int *g_flag = (int *)(g_den + L), *g_ref = g_flag + L;
     const int fl = PIPAMD_F_MINUS;
-    copy(g_den + nligne, &D, sizeof(i64), hipMemcpyHostToDevice);
+    copy(g_den + nligne, &D, sizeof(E), hipMemcpyHostToDevice);
     copy(g_flag + nligne, &fl, sizeof(int), hipMemcpyHostToDevice);
     copy(g_ref + nligne, &ni, sizeof(int), hipMemcpyHostToDevice);
     ni++;
@@ -659,12 +683,12 @@ class Tree {
 
   void emit_solution(const HostJob &job, int nvar, int nparm) {  // traiter.c:255-271
     const size_t n = (size_t)nvar * (nparm + 1);
-    std::vector<i64> buf(n + nvar);
+    std::vector<E> buf(n + nvar);
     if (n + nvar)
-      copy(buf.data(), d_arena_ + job.pj.sol_off, (n + nvar) * sizeof(i64), hipMemcpyDeviceToHost);
-    push(S_LIST, nvar, 0);
+      copy(buf.data(), d_arena_ + job.pj.sol_off, (n + nvar) * sizeof(E), hipMemcpyDeviceToHost);
+    push(S_LIST, (E)nvar, 0);
     for (int i = 0; i < nvar; i++) {
-      push(S_FORM, nparm + 1, 0);
+      push(S_FORM, (E)(nparm + 1), 0);
       for (int j = 0; j <= nparm; j++) push(S_VAL, buf[(size_t)i * (nparm + 1) + j], buf[n + i]);
     }
   }
@@ -682,7 +706,7 @@ class Tree {
     double smax = 0;
     for (int i = nvar; i < nligne; i++) {
       if (s.flag[i] & PIPAMD_F_UNIT) continue;
-      const i64 *r = s.row(i);
+      const E *r = s.row(i);
       double sz = 0, d = (double)s.den[i];
       for (int j = 0; j < nvar; j++) {
         int q = trunc_x86((double)r[j] / d);
@@ -720,13 +744,13 @@ class Tree {
   // solution_dual, traiter.c:274-294
   void emit_dual(const HostJob &job, int nvar, int ni, const std::vector<int> &pos) {
     Snap s = download(job);
-    push(S_LIST, ni, 0);
+    push(S_LIST, (E)ni, 0);
     for (int i = 0; i < ni; i++) {
       push(S_FORM, 1, 0);
       const int k = pos[i];
       if (s.flag[k] & PIPAMD_F_UNIT) {
         const int u = s.ref[k];
-        i64 v;
+        E v;
         if (s.flag[0] & PIPAMD_F_UNIT)
           v = (s.ref[0] == u) ? s.den[0] : 0;
         else
@@ -796,14 +820,14 @@ class Tree {
       const size_t mark = top_;
       HostJob child = alloc_job(nvar, nparm, ni, bigparm, flags, job.pj.S, job.pj.W);
       if (child.pj.L != job.pj.L || child.pj.S != job.pj.S || child.pj.W != job.pj.W) fail(PIPAMD_ST_INTERNAL);
-      copy(d_arena_ + child.block_off, d_arena_ + job.block_off,
-                         (2 * (size_t)job.pj.L + (size_t)job.pj.S * job.pj.W) * sizeof(i64), hipMemcpyDeviceToDevice);
+      copy(d_arena_ + child.block_off, d_arena_ + job.block_off, tab_words(job.pj.L, job.pj.S, job.pj.W) * sizeof(i64),
+           hipMemcpyDeviceToDevice);
       child.pj.ldet = job.pj.ldet;
       memcpy(child.pj.det, job.pj.det, sizeof job.pj.det);
       push(S_IF, 0, 0);
-      push(S_FORM, nparm + 1, 0);
-      const i64 *r = s.row(pivi);
-      i64 g = 0;
+      push(S_FORM, (E)(nparm + 1), 0);
+      const E *r = s.row(pivi);
+      E g = 0;
       for (int j = 0; j < nparm; j++) g = gcd(g, r[j + nvar + 1]);
       if (!(flags & PIPAMD_T_INT)) g = gcd(g, r[nvar]);
       const int nc = ctx.nc;
@@ -822,12 +846,13 @@ class Tree {
       }
       top_ = mark;
       for (int j = 0; j < nparm; j++) ctx.at(nc, j) = wneg(ctx.at(nc, j));
-      ctx.at(nc, nparm) = wneg(wadd(ctx.at(nc, nparm), 1));
+      ctx.at(nc, nparm) = wneg(wadd(ctx.at(nc, nparm), (E)1));
       ctx.nc = nc + 1;
       set_flag(job, pivi, PIPAMD_F_MINUS);
     }
   }
 };
+typedef TreeT<i64> Tree;
 
 // tab_simplify (tab.c:396-427) on a row-major matrix
 void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) {
@@ -863,6 +888,24 @@ static int export_tape(const std::vector<Cell> &tape, pipamd_sol_cell **cells, s
   return PIPAMD_OK;
 }
 
+static int export_tape(const std::vector<CellT<i128>> &tape, pipamd_sol_cell128 **cells, size_t *n_cells) {
+  *n_cells = tape.size();
+  *cells = nullptr;
+  if (tape.empty()) return PIPAMD_OK;
+  pipamd_sol_cell128 *c = (pipamd_sol_cell128 *)malloc(tape.size() * sizeof *c);
+  if (!c) return PIPAMD_E_NOMEM;
+  for (size_t i = 0; i < tape.size(); i++) {
+    c[i].kind = tape[i].kind;
+    c[i].reserved = 0;
+    c[i].param1_lo = (int64_t)(u64)(unsigned __int128)tape[i].a;
+    c[i].param1_hi = (int64_t)(tape[i].a >> 64);
+    c[i].param2_lo = (int64_t)(u64)(unsigned __int128)tape[i].b;
+    c[i].param2_hi = (int64_t)(tape[i].b >> 64);
+  }
+  *cells = c;
+  return PIPAMD_OK;
+}
+
 static bool valid_shape(int nvar, int nparm, int ni, int nc, int bigparm, const void *ineq, const void *ctx) {
   if (nvar < 0 || nparm < 0 || ni < 0 || nc < 0 || (ni && !ineq) || (nc && !ctx)) {
     pipamd_set_error("invalid tableau shape or missing rows");
@@ -878,8 +921,9 @@ static bool valid_shape(int nvar, int nparm, int ni, int nc, int bigparm, const 
 
 // one problem on an existing tree (device buffers and stream are reused between problems);
 // an empty tape with PIPAMD_OK is the front ends' "void" (empty context)
-static int solve_one(Tree &t, int nvar, int nparm, int ni, int nc, int bigparm, int nq, const int64_t *ineq,
-                     const int64_t *ctx, int simplify, int deepest_cut, pipamd_sol_cell **cells, size_t *n_cells,
+template <class TREE, class CELL>
+static int solve_one(TREE &t, int nvar, int nparm, int ni, int nc, int bigparm, int nq, const int64_t *ineq,
+                     const int64_t *ctx, int simplify, int deepest_cut, CELL **cells, size_t *n_cells,
                      int *status, int64_t *pivots) {
   if (!cells || !n_cells || !valid_shape(nvar, nparm, ni, nc, bigparm, ineq, ctx)) return PIPAMD_E_INVALID;
   const int ncol = nvar + nparm + 1;
@@ -923,9 +967,10 @@ extern "C" int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int n
 }
 
 // traiter() (traiter.c:628-791) behind the reference's own front ends: see include/piplib_amd.h
-extern "C" int pipamd_traiter(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int flags,
-                              int deepest_cut, const int64_t *tableau, const int64_t *context,
-                              pipamd_sol_cell **cells, size_t *n_cells, int *status, int64_t *pivots) {
+template <class E, class CELL>
+static int traiter_any(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int flags, int deepest_cut,
+                       const int64_t *tableau, const int64_t *context, CELL **cells, size_t *n_cells, int *status,
+                       int64_t *pivots) {
   if (!e || !cells || !n_cells || !valid_shape(nvar, nparm, ni, nc, bigparm, tableau, context)) return PIPAMD_E_INVALID;
   if ((flags & ~(PIPAMD_T_INT | PIPAMD_T_DUAL)) || ((flags & PIPAMD_T_INT) && (flags & PIPAMD_T_DUAL))) {
     pipamd_set_error("pipamd_traiter: flags must be 0, PIPAMD_T_INT or PIPAMD_T_DUAL (the dual needs a rational solve)");
@@ -938,7 +983,7 @@ extern "C" int pipamd_traiter(pipamd_engine *e, int nvar, int nparm, int ni, int
   if (pivots) *pivots = 0;
   int rc = PIPAMD_OK;
   try {
-    Tree t(e, deepest_cut);
+    TreeT<E> t(e, deepest_cut);
     try {
       t.traiter_call(nvar, nparm, ni, nc, bigparm, flags, (const i64 *)tableau, (const i64 *)context);
     } catch (int code) {
@@ -953,6 +998,32 @@ extern "C" int pipamd_traiter(pipamd_engine *e, int nvar, int nparm, int ni, int
     rc = code;
   }
   return rc;
+}
+extern "C" int pipamd_traiter(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int flags,
+                              int deepest_cut, const int64_t *tableau, const int64_t *context,
+                              pipamd_sol_cell **cells, size_t *n_cells, int *status, int64_t *pivots) {
+  return traiter_any<i64>(e, nvar, nparm, ni, nc, bigparm, flags, deepest_cut, tableau, context, cells, n_cells, status,
+                          pivots);
+}
+// the overflow-safe flavour (include/piplib/piplib.h:42-88): 128-bit entries on the device and in
+// the host tree, inputs still int64, cells with 128-bit parameters
+extern "C" int pipamd_traiter128(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int flags,
+                                 int deepest_cut, const int64_t *tableau, const int64_t *context,
+                                 pipamd_sol_cell128 **cells, size_t *n_cells, int *status, int64_t *pivots) {
+  return traiter_any<i128>(e, nvar, nparm, ni, nc, bigparm, flags, deepest_cut, tableau, context, cells, n_cells, status,
+                           pivots);
+}
+extern "C" int pipamd_solve_tableau128(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bigparm, int nq,
+                                       const int64_t *ineq, const int64_t *ctx, int simplify, int deepest_cut,
+                                       pipamd_sol_cell128 **cells, size_t *n_cells, int *status, int64_t *pivots) {
+  if (!e) return PIPAMD_E_INVALID;
+  if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
+  try {
+    TreeT<i128> t(e, deepest_cut);
+    return solve_one(t, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify, deepest_cut, cells, n_cells, status, pivots);
+  } catch (int code) {
+    return code;
+  }
 }
 
 // Many independent problems: `nthreads` host threads, each with its own tree (device arena and
@@ -1416,7 +1487,7 @@ class Forest {
     Frame &f = q.stack.back();
     const int nc = f.ctx.nc;
     for (int j = 0; j < f.nparm; j++) f.ctx.at(nc, j) = wneg(f.ctx.at(nc, j));
-    f.ctx.at(nc, f.nparm) = wneg(wadd(f.ctx.at(nc, f.nparm), 1));
+    f.ctx.at(nc, f.nparm) = wneg(wadd(f.ctx.at(nc, f.nparm), (i64)1));
     f.ctx.nc = nc + 1;
     patch_flag(jobs_[f.job], f.split_row, PIPAMD_F_MINUS);
     jobs_[f.job].status = PIPAMD_ST_RUN;
@@ -1493,10 +1564,10 @@ class Forest {
       f.rowvals.push_back(rv);
       std::vector<i64> ex(np + 1);
       for (int j = 0; j < np; j++) ex[j] = rv[1 + j];
-      ex[np] = r[1] ? rv[0] : wsub(rv[0], 1);
+      ex[np] = r[1] ? rv[0] : wsub(rv[0], (i64)1);
       context_job(i, f.ctx, np, f.ctx.nc, &ex);
       for (int j = 0; j < np; j++) ex[j] = wneg(rv[1 + j]);
-      ex[np] = wsub(wneg(rv[0]), 1);
+      ex[np] = wsub(wneg(rv[0]), (i64)1);
       context_job(i, f.ctx, np, f.ctx.nc, &ex);
       f.sub_count += 2;
     }
@@ -1659,7 +1730,7 @@ class Forest {
       f.ctx.at(nr + 1, nparm) = pc[1 + nparm];
       i64 x = pc[0];
       f.ctx.at(nr, nparm + 1) = wneg(x);
-      x = wsub(x, 1);
+      x = wsub(x, (i64)1);
       f.ctx.at(nr + 1, nparm + 1) = wadd(x, pc[1 + nparm]);
       nparm++;
       f.ctx.nc += 2;

@@ -251,47 +251,64 @@ def _rows(ineq, ctx, ni, nc, nvar, nparm):
     return a, c
 
 
-def solve_tableau_cells(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify=True, deepest_cut=False):
-    """Layer 3: one problem in .dat form (host arrays) -> (tape cells, pivots).
+class SolCell128(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("p1lo", C.c_int64), ("p1hi", C.c_int64),
+                ("p2lo", C.c_int64), ("p2hi", C.c_int64)]
+
+
+def _take_cells128(ptr, n):
+    if not ptr or not n:
+        return []
+    arr = C.cast(ptr, C.POINTER(SolCell128 * n)).contents
+    m = (1 << 64) - 1
+    cells = [(c.kind, (c.p1hi << 64) | (c.p1lo & m), (c.p2hi << 64) | (c.p2lo & m)) for c in arr]
+    lib().pipamd_free(ptr)
+    return cells
+
+
+def solve_tableau_cells(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify=True, deepest_cut=False, bits=64):
+    """Layer 3: one problem in .dat form (host arrays) -> (tape cells, pivots); bits=128 runs the
+    overflow-safe flavour (128-bit entries on the device and in the host tree).
     Raises SolverError(status) where the reference would have exit()ed."""
     a, c = _rows(ineq, ctx, ni, nc, nvar, nparm)
     L = lib()
-    L.pipamd_solve_tableau.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                                                    C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
-                                                                    C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    fn = L.pipamd_solve_tableau128 if bits == 128 else L.pipamd_solve_tableau
+    fn.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                                  C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     cells, n = C.c_void_p(), C.c_size_t(0)
     status, piv = C.c_int(0), C.c_int64(0)
-    rc = L.pipamd_solve_tableau(engine._h, nvar, nparm, ni, nc, bigparm, nq, C.c_void_p(a.ctypes.data),
-                                C.c_void_p(c.ctypes.data), int(bool(simplify)), int(bool(deepest_cut)),
-                                C.byref(cells), C.byref(n), C.byref(status), C.byref(piv))
+    rc = fn(engine._h, nvar, nparm, ni, nc, bigparm, nq, C.c_void_p(a.ctypes.data),
+            C.c_void_p(c.ctypes.data), int(bool(simplify)), int(bool(deepest_cut)),
+            C.byref(cells), C.byref(n), C.byref(status), C.byref(piv))
     if rc == -5:
         raise SolverError(status.value, piv.value)
     _check(rc)
-    return _take_cells(cells, n.value), piv.value
+    return (_take_cells128 if bits == 128 else _take_cells)(cells, n.value), piv.value
 
 
-def solve_tableau(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify=True, deepest_cut=False):
+def solve_tableau(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify=True, deepest_cut=False, bits=64):
     """solve_tableau_cells, with the tape printed as sol_edit would (tests compare texts)."""
-    cells, piv = solve_tableau_cells(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify, deepest_cut)
+    cells, piv = solve_tableau_cells(engine, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify, deepest_cut, bits)
     return tape_text(cells), piv
 
 
-def traiter(engine, nvar, nparm, ni, nc, bigparm, flags, tableau, context, deepest_cut=False):
-    """pipamd_traiter: one traiter() call -> (tape cells, pivots)."""
+def traiter(engine, nvar, nparm, ni, nc, bigparm, flags, tableau, context, deepest_cut=False, bits=64):
+    """pipamd_traiter / pipamd_traiter128: one traiter() call -> (tape cells, pivots)."""
     a, c = _rows(tableau, context, ni, nc, nvar, nparm)
     L = lib()
-    L.pipamd_traiter.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
-                                                                C.POINTER(C.c_size_t), C.POINTER(C.c_int),
-                                                                C.POINTER(C.c_int64)]
+    fn = L.pipamd_traiter128 if bits == 128 else L.pipamd_traiter
+    fn.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                                  C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     cells, n = C.c_void_p(), C.c_size_t(0)
     status, piv = C.c_int(0), C.c_int64(0)
-    rc = L.pipamd_traiter(engine._h, nvar, nparm, ni, nc, bigparm, int(flags), int(bool(deepest_cut)),
-                          C.c_void_p(a.ctypes.data), C.c_void_p(c.ctypes.data), C.byref(cells), C.byref(n),
-                          C.byref(status), C.byref(piv))
+    rc = fn(engine._h, nvar, nparm, ni, nc, bigparm, int(flags), int(bool(deepest_cut)),
+            C.c_void_p(a.ctypes.data), C.c_void_p(c.ctypes.data), C.byref(cells), C.byref(n),
+            C.byref(status), C.byref(piv))
     if rc == -5:
         raise SolverError(status.value, piv.value)
     _check(rc)
-    return _take_cells(cells, n.value), piv.value
+    return (_take_cells128 if bits == 128 else _take_cells)(cells, n.value), piv.value
 
 
 class SolverError(RuntimeError):

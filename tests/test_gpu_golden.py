@@ -17,7 +17,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 G = os.path.join(pb.ROOT, "tests", "golden")
 
 
-def solve_file(path, **kw):
+def solve_file(path, bits=64, **kw):
     from piplib_amd import engine as eng
     e = eng.Engine(0)
     out = []
@@ -26,7 +26,7 @@ def solve_file(path, **kw):
         out.append("(" + p["comment"])
         try:
             text, _ = eng.solve_tableau(e, p["nvar"], p["nparm"], p["ni"], p["nc"], p["bigparm"], p["nq"],
-                                        p["ineq"], p["ctx"], **kw)
+                                        p["ineq"], p["ctx"], bits=bits, **kw)
         except eng.SolverError as ex:
             status = ex.status
             break
@@ -179,3 +179,47 @@ def test_pip_solve_fuzz_regressions(name, dom, ctx, opts):
     g = subprocess.run([pb.REFPIP_GPU, "pip"], input=txt, capture_output=True, timeout=600)
     assert g.returncode == 0, g.stderr.decode()[-300:]
     assert pb.squash(g.stdout.decode("latin-1")) == pb.squash(o.stdout.decode("latin-1"))
+
+
+# ---------------------------------------------------------------- 128-bit host tree (layer 3)
+@pytest.mark.parametrize("name", PIPTEST_DAT)
+def test_dat_golden_on_gpu_128bit_tree(name):
+    """The reference's .dat suite through pipamd_solve_tableau128: 128-bit entries on the device, in
+    the context, the parametric cuts and the tape.  Nothing overflows on these inputs, so the
+    overflow-safe flavour must print the reference's int64 goldens."""
+    got, status = solve_file(os.path.join(G, "test", name + ".dat"), bits=128)
+    assert status is None
+    want = open(os.path.join(G, "test", name + ".ll"), encoding="latin-1").read()
+    assert pb.squash(got) == pb.squash(want)
+
+
+@pytest.mark.parametrize("seed,shape,cmax", [(81, (5, 2, 9, 2), 60), (82, (6, 1, 10, 1), 200), (83, (4, 3, 8, 3), 30),
+                                            (84, (8, 2, 12, 2), 25)])
+def test_parametric_128bit_tree_vs_oracle128(seed, shape, cmax):
+    """Parametric problems with coefficients large enough that the int64 build overflows on part of
+    them: pipamd_solve_tableau128 against the 128-bit build of the CPU restatement (whose pivot path
+    is pinned by the exact-arithmetic fixtures): same text, same pivot counts, same aborts."""
+    import subprocess
+    from piplib_amd import engine as eng, synth
+    probs = synth.random_problems(seed, 24, *shape, 1, cmax=cmax, bmax=4 * cmax)
+    e = eng.Engine(0)
+    checked = over64 = 0
+    for p in probs:
+        try:
+            o128 = pb.run_batch(pb.ORACLEPIP128, [p], timeout=5).results[0]
+            o64 = pb.run_batch(pb.ORACLEPIP, [p], timeout=5).results[0]
+        except subprocess.TimeoutExpired:
+            continue
+        if o128.pivots > 20000:
+            continue
+        over64 += o64.status == pb.ST_ABORT and o128.status != pb.ST_ABORT
+        try:
+            text, piv = eng.solve_tableau(e, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx, bits=128)
+        except eng.SolverError as ex:
+            assert o128.status == pb.ST_ABORT, (seed, ex.status)
+            continue
+        assert o128.status != pb.ST_ABORT
+        want = "void\n" if o128.status == pb.ST_VOID else o128.text
+        assert pb.squash(text) == pb.squash(want) and piv == o128.pivots
+        checked += 1
+    assert checked >= 12
