@@ -93,6 +93,66 @@ template <class E> struct CtxT {
     }
     if ((size_t)rows * width > v.size()) v.resize((size_t)(rows + 8) * width, 0);
   }
+
+  // ---- parameters introduced by parametric cuts (integrer.c:156-291) ----
+  // A cut with parameter part c.p + c0 over the denominator D needs q = floor(-(c.p + c0) / D),
+  // i.e. the parameter q with 0 <= -(c.p + c0) - D q <= D - 1.  The context stores such a
+  // definition as the two rows of that double inequality, with q in a column of its own:
+  //     lower:  -c.p - D q - c0          >= 0
+  //     upper:   c.p + D q + c0 + D - 1  >= 0
+  struct Quotient {
+    std::vector<E> c;  // coefficients of the nparm existing parameters
+    E c0, D;           // constant, divisor
+  };
+  // is there a row  sign * (c on the columns before p | D in column p | 0 behind it)  with constant cst?
+  bool has_row(int nparm, int p, const Quotient &k, bool negated, E cst) const {
+    for (int r = 0; r < nc; r++) {
+      if (at(r, p) != (negated ? wneg(k.D) : k.D) || at(r, nparm) != cst) continue;
+      bool same = true;
+      for (int col = p + 1; col < nparm && same; col++) same = at(r, col) == 0;
+      for (int col = 0; col < p && same; col++) same = at(r, col) == (negated ? wneg(k.c[col]) : k.c[col]);
+      if (same) return true;
+    }
+    return false;
+  }
+  // A parameter the cut does not use (trailing zero coefficients) whose two defining rows are the
+  // ones this quotient would get: its column, or -1 (find_parm, integrer.c:258-291).
+  int find_quotient(int nparm, const Quotient &k) const {
+    const E upper_cst = wsub(wadd(k.c0, k.D), (E)1);
+    for (int p = nparm - 1; p >= 0 && k.c[p] == 0; --p)
+      if (has_row(nparm, p, k, false, upper_cst) && has_row(nparm, p, k, true, wneg(k.c0))) return p;
+    return -1;
+  }
+  // The new parameter takes column nparm (the constants move one column right) and its two rows
+  // are appended (add_parm, integrer.c:194-224).  Returns its column.
+  int define_quotient(int nparm, const Quotient &k) {
+    const int nr = nc;
+    reserve(nr + 2, nparm + 2);
+    for (int r = 0; r < nr; r++) {
+      at(r, nparm + 1) = at(r, nparm);
+      at(r, nparm) = 0;
+    }
+    for (int j = 0; j < nparm; j++) {
+      at(nr, j) = wneg(k.c[j]);
+      at(nr + 1, j) = k.c[j];
+    }
+    at(nr, nparm) = wneg(k.D);
+    at(nr + 1, nparm) = k.D;
+    at(nr, nparm + 1) = wneg(k.c0);
+    at(nr + 1, nparm + 1) = wadd(wsub(k.c0, (E)1), k.D);
+    nc += 2;
+    return nparm;
+  }
+  // what the solution tape says about it (integrer.c:173-188): New k, Div, the form -c.p - c0, D
+  template <class PUSH>
+  static void announce_quotient(PUSH &&push, int nparm, const Quotient &k) {
+    push(S_NEW, (E)nparm, (E)0);
+    push(S_DIV, (E)0, (E)0);
+    push(S_FORM, (E)(nparm + 1), (E)0);
+    for (int j = 0; j < nparm; j++) push(S_VAL, wneg(k.c[j]), (E)1);
+    push(S_VAL, wneg(k.c0), (E)1);
+    push(S_VAL, k.D, (E)1);
+  }
 };
 typedef CtxT<i64> Ctx;
 
@@ -529,64 +589,7 @@ class TreeT {
     top_ = mark;
   }
 
-  // --------------------------------------------------- find_parm / add_parm
-  static bool has_cut(const Ctx &cx, int nr, int nparm, int p, const std::vector<E> &cut) {
-    for (int row = 0; row < nr; row++) {
-      if (cx.at(row, p) != cut[1 + nparm]) continue;
-      if (cx.at(row, nparm) != cut[0]) continue;
-      int col;
-      for (col = p + 1; col < nparm; col++)
-        if (cx.at(row, col) != 0) break;
-      if (col < nparm) continue;
-      for (col = 0; col < p; col++)
-        if (cx.at(row, col) != cut[1 + col]) break;
-      if (col < p) continue;
-      return true;
-    }
-    return false;
-  }
-  static int find_parm(const Ctx &cx, int nr, int nparm, std::vector<E> &cut) {  // integrer.c:258-291
-    if (cut[1 + nparm - 1] != 0) return -1;
-    cut[0] = wsub(wadd(cut[0], cut[1 + nparm]), (E)1);
-    for (int p = nparm - 1; p >= 0; --p) {
-      if (cut[1 + p] != 0) break;
-      if (!has_cut(cx, nr, nparm, p, cut)) continue;
-      cut[0] = wsub(wadd(cut[0], (E)1), cut[1 + nparm]);
-      for (auto &x : cut) x = wneg(x);
-      const bool found = has_cut(cx, nr, nparm, p, cut);
-      for (auto &x : cut) x = wneg(x);
-      if (found) return p;
-      cut[0] = wsub(wadd(cut[0], cut[1 + nparm]), (E)1);
-    }
-    cut[0] = wsub(wadd(cut[0], (E)1), cut[1 + nparm]);
-    return -1;
-  }
-  void add_parm(Ctx &cx, int &nparm, const std::vector<E> &cut) {  // integrer.c:156-227
-    const int nr = cx.nc;
-    push(S_NEW, (E)nparm, 0);
-    push(S_DIV, 0, 0);
-    push(S_FORM, (E)(nparm + 1), 0);
-    for (int j = 0; j < nparm; j++) push(S_VAL, wneg(cut[1 + j]), 1);
-    push(S_VAL, wneg(cut[0]), 1);
-    push(S_VAL, cut[1 + nparm], 1);
-    cx.reserve(nr + 2, nparm + 2);
-    for (int k = 0; k < nr; k++) {
-      cx.at(k, nparm + 1) = cx.at(k, nparm);
-      cx.at(k, nparm) = 0;
-    }
-    for (int j = 0; j < nparm; j++) {
-      cx.at(nr, j) = wneg(cut[1 + j]);
-      cx.at(nr + 1, j) = cut[1 + j];
-    }
-    cx.at(nr, nparm) = wneg(cut[1 + nparm]);
-    cx.at(nr + 1, nparm) = cut[1 + nparm];
-    E x = cut[0];
-    cx.at(nr, nparm + 1) = wneg(x);
-    x = wsub(x, (E)1);
-    cx.at(nr + 1, nparm + 1) = wadd(x, cut[1 + nparm]);
-    nparm++;
-    cx.nc += 2;
-  }
+  // (find_parm / add_parm, integrer.c:156-291: CtxT::find_quotient / define_quotient)
   static E bezout(E x, E y, E delta) {  // integrer.c:98-150
     E a = 1, b = 0, c = 0, d = 1, u = y, v = delta;
     for (;;) {
@@ -648,12 +651,12 @@ class TreeT {
         cut[nvar] = wneg(t);
       }
     } else {
-      std::vector<E> pc(cut.begin() + nvar, cut.end());  // constant | parameters | divisor
-      int parm = find_parm(ctx, ctx.nc, nparm, pc);
-      std::copy(pc.begin(), pc.end(), cut.begin() + nvar);
+      typename Ctx::Quotient k{std::vector<E>(cut.begin() + nvar + 1, cut.begin() + ncol), cut[nvar], D};
+      int parm = ctx.find_quotient(nparm, k);
       if (parm == -1) {
-        add_parm(ctx, nparm, pc);
-        parm = nparm - 1;
+        Ctx::announce_quotient([&](int kind, E a, E b) { push(kind, a, b); }, nparm, k);
+        parm = ctx.define_quotient(nparm, k);
+        nparm++;
       }
       if (!ok_var) fail(PIPAMD_ST_INTERNAL);  // assert(ok_var), integrer.c:499
       newcol = nvar + 1 + parm;
@@ -1705,36 +1708,12 @@ class Forest {
     }
     cut[ncol] = D;
     if (!ok_parm) throw (int)PIPAMD_E_TOOLARGE;  // only reached with options the Tree handles
-    std::vector<i64> pc(cut.begin() + nvar, cut.end());
-    int parm = Tree::find_parm(f.ctx, f.ctx.nc, nparm, pc);
-    std::copy(pc.begin(), pc.end(), cut.begin() + nvar);
-    if (parm == -1) {
-      // add_parm (integrer.c:156-227) on this problem's tape and context
-      const int nr = f.ctx.nc;
-      tape_push(i, S_NEW, nparm, 0);
-      tape_push(i, S_DIV, 0, 0);
-      tape_push(i, S_FORM, nparm + 1, 0);
-      for (int j = 0; j < nparm; j++) tape_push(i, S_VAL, wneg(pc[1 + j]), 1);
-      tape_push(i, S_VAL, wneg(pc[0]), 1);
-      tape_push(i, S_VAL, pc[1 + nparm], 1);
-      f.ctx.reserve(nr + 2, nparm + 2);
-      for (int k = 0; k < nr; k++) {
-        f.ctx.at(k, nparm + 1) = f.ctx.at(k, nparm);
-        f.ctx.at(k, nparm) = 0;
-      }
-      for (int j = 0; j < nparm; j++) {
-        f.ctx.at(nr, j) = wneg(pc[1 + j]);
-        f.ctx.at(nr + 1, j) = pc[1 + j];
-      }
-      f.ctx.at(nr, nparm) = wneg(pc[1 + nparm]);
-      f.ctx.at(nr + 1, nparm) = pc[1 + nparm];
-      i64 x = pc[0];
-      f.ctx.at(nr, nparm + 1) = wneg(x);
-      x = wsub(x, (i64)1);
-      f.ctx.at(nr + 1, nparm + 1) = wadd(x, pc[1 + nparm]);
+    Ctx::Quotient k{std::vector<i64>(cut.begin() + nvar + 1, cut.begin() + ncol), cut[nvar], D};
+    int parm = f.ctx.find_quotient(nparm, k);
+    if (parm == -1) {  // a new parameter on this problem's tape and context
+      Ctx::announce_quotient([&](int kind, i64 a, i64 b) { tape_push(i, kind, a, b); }, nparm, k);
+      parm = f.ctx.define_quotient(nparm, k);
       nparm++;
-      f.ctx.nc += 2;
-      parm = nparm - 1;
     }
     if (!ok_var) fail(i, PIPAMD_ST_INTERNAL);  // assert(ok_var), integrer.c:499
     const int newcol = nvar + 1 + parm;
