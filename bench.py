@@ -258,7 +258,7 @@ def main():
                          "over the ranks; weak (default for one GPU): --batch tableaux per GPU and batch.  The other "
                          "mode is measured too and reported as `other_scaling`.")
     ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (streams/threads)")
-    ap.add_argument("--stagger", type=float, default=-1.0,
+    ap.add_argument("--stagger", type=float, default=0.0,
                     help="ms between the lanes' starts (0 = none, <0 = step latency / lanes, measured in warm-up)")
     ap.add_argument("--no-dense", action="store_true", help="skip the row-skipping-off measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
