@@ -1163,12 +1163,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   const int Lmax = SC > 0 ? SC + NCH * 64 * ET<T>::CPL : Lmax_;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Scalars sc;
-  // Determinant limbs (traiter.c:413-446).  64-bit entries: scalar registers.  128-bit entries:
-  // eight limbs of four registers each do not fit, and a dynamically indexed local array would
-  // live in scratch memory -- they are kept in LDS and updated by wave 0 in phase A.
-  constexpr bool DET_LDS = sizeof(T) == 16;
-  __shared__ T sdet[DET_LDS ? PIPAMD_MAXDET : 1];
-  __shared__ int sldet;
   (void)Wmax;
   const int nq = q.in_count ? *q.in_count : njobs;
   if ((int)blockIdx.x >= nq) return;
@@ -1225,12 +1219,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   int *g_ref = g_flag + L;
   int nligne = nvar + ni;
   int npiv = J->npiv, ncut = J->ncut, nupd = J->nupd;
-  int ldet = J->ldet;
-  // 64-bit entries: the determinant limbs (traiter.c:412-446) are not updated here -- every pivot
-  // appends (pivot, denominator of the pivot row) to the job's log, pip_det_replay_kernel runs the
-  // bookkeeping and its "Integer overflow" tests after the launch, one lane per job
-  i64 *g_log = arena + J->log_off;
-  int nlog = DET_LDS ? 0 : J->nlog;
+  // The determinant limbs (traiter.c:412-446) are not updated here: every pivot appends (pivot,
+  // denominator of the pivot row) to the job's log, the pip_det_replay kernels run the bookkeeping
+  // and its "Integer overflow" tests after the launch
+  T *g_log = (T *)(arena + J->log_off);
+  constexpr int LOGCAP = PIPAMD_DETLOG / ET<T>::EW;  // the log area holds 512 pairs of 64-bit or 256 of 128-bit values
+  int nlog = J->nlog;
   if (ni > Smax || nligne > Lmax) {  // this launch's LDS image is too small: stay RUN for a larger one
     if (tid == 0 && q.out_count) {
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
@@ -1245,10 +1239,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
 
   // ---- stage the row tables in LDS -------------------------------------
   for (int j = tid; j < WP; j += NT) S.urow[j] = NOROW;  // prow is written whole by every phase A
-  if constexpr (DET_LDS) {
-    if (tid < PIPAMD_MAXDET) sdet[tid] = (T)(((u128)(u64)J->det[2 * tid + 1] << 64) | (u64)J->det[2 * tid]);
-    if (tid == 0) sldet = ldet;
-  }
   if (tid == 0) {
     sc.ovf = 0;
     sc.aux = 0;
@@ -1372,7 +1362,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   PROF(0);
   for (int iter = 0;; iter++) {
     if (iter >= iter_limit) break;  // status stays RUN: the host relaunches
-    if (!DET_LDS && nlog >= PIPAMD_DETLOG) break;  // determinant log full: likewise
+    if (nlog >= LOGCAP) break;  // determinant log full: likewise
     int pivi = sc.pivi;
     if (pivi == BIG_I) {
       // -------------- exam_coef, then (if nothing is negative) integrer ---------
@@ -1573,49 +1563,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         }
         if (lane == 0) sc.nwork = base;
       }
-      if constexpr (DET_LDS) {
-        if (pj >= 0) {  // determinant bookkeeping on the LDS limbs (wave-uniform; lane 0 writes)
-          const T pivot = uni64(S.prow[pj]), dpiv = uni64(S.den[pslot]);
-          T d = gcd_i64(pivot, dpiv);
-          T ppivot = pivot, dppiv = dpiv;
-          if (d != 1) {
-            ppivot = cquo(pivot, d);
-            dppiv = cquo(dpiv, d);
-          }
-          int ld = __builtin_amdgcn_readfirstlane(sldet);
-          for (int i = 0; i < ld && dppiv != 1; i++) {
-            T x = uni64(sdet[i]);
-            d = gcd_i64(x, dppiv);
-            if (d != 1) {
-              x = cquo(x, d);
-              dppiv = cquo(dppiv, d);
-              if (lane == 0) sdet[i] = x;
-            }
-          }
-          bool ovf = dppiv != 1;
-          if (!ovf) {
-            const int lpp = log2_64(ppivot);
-            int i = 0;
-            for (; i < ld; i++) {
-              const T x = uni64(sdet[i]);
-              if (log2_64(x) + lpp < ET<T>::BITS) {
-                if (ppivot != 1 && lane == 0) sdet[i] = wmul(x, ppivot);
-                break;
-              }
-            }
-            if (i >= ld) {
-              ld++;
-              if (ld >= PIPAMD_MAXDET)
-                ovf = true;
-              else if (lane == 0) {
-                sdet[i] = ppivot;
-                sldet = ld;
-              }
-            }
-          }
-          if (ovf && lane == 0) sc.ovf = 1;
-        }
-      }
       if (lane == 0) sc.pivj = pj;
     }
     bsync<NW>();
@@ -1652,21 +1599,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       const int sw = q == 0 ? wq0 : (q == 1 ? wq1 : (int)S.work[w < nwork ? w : 0]);
       if (w < nwork && sw != pslot) row_load<T, NCH>(rr[q], vals + (size_t)sw * W, ncolp, lane);
     }
-    // pivot scalars + determinant bookkeeping, traiter.c:394-446 (uniform, every thread)
+    // pivot scalars, traiter.c:394-396 (uniform, every thread); the determinant bookkeeping of
+    // traiter.c:412-446 only needs them logged
     const T pivot = uni64(S.prow[pivj]);
     const T dpiv = uni64(dpiv_v);
-    if constexpr (DET_LDS) {
-      if (sc.ovf) {  // "Integer overflow", traiter.c:424,442
-        status = PIPAMD_ST_OVERFLOW;
-        break;
-      }
-    } else {
-      if (tid == 0) {
-        g_log[2 * nlog] = (i64)pivot;
-        g_log[2 * nlog + 1] = (i64)dpiv;
-      }
-      nlog++;
+    if (tid == 0) {
+      g_log[2 * nlog] = pivot;
+      g_log[2 * nlog + 1] = dpiv;
     }
+    nlog++;
     const int ku = S.urow[pivj];  // unit row of the entering column
     const int pred = psig_v & SIG_RED;
     const int pc = pivj / (64 * ET<T>::CPL), ph = pivj % ET<T>::CPL, pl = (pivj % (64 * ET<T>::CPL)) / ET<T>::CPL;
@@ -1877,16 +1818,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     J->npiv = npiv;
     J->ncut = ncut;
     J->nupd = nupd;
-    if constexpr (DET_LDS) {
-      J->ldet = sldet;
-      for (int i = 0; i < PIPAMD_MAXDET; i++) {
-        J->det[2 * i] = (i64)(u64)(u128)sdet[i];
-        J->det[2 * i + 1] = (i64)(u64)((u128)sdet[i] >> 64);
-      }
-    } else {
-      (void)ldet;
-      J->nlog = nlog;
-    }
+    J->nlog = nlog;
     J->tflags = tflags;
     J->state_nch = NCH;
     J->maxabs = (u64)mc;  // magnitude class of the largest entry
@@ -1902,35 +1834,93 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
 }
 
 // ------------------------------------------------------------- determinant replay
-// traiter.c:394-446 for the pivots a launch logged, one WAVE per job: d = gcd(pivot, dpiv); the
-// limbs lose the factors of dpiv / d (if some factor is left: "Integer overflow"); the first limb
-// with room takes pivot / d (a fourth limb: "Integer overflow").  The bookkeeping never feeds
-// back into the pivot loop, so it can trail it; an overflow found here overrides whatever the
-// job's status became and sets the pivot count to the pivot that overflowed.
-// Two steps per block of 64 log entries: gcd(pivot, dpiv) and the two quotients do not depend on
-// the limbs, so the lanes compute them for 64 pivots at once; only the walk over the limbs (a
-// division pass when dpiv / d != 1, then the first-fit multiplication) is sequential, on the
-// scalar unit.  In the pivot loop itself this bookkeeping was ~12 % of all instructions.
+// traiter.c:394-446 for the pivots a launch logged: d = gcd(pivot, dpiv); the limbs lose the
+// factors of dpiv / d (if some factor is left: "Integer overflow"); the first limb with room takes
+// pivot / d (a fourth limb: "Integer overflow").  The bookkeeping never feeds back into the pivot
+// loop, so it can trail it; an overflow found here overrides whatever the job's status became
+// and sets the pivot count to the pivot that overflowed.  In the pivot loop itself this was
+// wave-uniform scalar work: ~12 % of all instructions with 64-bit entries, ~18 % of the run time
+// with 128-bit ones.
+template <class T>
+__device__ __forceinline__ T det_limb(const PipJob *J, int i) {
+  if constexpr (sizeof(T) == 16)
+    return (T)(((u128)(u64)J->det[2 * i + 1] << 64) | (u64)J->det[2 * i]);
+  else
+    return (T)J->det[i];
+}
+template <class T>
+__device__ __forceinline__ void det_limb_store(PipJob *J, int i, T x) {
+  if constexpr (sizeof(T) == 16) {
+    J->det[2 * i] = (i64)(u64)(u128)x;
+    J->det[2 * i + 1] = (i64)(u64)((u128)x >> 64);
+  } else
+    J->det[i] = (i64)x;
+}
+// one step of the walk over the limbs for the reduced pair (ppivot, dppiv); false = overflow
+template <class T>
+__device__ __forceinline__ bool det_step(T &det0, T &det1, T &det2, T &det3, int &ldet, T ppivot, T dppiv) {
+  // once dppiv is 1 the remaining limbs would be divided by gcd(limb, 1) = 1
+#define PIP_DET_DIVIDE(limb, i)                    \
+  if ((i) < ldet && dppiv != 1) {                  \
+    const T d_ = gcd_i64(limb, dppiv);             \
+    if (d_ != 1) {                                 \
+      limb = exact_quo(limb, d_);                  \
+      dppiv = exact_quo(dppiv, d_);                \
+    }                                              \
+  }
+  PIP_DET_DIVIDE(det0, 0)
+  PIP_DET_DIVIDE(det1, 1)
+  PIP_DET_DIVIDE(det2, 2)
+  PIP_DET_DIVIDE(det3, 3)
+#undef PIP_DET_DIVIDE
+  if (dppiv != 1) return false;
+  constexpr int B = ET<T>::BITS;
+  const int lp = log2_64(ppivot);
+  if (0 < ldet && log2_64(det0) + lp < B)
+    det0 = wmul(det0, ppivot);
+  else if (1 < ldet && log2_64(det1) + lp < B)
+    det1 = wmul(det1, ppivot);
+  else if (2 < ldet && log2_64(det2) + lp < B)
+    det2 = wmul(det2, ppivot);
+  else if (3 < ldet && log2_64(det3) + lp < B)
+    det3 = wmul(det3, ppivot);
+  else {
+    ldet++;
+    if (ldet >= PIPAMD_MAXDET) return false;
+    if (ldet == 1)
+      det0 = ppivot;
+    else if (ldet == 2)
+      det1 = ppivot;
+    else
+      det2 = ppivot;
+  }
+  return true;
+}
+
+// One WAVE per job: gcd(pivot, dpiv) and the two quotients do not depend on the limbs, so the
+// lanes compute them for 64 pivots at once; only the walk over the limbs is sequential, on the
+// scalar unit.  Shortest latency: used where few jobs ran and someone waits for them.
+template <class T>
 __global__ __launch_bounds__(64) void pip_det_replay_kernel(PipJob *jobs, i64 *arena, int njobs, PipQueue q) {
   const int t = blockIdx.x, lane = threadIdx.x;
   const int nq = q.in_count ? *q.in_count : njobs;
   if (t >= nq) return;
   PipJob *J = &jobs[q.in_list ? q.in_list[t] : t];
   const int nlog = J->nlog;
-  if (nlog <= 0 || J->ebits == 128) return;
-  const i64 *lg = arena + J->log_off;
-  i64 det0 = uni64((i64)J->det[0]), det1 = uni64((i64)J->det[1]), det2 = uni64((i64)J->det[2]), det3 = uni64((i64)J->det[3]);
+  if (nlog <= 0 || (J->ebits == 128) != (sizeof(T) == 16)) return;
+  const T *lg = (const T *)(arena + J->log_off);
+  T det0 = uni64(det_limb<T>(J, 0)), det1 = uni64(det_limb<T>(J, 1)), det2 = uni64(det_limb<T>(J, 2)),
+    det3 = uni64(det_limb<T>(J, 3));
   int ldet = __builtin_amdgcn_readfirstlane(J->ldet);
   int bad = -1;
   for (int base = 0; base < nlog && bad < 0; base += 64) {
     const int k = base + lane;
-    i64 pp = 1, dp = 1;
+    T pp = 1, dp = 1;
     if (k < nlog) {
-      const longlong2 e = *reinterpret_cast<const longlong2 *>(lg + 2 * k);
-      pp = e.x;
-      dp = e.y;
+      pp = lg[2 * k];
+      dp = lg[2 * k + 1];
       if (dp != 1) {
-        const i64 d = gcd_i64(pp, dp);
+        const T d = gcd_i64(pp, dp);
         if (d != 1) {
           pp = exact_quo(pp, d);
           dp = exact_quo(dp, d);
@@ -1939,47 +1929,8 @@ __global__ __launch_bounds__(64) void pip_det_replay_kernel(PipJob *jobs, i64 *a
     }
     const int n = nlog - base < 64 ? nlog - base : 64;
     for (int j = 0; j < n; j++) {
-      const i64 ppivot = readlane64(pp, j);
-      i64 dppiv = readlane64(dp, j);
-      // once dppiv is 1 the remaining limbs would be divided by gcd(limb, 1) = 1
-#define PIP_DET_DIVIDE(limb, i)                    \
-  if ((i) < ldet && dppiv != 1) {                  \
-    const i64 d_ = gcd_i64(limb, dppiv);           \
-    if (d_ != 1) {                                 \
-      limb = exact_quo(limb, d_);                  \
-      dppiv = exact_quo(dppiv, d_);                \
-    }                                              \
-  }
-      PIP_DET_DIVIDE(det0, 0)
-      PIP_DET_DIVIDE(det1, 1)
-      PIP_DET_DIVIDE(det2, 2)
-      PIP_DET_DIVIDE(det3, 3)
-#undef PIP_DET_DIVIDE
-      bool ovf = dppiv != 1;
-      if (!ovf) {
-        const int lp = log2_64(ppivot);
-        if (0 < ldet && log2_64(det0) + lp < 64)
-          det0 = wmul(det0, ppivot);
-        else if (1 < ldet && log2_64(det1) + lp < 64)
-          det1 = wmul(det1, ppivot);
-        else if (2 < ldet && log2_64(det2) + lp < 64)
-          det2 = wmul(det2, ppivot);
-        else if (3 < ldet && log2_64(det3) + lp < 64)
-          det3 = wmul(det3, ppivot);
-        else {
-          ldet++;
-          if (ldet >= PIPAMD_MAXDET)
-            ovf = true;
-          else if (ldet == 1)
-            det0 = ppivot;
-          else if (ldet == 2)
-            det1 = ppivot;
-          else
-            det2 = ppivot;
-        }
-      }
-      if (ovf) {  // traiter.c:424,442: the reference exits inside this call of pivoter
-        bad = base + j;
+      if (!det_step<T>(det0, det1, det2, det3, ldet, readlane64(pp, j), readlane64(dp, j))) {
+        bad = base + j;  // traiter.c:424,442: the reference exits inside this call of pivoter
         break;
       }
     }
@@ -1989,87 +1940,62 @@ __global__ __launch_bounds__(64) void pip_det_replay_kernel(PipJob *jobs, i64 *a
       J->status = PIPAMD_ST_OVERFLOW;
       J->npiv = J->npiv - nlog + bad + 1;
     }
-    J->det[0] = det0;
-    J->det[1] = det1;
-    J->det[2] = det2;
-    J->det[3] = det3;
+    det_limb_store<T>(J, 0, det0);
+    det_limb_store<T>(J, 1, det1);
+    det_limb_store<T>(J, 2, det2);
+    det_limb_store<T>(J, 3, det3);
     J->ldet = ldet;
     J->nlog = 0;
   }
 }
 
-// The same with one LANE per job (64 jobs per wave): far fewer instructions issued in all -- what
-// counts behind a bulk launch, when the GPU is kept busy by other batches -- at the price of a
-// longer latency per job (a lane walks its log alone).
+// One LANE per job (64 jobs per wave): far fewer instructions issued in all -- what counts behind
+// a bulk launch, when the GPU is kept busy by other batches -- at the price of a longer latency
+// per job (a lane walks its log alone).
+template <class T>
 __global__ __launch_bounds__(64) void pip_det_replay_lanes_kernel(PipJob *jobs, i64 *arena, int njobs, PipQueue q) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int nq = q.in_count ? *q.in_count : njobs;
   if (t >= nq) return;
   PipJob *J = &jobs[q.in_list ? q.in_list[t] : t];
   const int nlog = J->nlog;
-  if (nlog <= 0 || J->ebits == 128) return;
-  const i64 *lg = arena + J->log_off;
-  i64 det[PIPAMD_MAXDET];
-  for (int i = 0; i < PIPAMD_MAXDET; i++) det[i] = J->det[i];
+  if (nlog <= 0 || (J->ebits == 128) != (sizeof(T) == 16)) return;
+  const T *lg = (const T *)(arena + J->log_off);
+  T det0 = det_limb<T>(J, 0), det1 = det_limb<T>(J, 1), det2 = det_limb<T>(J, 2), det3 = det_limb<T>(J, 3);
   int ldet = J->ldet;
+  constexpr int CH = sizeof(T) == 16 ? 4 : 8;  // log entries per 128-byte line
   bool stop = false;
-  for (int k0 = 0; k0 < nlog && !stop; k0 += 8) {
-    // eight log entries (one 128-byte line of this lane's log) per round trip to memory
-    longlong2 ev[8];
+  for (int k0 = 0; k0 < nlog && !stop; k0 += CH) {
+    T ev[CH][2];
 #pragma unroll
-    for (int u = 0; u < 8; u++)
-      ev[u] = k0 + u < nlog ? *reinterpret_cast<const longlong2 *>(lg + 2 * (k0 + u)) : longlong2{1, 1};
+    for (int u = 0; u < CH; u++) {
+      const bool in = k0 + u < nlog;
+      ev[u][0] = in ? lg[2 * (k0 + u)] : (T)1;
+      ev[u][1] = in ? lg[2 * (k0 + u) + 1] : (T)1;
+    }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-    const int k = k0 + u;
-    if (k >= nlog || stop) break;
-    i64 ppivot = ev[u].x, dppiv = ev[u].y;
-    if (dppiv != 1) {
-      i64 d = gcd_i64(ppivot, dppiv);
-      if (d != 1) {
-        ppivot = exact_quo(ppivot, d);
-        dppiv = exact_quo(dppiv, d);
-      }
-      // once dppiv is 1 the remaining limbs would be divided by gcd(limb, 1) = 1
-      for (int i = 0; i < PIPAMD_MAXDET; i++) {
-        if (i >= ldet || dppiv == 1) break;
-        d = gcd_i64(det[i], dppiv);
+    for (int u = 0; u < CH; u++) {
+      const int k = k0 + u;
+      if (k >= nlog || stop) break;
+      T ppivot = ev[u][0], dppiv = ev[u][1];
+      if (dppiv != 1) {
+        const T d = gcd_i64(ppivot, dppiv);
         if (d != 1) {
-          det[i] = exact_quo(det[i], d);
+          ppivot = exact_quo(ppivot, d);
           dppiv = exact_quo(dppiv, d);
         }
       }
-    }
-    bool ovf = dppiv != 1;
-    // ppivot == 1 with room in the first limb: det[0] *= 1
-    if (!ovf && !(ppivot == 1 && log2_64(det[0]) + 1 < 64)) {
-      bool placed = false;
-      const int lp = log2_64(ppivot);
-      for (int i = 0; i < PIPAMD_MAXDET; i++) {
-        if (i >= ldet || placed) break;
-        if (log2_64(det[i]) + lp < 64) {
-          det[i] = wmul(det[i], ppivot);
-          placed = true;
-        }
+      if (!det_step<T>(det0, det1, det2, det3, ldet, ppivot, dppiv)) {
+        J->status = PIPAMD_ST_OVERFLOW;
+        J->npiv = J->npiv - nlog + k + 1;
+        stop = true;
       }
-      if (!placed) {
-        ldet++;
-        if (ldet >= PIPAMD_MAXDET)
-          ovf = true;
-        else {
-          for (int i = 0; i < PIPAMD_MAXDET; i++)  // det[ldet - 1] without a dynamic register index
-            if (i == ldet - 1) det[i] = ppivot;
-        }
-      }
-    }
-    if (ovf) {
-      J->status = PIPAMD_ST_OVERFLOW;
-      J->npiv = J->npiv - nlog + k + 1;
-      stop = true;
-    }
     }
   }
-  for (int i = 0; i < PIPAMD_MAXDET; i++) J->det[i] = det[i];
+  det_limb_store<T>(J, 0, det0);
+  det_limb_store<T>(J, 1, det1);
+  det_limb_store<T>(J, 2, det2);
+  det_limb_store<T>(J, 3, det3);
   J->ldet = ldet;
   J->nlog = 0;
 }
@@ -2475,13 +2401,20 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
   const bool one = waves_per_job == 1;
   const int wp = wp_of(Wmax, ebits);
   hipError_t le = launch_by_shape(a, one, wp, ebits);
-  if (le != hipSuccess || ebits != 64) return le;
-  // the determinant bookkeeping of the pivots just logged, one wave per job
+  if (le != hipSuccess) return le;
+  // the determinant bookkeeping of the pivots just logged
   const int nrep = a.grid > 0 && a.grid < njobs ? a.grid : njobs;
-  if (one)  // behind a bulk launch: fewest instructions
-    hipLaunchKernelGGL(pip_det_replay_lanes_kernel, dim3((nrep + 63) / 64), dim3(64), 0, stream, jobs, arena, njobs, a.q);
-  else  // few jobs, someone is waiting for them: shortest latency
-    hipLaunchKernelGGL(pip_det_replay_kernel, dim3(nrep), dim3(64), 0, stream, jobs, arena, njobs, a.q);
+  if (one) {  // behind a bulk launch: fewest instructions
+    if (ebits == 128)
+      hipLaunchKernelGGL(pip_det_replay_lanes_kernel<i128>, dim3((nrep + 63) / 64), dim3(64), 0, stream, jobs, arena, njobs, a.q);
+    else
+      hipLaunchKernelGGL(pip_det_replay_lanes_kernel<i64>, dim3((nrep + 63) / 64), dim3(64), 0, stream, jobs, arena, njobs, a.q);
+  } else {  // few jobs, someone is waiting for them: shortest latency
+    if (ebits == 128)
+      hipLaunchKernelGGL(pip_det_replay_kernel<i128>, dim3(nrep), dim3(64), 0, stream, jobs, arena, njobs, a.q);
+    else
+      hipLaunchKernelGGL(pip_det_replay_kernel<i64>, dim3(nrep), dim3(64), 0, stream, jobs, arena, njobs, a.q);
+  }
   return hipGetLastError();
 }
 
