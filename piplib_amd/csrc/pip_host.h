@@ -47,7 +47,6 @@ hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long lon
 hipError_t pipk_launch_batch_results(const PipJob *jobs, const long long *arena, int njobs, int nvar, int nparm,
                                      int ebits, int *status, int *pivots, int *cuts, void *sol_num, void *sol_den,
                                      hipStream_t stream);
-hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, int *out2, hipStream_t stream);
 hipError_t pipk_launch_clone(long long *arena, const long long *list, int n, hipStream_t stream);
 hipError_t pipk_launch_patch(long long *arena, const int *buf, const long long *index, int n, hipStream_t stream);
 hipError_t pipk_launch_fresh(long long *arena, const long long *buf, const long long *index, int n, hipStream_t stream);

@@ -2103,17 +2103,6 @@ __global__ void pip_batch_counters_kernel(const PipJob *jobs, int njobs, unsigne
   if (J->status == PIPAMD_ST_SOLUTION || J->status == PIPAMD_ST_NIL) atomicAdd(&out[3], 1ull);
 }
 
-// [0] jobs still PIPAMD_ST_RUN, [1] the largest current row count among them
-__global__ void pip_batch_running_kernel(const PipJob *jobs, int njobs, int *out2) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= njobs) return;
-  const PipJob *J = &jobs[b];
-  if (J->status == PIPAMD_ST_RUN) {
-    atomicAdd(&out2[0], 1);
-    atomicMax(&out2[1], J->ni);
-  }
-}
-
 // ---------------------------------------------------------------- forest helpers
 // Batched host<->device traffic of the lock-step decision-tree scheduler (pip_forest.cpp):
 // one clone pass, one patch pass, one advance launch and one gather pass per step serve every
@@ -2248,13 +2237,6 @@ extern "C" hipError_t pipk_launch_gather(const PipJob *jobs, const i64 *arena, i
 static int wp_of(int Wmax, int ebits) {
   if (ebits == 128) return Wmax <= 64 ? 64 : (Wmax <= 128 ? 128 : (Wmax <= 256 ? 256 : 512));
   return Wmax <= 128 ? 128 : (Wmax <= 256 ? 256 : 512);
-}
-
-extern "C" hipError_t pipk_launch_batch_running(const PipJob *jobs, int njobs, int *out2, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(out2, 0, 2 * sizeof(int), stream);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(pip_batch_running_kernel, dim3((njobs + 255) / 256), dim3(256), 0, stream, jobs, njobs, out2);
-  return hipGetLastError();
 }
 
 extern "C" size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax, int ebits) {
