@@ -135,6 +135,11 @@ class Lanes:
                 e.set_round_pivots(args.round)
             if args.round_rows:
                 e.set_round_rows(args.round_rows)
+            # a lone batch is latency-bound in its tail: eight waves per tableau there (+8 % for one batch
+            # at a time, -3 % with 12 in flight, where the waves of a tail crowd out other batches' bulk)
+            tw = getattr(args, "tail_waves", 0) or (8 if depth == 1 and cfg["ebits"] == 64 and cfg["nvar"] + 1 <= 128 else 0)
+            if tw:
+                e.set_tail_waves(tw)
             e.set_timing(False)  # no HIP events in the timed region (kernel_ms_of switches them on)
             bulk_min = args.bulk_min if args.bulk_min > 0 else (256 if depth > 1 else 0)  # depth = this Lanes' lane count
             if bulk_min:
@@ -250,6 +255,7 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="waves per tableau (0 = engine default)")
     ap.add_argument("--round", type=int, default=0, help="pivot budget per tableau in the bulk launch (0 = engine default)")
     ap.add_argument("--round-rows", type=int, default=0, help="spare rows in the bulk launch's LDS image (0 = engine default)")
+    ap.add_argument("--tail-waves", type=int, default=0, help="waves per tableau in the tail launch (0 = engine default)")
     ap.add_argument("--bulk-min", type=int, default=-1,
                     help="smallest batch that starts with the one-wave bulk launch (-1 = 256 when several batches are "
                          "in flight, the engine default of 2048 otherwise)")

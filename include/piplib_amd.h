@@ -81,8 +81,14 @@ const char *pipamd_last_error(void);
 int pipamd_engine_set_iter_limit(pipamd_engine *e, int pivots_per_launch);
 /* Waves (64 lanes each) that share one tableau: 1 keeps more tableaux in flight per CU (best for
  * large batches of sparse problems), 4 spreads a tableau's rows over four waves (few or dense
- * tableaux); 0 (default) = 1 when the batch has >= 2048 tableaux, else 4. */
+ * tableaux), 8 likewise (64-bit entries of <= 128 columns); 0 (default) = 1 when the batch has >= 2048
+ * tableaux, else 4. */
 int pipamd_engine_set_waves_per_job(pipamd_engine *e, int waves);
+/* Waves per tableau of the tail launch of pipamd_batch_solve (4, the default, or 8).  Eight spread
+ * the 15-25 rows a late pivot of a long tableau rewrites over twice the waves: a caller that runs
+ * one batch at a time gains ~8 %; with many batches in flight the extra waves of a tail crowd out
+ * other batches' bulk launches (-3 %).  64-bit entries of <= 128 columns; 4 otherwise. */
+int pipamd_engine_set_tail_waves(pipamd_engine *e, int waves);
 int pipamd_version(void);
 
 /* ------------------------------------------------------------------ layer 1 */

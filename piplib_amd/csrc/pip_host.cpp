@@ -221,8 +221,8 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
     have_list = true;
     return PIPAMD_OK;
   };
-  const int tail_waves = e->waves_per_job ? e->waves_per_job : 4;
-  if (lay.batch >= (e->bulk_min > 0 ? e->bulk_min : 2048) && e->waves_per_job != 4 && !e->single_launch) {
+  const int tail_waves = e->waves_per_job ? e->waves_per_job : (e->tail_waves ? e->tail_waves : 4);
+  if (lay.batch >= (e->bulk_min > 0 ? e->bulk_min : 2048) && e->waves_per_job != 4 && e->waves_per_job != 8 && !e->single_launch) {
     const int budget = e->iter_limit < K1 ? e->iter_limit : K1;
     rc = launch(1, budget, lay.ni + (KA < budget ? KA : budget), lay.batch);
     if (rc) return rc;
@@ -274,6 +274,12 @@ extern "C" int pipamd_last_launch_ms(pipamd_engine *e, int i, float *ms) {
 extern "C" int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots) {
   if (!e || pivots < 1) return PIPAMD_E_INVALID;
   e->round_pivots = pivots;
+  return PIPAMD_OK;
+}
+
+extern "C" int pipamd_engine_set_tail_waves(pipamd_engine *e, int waves) {
+  if (!e || (waves != 4 && waves != 8)) return PIPAMD_E_INVALID;
+  e->tail_waves = waves;
   return PIPAMD_OK;
 }
 
@@ -333,7 +339,7 @@ extern "C" int pipamd_debug_profile(pipamd_engine *e, int enable, uint64_t *host
 }
 
 extern "C" int pipamd_engine_set_waves_per_job(pipamd_engine *e, int waves) {
-  if (!e || (waves != 0 && waves != 1 && waves != 4)) return PIPAMD_E_INVALID;
+  if (!e || (waves != 0 && waves != 1 && waves != 4 && waves != 8)) return PIPAMD_E_INVALID;
   e->waves_per_job = waves;
   return PIPAMD_OK;
 }

@@ -24,6 +24,7 @@ struct pipamd_engine {
   int q_cap;         /* jobs the lists hold */
   int iter_limit;
   int waves_per_job; /* 0 = choose by batch size */
+  int tail_waves;    /* waves per tableau of the tail launch when waves_per_job is 0 (0 = default 4) */
   unsigned long long *d_prof; /* diagnostic builds only (-DPIP_PROFILE) */
   void *d_scratch;
   size_t scratch_bytes;

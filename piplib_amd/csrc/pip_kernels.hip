@@ -2262,6 +2262,7 @@ struct AdvanceLaunch {
   i64 *arena;
   int njobs, Lmax, Smax, Wmax, iter_limit;
   PipQueue q;
+  int waves; // waves per job: 1, 4 or 8 (8: 64-bit entries of <= 128 columns only, else 4)
   int grid;  // workgroups = upper bound on the entries of the input list (0: njobs)
   bool full; // every job: no parameters, no big parameter, nvar + 1 == W == 128 (see FULL)
   unsigned long long *prof;
@@ -2319,6 +2320,11 @@ static hipError_t launch_advance_w(bool one, const AdvanceLaunch &a) {
     }
 #endif
   }
+  if constexpr (sizeof(T) == 8 && NCH == 1) {
+    // eight waves per job: the rows of a late pivot of a long tableau (15-25 of them change) are
+    // spread over twice the waves -- for the few tableaux of a tail launch
+    if (a.waves == 8) return launch_advance_t<T, NCH, 8, false, 0>(a);
+  }
   return one ? launch_advance_t<T, NCH, 1, false, 0>(a) : launch_advance_t<T, NCH, 4, false, 0>(a);
 }
 
@@ -2358,6 +2364,7 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
     a.grid = grid;
   }
   a.prof = prof;
+  a.waves = waves_per_job;
   a.full = (hints & 1) != 0;
   a.shm = pipk_advance_lds_bytes(Lmax, Smax, Wmax, ebits);
   a.gimg = nullptr;

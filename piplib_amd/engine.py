@@ -82,6 +82,10 @@ class Engine:
         lib().pipamd_engine_set_bulk_min.argtypes = [C.c_void_p, C.c_int]
         _check(lib().pipamd_engine_set_bulk_min(self._h, int(n)))
 
+    def set_tail_waves(self, n):
+        lib().pipamd_engine_set_tail_waves.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().pipamd_engine_set_tail_waves(self._h, int(n)))
+
     def set_timing(self, on):
         lib().pipamd_engine_set_timing.argtypes = [C.c_void_p, C.c_int]
         _check(lib().pipamd_engine_set_timing(self._h, int(bool(on))))

@@ -302,7 +302,7 @@ def test_many_parametric_problems_multithreaded():
 
 @pytest.mark.parametrize("seed", [51, 52, 53])
 def test_engine_variants_agree(seed):
-    """One batch through every engine configuration -- 1 or 4 waves per tableau, short rounds,
+    """One batch through every engine configuration -- 1, 4 or 8 waves per tableau, short rounds,
     row skipping off, 128-bit entries -- must give bit-identical statuses, pivot counts and
     solutions (and match the oracle, checked on the first configuration)."""
     import numpy as np
@@ -315,7 +315,8 @@ def test_engine_variants_agree(seed):
     rows = synth.lexmin_batch(seed, 40, nvar, ni, nnz=int(rng.integers(2, 6)), cmax=int(rng.integers(2, 9)))
     nq = int(seed % 2 == 1)
     outs = []
-    for waves, rnd, extra, bits in [(4, 0, 0, 64), (1, 0, 0, 64), (1, 5, 0, 64), (4, 3, eng.T_NOSKIP, 64), (4, 0, 0, 128)]:
+    for waves, rnd, extra, bits in [(4, 0, 0, 64), (1, 0, 0, 64), (1, 5, 0, 64), (4, 3, eng.T_NOSKIP, 64), (4, 0, 0, 128),
+                                    (8, 0, 0, 64)]:
         e = eng.Engine(0)
         e.set_waves_per_job(waves)
         if rnd:
