@@ -137,7 +137,8 @@ class Lanes:
                 e.set_round_rows(args.round_rows)
             # a lone batch is latency-bound in its tail: eight waves per tableau there (+8 % for one batch
             # at a time, -3 % with 12 in flight, where the waves of a tail crowd out other batches' bulk)
-            tw = getattr(args, "tail_waves", 0) or (8 if depth == 1 and cfg["ebits"] == 64 and cfg["nvar"] + 1 <= 128 else 0)
+            tw = getattr(args, "tail_waves", 0) or (8 if depth == 1 and cfg["ebits"] == 64 and cfg["nvar"] + 1 <= 128
+                                                    and cfg["batch"] >= 2048 else 0)
             if tw:
                 e.set_tail_waves(tw)
             e.set_timing(False)  # no HIP events in the timed region (kernel_ms_of switches them on)
@@ -439,8 +440,8 @@ def main():
         torch.cuda.empty_cache()
         others = []
         for oc in OTHERS:
-            # a 1k-tableau batch is a fraction of a millisecond of GPU work: twice the lanes keep the GPU fed
-            od = args.pipeline * (2 if oc["batch"] < 4096 else 1)
+            # a 1k batch of small tableaux is a tenth of a millisecond of GPU work: twice the lanes keep the GPU fed
+            od = args.pipeline * (2 if oc["batch"] < 4096 and oc["nvar"] < 128 else 1)
             ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args)
             osteps = 16 * od
             odt, osh = timed(ol, osteps, od, barrier, args.stagger)
