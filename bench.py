@@ -444,7 +444,9 @@ def main():
             od = args.pipeline * (2 if oc["batch"] < 4096 and oc["nvar"] < 128 else 1)
             ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args)
             osteps = 16 * od
-            odt, osh = timed(ol, osteps, od, barrier, args.stagger)
+            # 16 steps per lane: long enough for the lanes to start a fraction of a step apart (their tails
+            # then fall into other lanes' bulk phases; it costs the short headline runs more than it gives)
+            odt, osh = timed(ol, osteps, od, barrier, args.stagger if args.stagger != 0 else -1.0)
             ot = ol.totals(osh)
             oe, ob, _ = ol.lanes[0]
             okm = kernel_ms_of(ob)
