@@ -97,7 +97,7 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
                               : (lay->W <= 128 ? 128 : (lay->W <= 256 ? 256 : 512));
   const int nm = wp / 64;
   // saved summaries, then the determinant log of the last launch (64-bit jobs)
-  const int64_t state = round_even(lay->S * nm + (3 * lay->L + 7) / 8) + 2 * PIPAMD_DETLOG;
+  const int64_t state = round_even(lay->S * nm + (3 * lay->L + 7) / 8) + 2 * PIPAMD_DETLOG * ew;
   lay->sol_words = (int32_t)sol;
   lay->state_words = (int32_t)state;
   // rows: den[L] (entry type) | flag[L] | ref[L];  then S x W entries;  solution;  saved summaries

@@ -17,8 +17,7 @@
 #define PIPAMD_LDS_BUDGET (160 * 1024 - 1024) /* dynamic LDS a workgroup can get */
 /* The pivot kernel does not run the determinant bookkeeping of traiter.c:412-446 itself
  * (wave-uniform scalar work, ~12 % of its instructions with 64-bit entries); it logs (pivot,
- * denominator of the pivot row) per pivot -- at most this many per launch with 64-bit entries,
- * half as many with 128-bit ones -- and pip_det_replay_kernel replays
+ * denominator of the pivot row) per pivot -- at most this many per launch -- and pip_det_replay_kernel replays
  * the log right after the launch, one wave per job: the gcds of 64 pivots at a time on the lanes,
  * only the walk over the limbs sequentially. */
 #define PIPAMD_DETLOG 512
@@ -32,7 +31,7 @@
  * Mirrors the reference's struct T / struct L (tab.h:36-85) without pointers. */
 typedef struct PipJob {
   int64_t vals_off, rows_off, sol_off, state_off;
-  int64_t log_off; /* 2 * PIPAMD_DETLOG int64: the determinant log of the last launch */
+  int64_t log_off; /* 2 * PIPAMD_DETLOG entries: the determinant log of the last launch */
   int32_t nvar, nparm, ni, bigparm;
   int32_t tflags;
   int32_t L, S, W;

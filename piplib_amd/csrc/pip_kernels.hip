@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   // denominator of the pivot row) to the job's log, the pip_det_replay kernels run the bookkeeping
   // and its "Integer overflow" tests after the launch
   T *g_log = (T *)(arena + J->log_off);
-  constexpr int LOGCAP = PIPAMD_DETLOG / ET<T>::EW;  // the log area holds 512 pairs of 64-bit or 256 of 128-bit values
+  constexpr int LOGCAP = PIPAMD_DETLOG;  // pairs the log area holds
   int nlog = J->nlog;
   if (ni > Smax || nligne > Lmax) {  // this launch's LDS image is too small: stay RUN for a larger one
     if (tid == 0 && q.out_count) {
@@ -2049,7 +2049,7 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
     J->vals_off = base + rows_words;
     J->sol_off = J->vals_off + (int64_t)lay.S * lay.W * EW;
     J->state_off = J->sol_off + lay.sol_words;
-    J->log_off = J->state_off + lay.state_words - 2 * PIPAMD_DETLOG;
+    J->log_off = J->state_off + lay.state_words - 2 * PIPAMD_DETLOG * EW;
     J->nlog = 0;
     J->nvar = lay.nvar;
     J->nparm = lay.nparm;

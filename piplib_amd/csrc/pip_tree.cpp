@@ -319,7 +319,7 @@ class TreeT {
     const int L = even(nvar + S);
     const int nm = 8;  // room for the bitmaps of any launch geometry (jobs of mixed widths share launches)
     const size_t sol = (size_t)even(nvar * (W - nvar) + nvar) * EW;
-    const size_t state = (size_t)even(S * nm + (3 * L + 7) / 8) + 2 * PIPAMD_DETLOG;  // summaries | determinant log
+    const size_t state = (size_t)even(S * nm + (3 * L + 7) / 8) + 2 * PIPAMD_DETLOG * EW;  // summaries | determinant log
     // den[L] (entries) | flag[L] | ref[L], then S x W entries, the solution, the saved summaries
     j.block_words = (size_t)(EW + 1) * L + (size_t)S * W * EW + sol + state;
     ensure_arena(top_ + j.block_words);
@@ -329,7 +329,7 @@ class TreeT {
     j.pj.vals_off = j.block_off + (i64)(EW + 1) * L;
     j.pj.sol_off = j.pj.vals_off + (i64)S * W * EW;
     j.pj.state_off = j.pj.sol_off + (i64)sol;
-    j.pj.log_off = j.pj.state_off + (i64)state - 2 * PIPAMD_DETLOG;
+    j.pj.log_off = j.pj.state_off + (i64)state - 2 * PIPAMD_DETLOG * EW;
     j.pj.nvar = nvar;
     j.pj.nparm = nparm;
     j.pj.ni = ni;
