@@ -240,6 +240,16 @@ int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *problem
 int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
                                    int deepest_cut, pipamd_sol_cell **cells, size_t *n_cells, int *rcs,
                                    int *statuses, int64_t *pivots);
+/* Small problems (at most 64 columns and 64 inequalities, spare room for cuts and new parameters
+ * included) are first given to the device-resident traiter() (csrc/pip_quast.hip): one wave per
+ * problem runs the whole call tree -- pivots, compa_test sub-problems (traiter.c:162-243), forks of the
+ * quast (traiter.c:695-759), cuts with new parameters (integrer.c:156-291) -- and writes the tape, with
+ * no host round trip.  A problem in which a 64-bit operation would overflow, or that outgrows its
+ * reserved rows, is handed back and served by the lock-step scheduler / the per-problem tree, which
+ * reproduce the reference's wrap-around and "Integer overflow" behaviour.  On by default;
+ * pipamd_last_device_tree reports how many problems of the last call each side served. */
+int pipamd_engine_set_device_tree(pipamd_engine *e, int on);
+int pipamd_last_device_tree(const pipamd_engine *e, int *served, int *handed_back);
 
 #ifdef __cplusplus
 }

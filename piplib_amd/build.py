@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpipamd.so")
-SOURCES = ["pip_kernels.hip", "pip_host.cpp", "pip_tree.cpp"]
-HEADERS = ["pip_job.h", "pip_host.h", os.path.join("..", "..", "include", "piplib_amd.h")]
+SOURCES = ["pip_kernels.hip", "pip_quast.hip", "pip_host.cpp", "pip_tree.cpp"]
+HEADERS = ["pip_job.h", "pip_host.h", "pip_quast.h", os.path.join("..", "..", "include", "piplib_amd.h")]
 
 
 def needs_build():

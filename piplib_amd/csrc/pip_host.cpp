@@ -283,6 +283,18 @@ extern "C" int pipamd_engine_set_tail_waves(pipamd_engine *e, int waves) {
   return PIPAMD_OK;
 }
 
+extern "C" int pipamd_engine_set_device_tree(pipamd_engine *e, int on) {
+  if (!e) return PIPAMD_E_INVALID;
+  e->no_device_tree = on ? 0 : 1;
+  return PIPAMD_OK;
+}
+extern "C" int pipamd_last_device_tree(const pipamd_engine *e, int *served, int *handed_back) {
+  if (!e) return PIPAMD_E_INVALID;
+  if (served) *served = e->dt_served;
+  if (handed_back) *handed_back = e->dt_fallback;
+  return PIPAMD_OK;
+}
+
 extern "C" int pipamd_engine_set_bulk_min(pipamd_engine *e, int tableaux) {
   if (!e || tableaux < 1) return PIPAMD_E_INVALID;
   e->bulk_min = tableaux;

@@ -1,0 +1,41 @@
+// piplib_amd/csrc/pip_quast.h -- the device-resident traiter() of pip_quast.hip: launch interface.
+#ifndef PIP_QUAST_H
+#define PIP_QUAST_H
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// one problem: its rows sit at input[in_off]: ni x (nvar+nparm+1) inequalities, then nc x (nparm+1) context rows
+struct QProb {
+  long long in_off;
+  int nvar, nparm, ni, nc, bigparm, nq;
+};
+// capacities of one launch (every problem of the launch gets the same LDS image and HBM regions)
+struct QCaps {
+  int R, S, W;    // main tableau: logical rows, real-row slots, columns (W <= 64, S <= 64)
+  int CR, CW;     // context: rows, columns (parameters | constant)
+  int SR, SS;     // compa_test sub-problems: logical rows, real-row slots (their width is CW)
+  int depth;      // frames of the fork stack
+  int cells;      // tape cells
+  int deepest;    // deepest-cut option (integrer.c:417-438)
+};
+// out[Q_OUT*i]: result; +1: cells; +2: pivots; +3: why a problem was handed back (Q_WHY_* bits);
+// +4: run time of the problem's wave in 10 ns units; +5: cells written when it stopped
+enum { Q_DONE = 0, Q_VOID = 1, Q_FALLBACK = 2 };
+enum { Q_OUT = 10 };  // +6..+9: diagnostics (clock ticks / 16: main pivots, compa sub-problems, sorts, total)
+enum {
+  Q_WHY_OVERFLOW = 1,  // a 64-bit product / sum overflowed, or the determinant did ("Integer overflow")
+  Q_WHY_ROWS = 2,      // rows, columns or context rows reserved for the problem ran out
+  Q_WHY_TAPE = 4,      // SOL_SIZE cells
+  Q_WHY_STACK = 8,     // fork depth
+  Q_WHY_OTHER = 16     // too many parameters, iteration guard, assert(ok_var), ...
+};
+
+extern "C" {
+size_t pipk_quast_lds_bytes(const QCaps *c);
+size_t pipk_quast_frame_words(const QCaps *c);
+hipError_t pipk_launch_quast(const QProb *probs, const long long *input, long long *stack, long long *cells, int *out,
+                             int nprob, const QCaps *cap, hipStream_t stream);
+hipError_t pipk_launch_quast_pack(const long long *cells, const long long *off, long long *packed, int nprob,
+                                  int cells_cap, hipStream_t stream);
+}
+#endif

@@ -1,0 +1,1066 @@
+// piplib_amd/csrc/pip_quast.hip -- traiter() with its quast decision tree on the device, for SMALL
+// parametric problems (at most 64 columns and 64 real rows).
+//
+// One wave64 per problem runs the whole call tree of traiter() (traiter.c:628-791) without a host
+// round trip: the dual simplex with lexicographic pivoting (pivoter, traiter.c:345-548), exam_coef
+// (traiter.c:101-159), compa_test with its two integer feasibility sub-problems per undecided row
+// (traiter.c:162-243), the forks of the quast (traiter.c:695-759; the "else" state waits on a stack in
+// HBM while the "then" branch runs), Gomory cuts with new parameters (integrer.c:156-291,305-534)
+// and the solution tape (sol.c:104-209).  Lane j owns column j of the tableau, which lives in LDS.
+//
+// The kernel computes on true integers: every product and sum is checked, and a problem in which a
+// 64-bit operation overflows (where the reference's `long long` build wraps or exits with "Integer
+// overflow"), or that outgrows the reserved rows / columns / stack / tape, ends with Q_FALLBACK and
+// is solved again by the host tree over pip_advance_kernel, which reproduces those cases bit for
+// bit.  Whatever this kernel does finish is, cell for cell, the reference's tape.
+#include <hip/hip_runtime.h>
+
+#include "pip_job.h"
+#include "pip_quast.h"
+
+namespace {
+typedef long long i64;
+typedef unsigned long long u64;
+
+enum { F_UNIT = 1, F_PLUS = 2, F_MINUS = 4, F_ZERO = 8, F_CRITIC = 16, F_UNKNOWN = 32 };
+enum { C_NIL = 1, C_IF = 2, C_LIST = 3, C_FORM = 4, C_NEW = 5, C_DIV = 6, C_VAL = 7 };
+enum { MAXDET = 4 };  // tab.h:67
+
+// one tableau in LDS: logical rows (unit row on column `ref`, or real row in slot `ref`)
+struct Tab {
+  i64 *den;   // [rows]
+  i64 *val;   // [slots][W]
+  int *flag;  // [rows]
+  int *ref;   // [rows]
+  int *ldet;  // -> number of determinant limbs in use
+  i64 *det;   // -> MAXDET limbs
+  int W, rows_cap, slots_cap;
+};
+
+struct Wv {
+  long long t_piv = 0, t_sub = 0, t_sort = 0, t_build = 0;  // diagnostics: clock64 ticks per phase
+  int lane;
+  int bad;  // sticky: an overflow or a capacity limit was hit (uniform when tested)
+  int pivots;
+  int deepest;
+};
+
+// scalars of the main tableau that travel with a stack frame
+struct QState {
+  int nvar, nparm, ni, nc, pivi, ldet, pad0, pad1;
+  i64 det[MAXDET];
+};
+
+#define BAD(w) (__any((w).bad) != 0)
+__device__ __forceinline__ void wsync() { __syncthreads(); }  // one wave per workgroup: orders its LDS traffic
+__device__ __forceinline__ i64 bcast(i64 x, int src) { return __shfl(x, src); }
+__device__ __forceinline__ int popc64(u64 m) { return __popcll(m); }
+__device__ __forceinline__ int first64(u64 m) { return __ffsll((long long)m) - 1; }
+
+__device__ __forceinline__ i64 cmul(i64 a, i64 b, int &bad) {
+  i64 r;
+  bad |= __builtin_mul_overflow(a, b, &r);
+  return r;
+}
+__device__ __forceinline__ i64 cadd(i64 a, i64 b, int &bad) {
+  i64 r;
+  bad |= __builtin_add_overflow(a, b, &r);
+  return r;
+}
+__device__ __forceinline__ i64 csub(i64 a, i64 b, int &bad) {
+  i64 r;
+  bad |= __builtin_sub_overflow(a, b, &r);
+  return r;
+}
+__device__ __forceinline__ i64 cneg(i64 a, int &bad) { return csub(0, a, bad); }
+__device__ __forceinline__ u64 uabs(i64 a) { return a < 0 ? 0ull - (u64)a : (u64)a; }
+__device__ __forceinline__ u64 umod(u64 a, u64 b) {
+  return ((a | b) >> 32) ? a % b : (u64)((unsigned)a % (unsigned)b);
+}
+__device__ __forceinline__ u64 udiv(u64 a, u64 b) {
+  return ((a | b) >> 32) ? a / b : (u64)((unsigned)a / (unsigned)b);
+}
+// integrer.c:43-50 on true integers: gcd(|a|, |b|)
+__device__ __forceinline__ i64 gcd64(i64 a, i64 b) {
+  u64 x = uabs(a), y = uabs(b);
+  if (x == 1 || y == 1) return 1;
+  while (y) {
+    const u64 t = umod(x, y);
+    x = y;
+    y = t;
+  }
+  return (i64)x;
+}
+// C '/' and '%' (truncating) for a non-zero divisor
+__device__ __forceinline__ i64 quo(i64 a, i64 b) {
+  const u64 q = udiv(uabs(a), uabs(b));
+  return ((a < 0) != (b < 0)) ? -(i64)q : (i64)q;
+}
+__device__ __forceinline__ i64 rem(i64 a, i64 b) {
+  const u64 r = umod(uabs(a), uabs(b));
+  return a < 0 ? -(i64)r : (i64)r;
+}
+// integrer.c:69-74: remainder in [0, |b|)
+__device__ __forceinline__ i64 pmod(i64 a, i64 b) {
+  i64 m = rem(a, b);
+  if (m < 0) m += (i64)uabs(b);
+  return m;
+}
+// piplib.h:147-149
+__device__ __forceinline__ i64 floordiv(i64 a, i64 b, int &bad) { return quo(csub(a, pmod(a, b), bad), b); }
+// integrer.c:51-59: bit length of |x|, 1 for 0
+__device__ __forceinline__ int blen(i64 x) {
+  const u64 u = uabs(x);
+  return u ? 64 - __clzll((long long)u) : 1;
+}
+__device__ __forceinline__ int sgn_flag(i64 x) { return x < 0 ? F_MINUS : (x > 0 ? F_PLUS : F_ZERO); }
+
+__device__ __forceinline__ int wave_max_i(int x) {
+  for (int o = 32; o; o >>= 1) {
+    const int y = __shfl_xor(x, o);
+    x = x > y ? x : y;
+  }
+  return x;
+}
+__device__ __forceinline__ float wave_min_f(float x) {
+  for (int o = 32; o; o >>= 1) {
+    const float y = __shfl_xor(x, o);
+    x = x < y ? x : y;
+  }
+  return x;
+}
+
+// value of logical row k in column `lane` (traiter.c:246-252 valeur); 0 beyond ncol
+__device__ __forceinline__ i64 row_at(const Tab &t, int k, int lane, int ncol) {
+  const int fl = t.flag[k], rf = t.ref[k];
+  if (fl & F_UNIT) return rf == lane ? t.den[k] : 0;
+  return lane < ncol ? t.val[rf * t.W + lane] : 0;
+}
+
+// traiter.c:39-44 chercher: first row among 0..n-1 whose flag meets `mask`, n if none
+__device__ __forceinline__ int first_flagged(const Tab &t, int mask, int n, int lane) {
+  for (int base = 0; base < n; base += 64) {
+    const int k = base + lane;
+    const u64 m = __ballot(k < n && (t.flag[k] & mask));
+    if (m) return base + first64(m);
+  }
+  return n;
+}
+
+// traiter.c:101-159 exam_coef: obvious signs of Unknown rows; stops at the first row proven negative
+__device__ int classify_rows(Tab &t, int nvar, int ncol, int bigparm, int nligne, int lane) {
+  if (bigparm >= 0) {
+    for (int base = 0; base < nligne; base += 64) {
+      const int k = base + lane;
+      int s = 0;
+      if (k < nligne && t.flag[k] == F_UNKNOWN) {
+        const i64 v = t.val[t.ref[k] * t.W + bigparm];
+        s = v < 0 ? -1 : (v > 0 ? 1 : 0);
+      }
+      const u64 neg = __ballot(s < 0);
+      const int stop = neg ? first64(neg) : 64;
+      if (s > 0 && lane < stop) t.flag[k] = F_PLUS;
+      if (neg) {
+        if (lane == stop) t.flag[k] = F_MINUS;
+        wsync();
+        return base + stop;
+      }
+    }
+    wsync();
+  }
+  for (int base = 0; base < nligne; base += 64) {
+    const int k = base + lane;
+    int nf = 0;
+    if (k < nligne && t.flag[k] == F_UNKNOWN) {
+      const i64 *r = t.val + t.ref[k] * t.W;
+      int ff = F_ZERO;
+      for (int j = nvar + 1; j < ncol; j++) {
+        const int fj = sgn_flag(r[j]);
+        if (fj != F_ZERO && fj != ff) {
+          if (ff == F_ZERO)
+            ff = fj;
+          else {
+            ff = F_UNKNOWN;
+            break;
+          }
+        }
+      }
+      const int fc = sgn_flag(r[nvar]);  // constant term, traiter.c:138-140
+      if (ff == F_PLUS) {
+        if (fc == F_MINUS) ff = F_UNKNOWN;
+      } else if (ff == F_ZERO) {
+        ff = fc;
+      } else if (ff == F_MINUS) {
+        if (fc != F_MINUS) ff = F_UNKNOWN;
+      }
+      nf = ff;
+    }
+    const u64 neg = __ballot(nf == F_MINUS);
+    const int stop = neg ? first64(neg) : 64;
+    if (nf && lane <= stop) t.flag[k] = nf;
+    if (neg) {
+      wsync();
+      return base + stop;
+    }
+  }
+  wsync();
+  return nligne;
+}
+
+// traiter.c:556-623 tab_sort_rows: selection sort of the real rows nvar..nligne-1 by
+// max |trunc(coefficient / denominator)| over the unknowns (float keys, the reference's types)
+__device__ __forceinline__ int trunc_x86(double t) {
+  return (!(t > -2147483649.0 && t < 2147483648.0)) ? (int)0x80000000 : (int)t;
+}
+__device__ void sort_rows(Tab &t, int nvar, int nligne, float *key, Wv &w) {
+  const int lane = w.lane;
+  const int n = nligne - nvar;  // rows to sort: at most 64 + the unit rows among them
+  if (n > 64) {
+    w.bad |= Q_WHY_ROWS;
+    return;
+  }
+  const int k = nvar + lane;
+  bool real = false;
+  int s = 0;
+  if (lane < n && !(t.flag[k] & F_UNIT)) {
+    real = true;
+    const i64 *r = t.val + t.ref[k] * t.W;
+    const double d = (double)t.den[k];
+    for (int j = 0; j < nvar; j++) {
+      const int q = trunc_x86((double)r[j] / d);
+      const int a = q < 0 ? (int)(0u - (unsigned)q) : q;  // abs() incl. INT_MIN
+      s = s > a ? s : a;  // (double)INT_MIN never wins against s >= 0
+    }
+  }
+  const double smax = (double)wave_max_i(s);
+  if (!__ballot(real && (double)(float)(double)s < smax)) return;  // no key below the maximum: no row moves
+  key[lane] = real ? (float)(double)s : -1.0f;                     // -1: a unit row (skipped)
+  wsync();
+  for (int i = 0; i < n; i++) {
+    const float ki = key[i];
+    if (ki < 0) continue;
+    const float mine = key[lane];
+    const bool cand = lane >= i && lane < n && mine >= 0 && (double)mine < smax;
+    if (!__ballot(cand)) continue;  // nothing below smax: pivi stays i (and every later pass too, but cheap)
+    const float m = wave_min_f(cand ? mine : 3.0e38f);
+    const int p = first64(__ballot(cand && mine == m));
+    if (p != i) {
+      if (lane == 0) {
+        const int a = nvar + i, b = nvar + p;
+        const int f = t.flag[a], r = t.ref[a];
+        const i64 d = t.den[a];
+        t.flag[a] = t.flag[b];
+        t.ref[a] = t.ref[b];
+        t.den[a] = t.den[b];
+        t.flag[b] = f;
+        t.ref[b] = r;
+        t.den[b] = d;
+        key[i] = m;
+        key[p] = ki;
+      }
+      wsync();
+    }
+  }
+}
+
+// traiter.c:345-548 pivoter (with choisir_piv, traiter.c:297-341, as a tournament over the rows);
+// returns -1 when the pivot row has no positive entry among the unknowns
+__device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &w) {
+  const int lane = w.lane, W = t.W;
+  w.pivots++;
+  const int pslot = t.ref[pivi];
+  const i64 p = lane < ncol ? t.val[pslot * W + lane] : 0;
+  u64 tied = __ballot(lane < nvar && p > 0);
+  if (!tied) return -1;
+  for (int k = 0; k < nligne && popc64(tied) > 1; k++) {
+    const int fl = t.flag[k], rf = t.ref[k];
+    if (fl & F_UNIT) {  // its own column has the only positive ratio there: every other tied column is smaller
+      tied &= ~(1ull << rf);
+      continue;
+    }
+    const i64 v = lane < ncol ? t.val[rf * W + lane] : 0;
+    const bool in = (tied >> lane) & 1;
+    if (!__ballot(in && v != 0)) continue;
+    int c = first64(tied);
+    for (;;) {
+      const i64 pc = bcast(p, c), vc = bcast(v, c);
+      const i64 x = csub(cmul(pc, v, w.bad), cmul(vc, p, w.bad), w.bad);
+      const u64 less = __ballot(in && x < 0);
+      if (!less) {
+        tied = __ballot(in && x == 0);
+        break;
+      }
+      c = first64(less);
+    }
+  }
+  const int pivj = first64(tied);
+  const i64 pivot = bcast(p, pivj), dpiv = t.den[pivi];
+  {  // the determinant in limbs, traiter.c:412-446 (uniform values; lane 0 publishes them)
+    i64 d = gcd64(pivot, dpiv);
+    const i64 ppivot = quo(pivot, d);
+    i64 dppiv = quo(dpiv, d);
+    int ldet = *t.ldet;
+    i64 dt[MAXDET];
+#pragma unroll
+    for (int i = 0; i < MAXDET; i++) dt[i] = t.det[i];
+#pragma unroll
+    for (int i = 0; i < MAXDET; i++)
+      if (i < ldet) {
+        d = gcd64(dt[i], dppiv);
+        dt[i] = quo(dt[i], d);
+        dppiv = quo(dppiv, d);
+      }
+    if (dppiv != 1) w.bad |= Q_WHY_OVERFLOW;  // "Integer overflow", traiter.c:424
+    bool placed = false;
+#pragma unroll
+    for (int i = 0; i < MAXDET; i++)
+      if (!placed && i < ldet && blen(dt[i]) + blen(ppivot) < 64) {
+        dt[i] *= ppivot;
+        placed = true;
+      }
+    if (!placed) {
+      if (ldet + 1 >= MAXDET) {
+        w.bad |= Q_WHY_OVERFLOW;  // traiter.c:442
+      } else {
+#pragma unroll
+        for (int i = 0; i < MAXDET; i++)
+          if (i == ldet) dt[i] = ppivot;
+        ldet++;
+      }
+    }
+    wsync();
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < MAXDET; i++) t.det[i] = dt[i];
+      *t.ldet = ldet;
+    }
+    wsync();
+    if (BAD(w)) return 0;
+  }
+  // eliminate column pivj from every other real row, traiter.c:467-502.  Lane k first works out row k's
+  // multipliers (all rows at once), then the rows that change are rewritten one by one, a column per lane.
+  for (int base = 0; base < nligne; base += 64) {
+    const int k = base + lane;
+    bool need = false;
+    i64 lpiv = 1, fo = 0, g = 1;
+    int rf = 0;
+    if (k < nligne && k != pivi && !(t.flag[k] & F_UNIT)) {
+      rf = t.ref[k];
+      const i64 foo = t.val[rf * W + pivj], oden = t.den[k];
+      if (foo != 0 || oden != 1) {  // else: multipliers (1, 0) and g = 1, the row keeps its bits
+        need = true;
+        const i64 d = gcd64(pivot, foo);
+        lpiv = quo(pivot, d);
+        fo = quo(foo, d);
+        g = cmul(lpiv, oden, w.bad);
+      }
+    }
+    u64 todo = __ballot(need);
+    while (todo) {
+      const int src = first64(todo);
+      todo &= todo - 1;
+      const int rfk = __shfl(rf, src);
+      const i64 lp = bcast(lpiv, src), ff = bcast(fo, src), gg = bcast(g, src);
+      const i64 v = lane < ncol ? t.val[rfk * W + lane] : 0;
+      i64 z = lane == pivj ? cmul(dpiv, ff, w.bad) : csub(cmul(v, lp, w.bad), cmul(p, ff, w.bad), w.bad);
+      if (lane >= ncol) z = 0;
+      i64 nden = gg;
+      if (gg != 1) {  // gcd of g and the whole row: fold in one non-zero remainder at a time
+        u64 G = uabs(gg);
+        for (;;) {
+          const u64 r = umod(uabs(z), G);
+          const u64 m = __ballot(r != 0);
+          if (!m) break;
+          G = (u64)gcd64((i64)G, bcast((i64)r, first64(m)));
+          if (G == 1) break;
+        }
+        if (G != 1) {
+          z = quo(z, (i64)G);
+          nden = quo(gg, (i64)G);
+        }
+      }
+      if (lane < ncol) t.val[rfk * W + lane] = z;
+      if (lane == 0) t.den[base + src] = nden;
+    }
+    wsync();
+  }
+  // swap roles, traiter.c:503-516: the unit row of pivj becomes real (in the pivot row's slot)
+  int ku = -1;
+  for (int base = 0; base < nligne; base += 64) {
+    const int k = base + lane;
+    const u64 m = __ballot(k < nligne && (t.flag[k] & F_UNIT) && t.ref[k] == pivj);
+    if (m) {
+      ku = base + first64(m);
+      break;
+    }
+  }
+  if (ku < 0) {
+    w.bad |= Q_WHY_OTHER;
+    return 0;
+  }
+  if (lane < ncol) t.val[pslot * W + lane] = lane == pivj ? dpiv : cneg(p, w.bad);
+  if (lane == 0) {
+    t.flag[ku] = F_PLUS;
+    t.ref[ku] = pslot;
+    t.den[ku] = pivot;
+    t.flag[pivi] = F_UNIT | F_ZERO;
+    t.den[pivi] = 1;
+    t.ref[pivi] = pivj;
+  }
+  wsync();
+  // sign hints after the pivot, traiter.c:518-529
+  for (int base = 0; base < nligne; base += 64) {
+    const int k = base + lane;
+    if (k < nligne) {
+      int ff = t.flag[k];
+      if (!(ff & F_UNIT)) {
+        const int fff = sgn_flag(t.val[t.ref[k] * W + pivj]);
+        if (fff != F_ZERO && fff != ff) {
+          ff = ff == F_ZERO ? (fff == F_MINUS ? F_UNKNOWN : fff) : F_UNKNOWN;
+          t.flag[k] = ff;
+        }
+      }
+    }
+  }
+  wsync();
+  return 0;
+}
+
+// integrer.c:98-150 bezout
+__device__ i64 bezout(i64 x, i64 y, i64 delta, int &bad) {
+  i64 a = 1, b = 0, c = 0, d = 1, u = y, v = delta;
+  for (int guard = 0; guard < 200; guard++) {
+    const i64 q = floordiv(u, v, bad), r = pmod(u, v);
+    if (r == 0) break;
+    u = v;
+    v = r;
+    const i64 e = csub(a, cmul(q, c, bad), bad), f = csub(b, cmul(q, d, bad), bad);
+    a = c;
+    b = d;
+    c = e;
+    d = f;
+  }
+  if (v != 1) return 0;
+  return pmod(cmul(c, x, bad), delta);
+}
+
+// the cut of row i (integrer.c:342-400), one column per lane
+struct Cut {
+  i64 c;
+  bool ok_var, ok_const, ok_parm;
+};
+__device__ __forceinline__ Cut make_cut(const Tab &t, int i, int nvar, int ncol, int bigparm, int lane) {
+  Cut q;
+  const i64 D = t.den[i];
+  const i64 v = lane < ncol ? t.val[t.ref[i] * t.W + lane] : 0;
+  i64 c = 0;
+  if (lane < nvar)
+    c = pmod(v, D);
+  else if (lane < ncol && lane != bigparm)  // the big parameter is a multiple of everything
+    c = -pmod(-v, D);
+  q.c = c;
+  q.ok_var = __ballot(lane < nvar && c > 0) != 0;
+  q.ok_const = bcast(c, nvar) != 0;
+  q.ok_parm = __ballot(lane > nvar && lane < ncol && c != 0) != 0;
+  return q;
+}
+
+// deepest cut, integrer.c:417-438 (constant cuts only)
+__device__ __forceinline__ i64 deepen(i64 c, i64 D, int nvar, int lane, Wv &w) {
+  const i64 cst = bcast(c, nvar);
+  i64 tt = -cst;
+  const i64 delta = gcd64(tt, D), tau = quo(tt, delta), dd = quo(D, delta);
+  tt = dd - 1;
+  i64 lambda = bezout(tt, tau, dd, w.bad);
+  tt = gcd64(lambda, D);
+  for (int guard = 0; tt != 1 && guard < 100000; guard++) {
+    lambda = cadd(lambda, dd, w.bad);
+    tt = gcd64(lambda, D);
+  }
+  if (tt != 1) w.bad |= Q_WHY_OTHER;
+  if (lane < nvar) return pmod(cmul(lambda, c, w.bad), D);
+  if (lane == nvar) return -(D - pmod(cmul(c, lambda, w.bad), D));
+  return c;
+}
+
+// append a cut as logical row nligne in slot ni (flag Minus, denominator D); false: no room
+__device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i64 c, i64 D, int lane) {
+  if (nligne >= t.rows_cap || ni >= t.slots_cap) return false;
+  if (lane < t.W) t.val[ni * t.W + lane] = c;
+  if (lane == 0) {
+    t.flag[nligne] = F_MINUS;
+    t.ref[nligne] = ni;
+    t.den[nligne] = D;
+  }
+  wsync();
+  return true;
+}
+
+// traiter() of a tableau without parameters, integer solve (the sub-problems of compa_test and the
+// context test): true when the first cell of its tape would not be Nil
+__device__ bool solve_plain(Tab &t, int nvar, int ni, float *key, Wv &w) {
+  const int lane = w.lane, ncol = nvar + 1;
+  sort_rows(t, nvar, nvar + ni, key, w);
+  if (BAD(w)) return false;
+  for (int guard = 0; guard < 100000 && !BAD(w); guard++) {
+    const int nligne = nvar + ni;
+    int pivi = first_flagged(t, F_MINUS, nligne, lane);
+    if (pivi >= nligne) pivi = classify_rows(t, nvar, ncol, -1, nligne, lane);
+    if (pivi >= nligne) {
+      // integrer.c:305-534 with constant cuts only
+      int i;
+      const u64 frac = __ballot(lane < nvar && !(t.flag[lane] & F_UNIT) && t.den[lane] != 1);  // rows that may be fractional
+      for (i = frac ? first64(frac) : nvar; i < nvar; i++) {
+        if (!((frac >> i) & 1)) continue;
+        Cut q = make_cut(t, i, nvar, ncol, -1, lane);
+        if (!q.ok_const) continue;  // integral row
+        if (!q.ok_var) return false;  // constant fractional, nothing to cut with
+        const i64 D = t.den[i];
+        i64 c = q.c;
+        if (w.deepest) c = deepen(c, D, nvar, lane, w);
+        if (lane >= ncol) c = 0;
+        if (!append_row(t, nligne, ni, c, D, lane)) {
+          w.bad |= Q_WHY_ROWS;
+          return false;
+        }
+        pivi = nligne;
+        ni++;
+        break;
+      }
+      if (i >= nvar) return true;  // every unknown integral: a solution
+    }
+    if (pivot_step(t, pivi, nvar, ncol, nvar + ni, w) < 0) return false;
+  }
+  w.bad |= Q_WHY_OTHER;
+  return false;
+}
+
+// the tableau "context (+ one more row)" of compa_test / the context test (traiter.c:196-233,
+// maind.c:196-203): nparm unit rows, the nc context rows, `extra` as the last row
+__device__ __forceinline__ int build_sub(Tab &s, const i64 *ctx, int CW, int nparm, int nc, bool has_extra, i64 extra,
+                                         int lane) {
+  const int ni = nc + (has_extra ? 1 : 0);
+  if (nparm + ni > s.rows_cap || ni > s.slots_cap) return -1;
+  for (int base = 0; base < nparm + ni; base += 64) {
+    const int k = base + lane;
+    if (k < nparm) {
+      s.flag[k] = F_UNIT;
+      s.ref[k] = k;
+      s.den[k] = 1;
+    } else if (k < nparm + ni) {
+      s.flag[k] = F_UNKNOWN;
+      s.ref[k] = k - nparm;
+      s.den[k] = 1;
+    }
+  }
+  for (int r = 0; r < nc; r++)
+    if (lane < s.W) s.val[r * s.W + lane] = lane <= nparm ? ctx[r * CW + lane] : 0;
+  if (has_extra && lane < s.W) s.val[nc * s.W + lane] = lane <= nparm ? extra : 0;
+  if (lane == 0) {
+    *s.ldet = 1;
+    s.det[0] = 1;
+  }
+  wsync();
+  return ni;
+}
+
+struct Tape {
+  i64 *cell;  // global: 3 words per cell (kind, param1, param2)
+  int n, cap;
+};
+__device__ __forceinline__ void tape_put(Tape &tp, int at, int kind, i64 a, i64 b) {
+  if (at < tp.cap) {
+    tp.cell[3 * (size_t)at] = kind;
+    tp.cell[3 * (size_t)at + 1] = a;
+    tp.cell[3 * (size_t)at + 2] = b;
+  }
+}
+
+// integrer.c:230-254 has_cut on the context rows; cut = constant | parameters | divisor (uniform code)
+__device__ bool ctx_has_cut(const i64 *ctx, int CW, int nr, int nparm, int p, const i64 *cut) {
+  for (int row = 0; row < nr; row++) {
+    const i64 *v = ctx + row * CW;
+    if (v[p] != cut[1 + nparm]) continue;
+    if (v[nparm] != cut[0]) continue;
+    int col;
+    for (col = p + 1; col < nparm; col++)
+      if (v[col] != 0) break;
+    if (col < nparm) continue;
+    for (col = 0; col < p; col++)
+      if (v[col] != cut[1 + col]) break;
+    if (col < p) continue;
+    return true;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const i64 *input, i64 *stack, i64 *cells,
+                                                        int *out, int nprob, QCaps cap) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int pi = blockIdx.x;
+  if (pi >= nprob) return;
+  const QProb P = probs[pi];
+  const long long t_start = wall_clock64(), c_start = clock64();
+  Wv w;
+  w.lane = threadIdx.x;
+  w.bad = 0;
+  w.pivots = 0;
+  w.deepest = cap.deepest;
+  const int lane = w.lane;
+
+  // ---- LDS carve-up: [main: den | val | ctx | flag | ref | state] [sub: den | val | flag | ref | det] [key] [cutv]
+  unsigned char *q = smem;
+  Tab M, S;
+  M.den = (i64 *)q;
+  q += 8 * (size_t)cap.R;
+  M.val = (i64 *)q;
+  q += 8 * (size_t)cap.S * cap.W;
+  i64 *ctx = (i64 *)q;
+  q += 8 * (size_t)cap.CR * cap.CW;
+  M.flag = (int *)q;
+  q += 4 * (size_t)cap.R;
+  M.ref = (int *)q;
+  q += 4 * (size_t)cap.R;
+  QState *st = (QState *)q;
+  q += sizeof(QState);
+  const size_t main_words = (size_t)(q - smem) / 8;
+  M.ldet = &st->ldet;
+  M.det = st->det;
+  M.W = cap.W;
+  M.rows_cap = cap.R;
+  M.slots_cap = cap.S;
+  S.den = (i64 *)q;
+  q += 8 * (size_t)cap.SR;
+  S.val = (i64 *)q;
+  q += 8 * (size_t)cap.SS * cap.CW;
+  S.det = (i64 *)q;
+  q += 8 * MAXDET;
+  S.flag = (int *)q;
+  q += 4 * (size_t)cap.SR;
+  S.ref = (int *)q;
+  q += 4 * (size_t)cap.SR;
+  S.ldet = (int *)q;
+  q += 8;
+  S.W = cap.CW;
+  S.rows_cap = cap.SR;
+  S.slots_cap = cap.SS;
+  float *key = (float *)q;
+  q += 4 * 64;
+  i64 *cutv = (i64 *)q;  // [CW + 2]
+
+  i64 *my_stack = stack + (size_t)pi * cap.depth * main_words;
+  Tape tape;
+  tape.cell = cells + (size_t)pi * cap.cells * 3;
+  tape.n = 0;
+  tape.cap = cap.cells;
+  int sp = 0;
+
+  int nvar = P.nvar, nparm = P.nparm, ni = P.ni, nc = P.nc;
+  const int bigparm = P.bigparm, CW = cap.CW, W = cap.W;
+  const bool integer = P.nq != 0;
+  int result = Q_DONE;
+
+  // ---- load: zero the main image, rows Unknown with denominator 1 under nvar unit rows (tab.c:158-248)
+  for (size_t k = lane; k < main_words; k += 64) ((i64 *)smem)[k] = 0;
+  wsync();
+  {
+    const int ncol = nvar + nparm + 1;
+    const i64 *in = input + P.in_off;
+    for (int r = 0; r < ni; r++)
+      if (lane < ncol) M.val[r * W + lane] = in[(size_t)r * ncol + lane];
+    const i64 *cin = in + (size_t)ni * ncol;
+    for (int r = 0; r < nc; r++)
+      if (lane <= nparm) ctx[r * CW + lane] = cin[(size_t)r * (nparm + 1) + lane];
+    for (int base = 0; base < nvar + ni; base += 64) {
+      const int k = base + lane;
+      if (k < nvar) {
+        M.flag[k] = F_UNIT;
+        M.ref[k] = k;
+        M.den[k] = 1;
+      } else if (k < nvar + ni) {
+        M.flag[k] = F_UNKNOWN;
+        M.ref[k] = k - nvar;
+        M.den[k] = 1;
+      }
+    }
+    if (lane == 0) {
+      st->ldet = 1;
+      st->det[0] = 1;
+    }
+  }
+  wsync();
+
+  // ---- maind.c:196-203 / piplib.c:813-823: is the context empty?
+  if (nc) {
+    const int sni = build_sub(S, ctx, CW, nparm, nc, false, 0, lane);
+    if (sni < 0)
+      w.bad |= Q_WHY_ROWS;
+    else if (!solve_plain(S, nparm, sni, key, w) && !BAD(w))
+      result = Q_VOID;
+  }
+
+  // ---- traiter(), traiter.c:628-791, as a state machine: DECIDE (the head of the reference's loop) ->
+  // PIVOT (its `pirouette` label) or LEAVE (the call returns: the caller's "else" state is popped)
+  if (result == Q_DONE && !BAD(w)) {
+    enum { DECIDE = 0, PIVOT = 1, LEAVE = 2 };
+    int pivi = 0, next = DECIDE;
+    bool enter = true, finished = false;
+    for (int guard = 0; guard < 2000000 && !finished; guard++) {
+      if (BAD(w)) break;
+      if (next == DECIDE) {
+        if (enter) {
+          const long long tq0 = clock64();
+          sort_rows(M, nvar, nvar + ni, key, w);
+          w.t_sort += clock64() - tq0;
+          enter = false;
+          if (BAD(w)) break;
+        }
+        const int nligne = nvar + ni, ncol = nvar + nparm + 1;
+        pivi = first_flagged(M, F_MINUS, nligne, lane);
+        if (pivi >= nligne) pivi = classify_rows(M, nvar, ncol, bigparm, nligne, lane);
+        if (pivi >= nligne && nparm > 0) {
+          // compa_test, traiter.c:162-243
+          if (nparm >= PIPAMD_MAXPARM) w.bad |= Q_WHY_OTHER;
+          for (int i = first_flagged(M, F_CRITIC | F_UNKNOWN, nligne, lane); i < nligne && !BAD(w); i++) {
+            const int fl = M.flag[i];
+            if (!(fl & (F_CRITIC | F_UNKNOWN))) continue;
+            const i64 v = lane < ncol ? M.val[M.ref[i] * W + lane] : 0;
+            const bool critic = __ballot(lane < nvar && v > 0) == 0;
+            // lane j <= nparm of the new context row: parameters, then the constant
+            const i64 vc = bcast(v, nvar);
+            const i64 vp = __shfl(v, (lane + nvar + 1) & 63);  // lane j < nparm: column nvar+1+j
+            i64 ex = lane < nparm ? vp : (lane == nparm ? (critic ? vc : csub(vc, 1, w.bad)) : 0);
+            int sni = build_sub(S, ctx, CW, nparm, nc, true, ex, lane);
+            if (sni < 0) {
+              w.bad |= Q_WHY_ROWS;
+              break;
+            }
+            const long long ts0 = clock64();
+            const bool can_pos = solve_plain(S, nparm, sni, key, w);
+            ex = lane < nparm ? cneg(vp, w.bad) : (lane == nparm ? csub(cneg(vc, w.bad), 1, w.bad) : 0);
+            sni = build_sub(S, ctx, CW, nparm, nc, true, ex, lane);
+            const bool can_neg = solve_plain(S, nparm, sni, key, w);
+            w.t_sub += clock64() - ts0;
+            int nf;
+            if (can_pos && can_neg)
+              nf = critic ? F_CRITIC : F_UNKNOWN;
+            else if (can_neg)
+              nf = F_MINUS;
+            else
+              nf = can_pos ? F_PLUS : F_ZERO;
+            if (lane == 0) M.flag[i] = nf;
+            wsync();
+            if (nf == F_MINUS) break;
+          }
+          if (BAD(w)) break;
+          pivi = first_flagged(M, F_MINUS, nligne, lane);
+        }
+        if (pivi < nligne) {
+          next = PIVOT;
+        } else {
+          pivi = first_flagged(M, F_CRITIC, nligne, lane);
+          if (pivi >= nligne) pivi = first_flagged(M, F_UNKNOWN, nligne, lane);
+          if (pivi < nligne) {
+            // ---- the quast forks on the sign of row pivi, traiter.c:695-759
+            if (nparm >= PIPAMD_MAXPARM || nc >= cap.CR || sp >= cap.depth || tape.n + nparm + 3 >= tape.cap) {
+              w.bad |= sp >= cap.depth ? Q_WHY_STACK : (nc >= cap.CR ? Q_WHY_ROWS : (nparm >= PIPAMD_MAXPARM ? Q_WHY_OTHER : Q_WHY_TAPE));
+              break;
+            }
+            const i64 v = lane < ncol ? M.val[M.ref[pivi] * W + lane] : 0;
+            const i64 vc = bcast(v, nvar);
+            const i64 vp = __shfl(v, (lane + nvar + 1) & 63);
+            i64 g = 0;
+            for (int j = 0; j < nparm; j++) g = gcd64(g, bcast(vp, j));
+            if (!integer) g = gcd64(g, vc);
+            if (g == 0) {
+              w.bad |= Q_WHY_OTHER;
+              break;
+            }
+            const i64 cr =
+                lane < nparm ? quo(vp, g) : (lane == nparm ? (integer ? floordiv(vc, g, w.bad) : quo(vc, g)) : 0);
+            if (lane == 0) {
+              tape_put(tape, tape.n, C_IF, 0, 0);
+              tape_put(tape, tape.n + 1, C_FORM, nparm + 1, 0);
+            }
+            if (lane <= nparm) tape_put(tape, tape.n + 2 + lane, C_VAL, cr, 1);
+            tape.n += nparm + 3;
+            // the "else" state waits on the stack: row pivi negative, the negated condition in the context
+            if (lane < CW)
+              ctx[nc * CW + lane] =
+                  lane < nparm ? cneg(cr, w.bad) : (lane == nparm ? cneg(cadd(cr, 1, w.bad), w.bad) : 0);
+            if (lane == 0) {
+              M.flag[pivi] = F_MINUS;
+              st->nvar = nvar;
+              st->nparm = nparm;
+              st->ni = ni;
+              st->nc = nc + 1;
+              st->pivi = pivi;
+            }
+            wsync();
+            {
+              i64 *dst = my_stack + (size_t)sp * main_words;
+              for (size_t k = lane; k < main_words; k += 64) dst[k] = ((const i64 *)smem)[k];
+              sp++;
+            }
+            wsync();
+            // the "then" branch: row pivi positive, the condition in the context; a new traiter() call
+            if (lane < CW) ctx[nc * CW + lane] = lane <= nparm ? cr : 0;
+            if (lane == 0) M.flag[pivi] = F_PLUS;
+            wsync();
+            nc++;
+            enter = true;
+            continue;  // next == DECIDE
+          }
+          // ---- every sign settled: the solution, or a cut
+          bool solution = !integer, nil = false;
+          if (integer) {
+            // integrer.c:305-534
+            int i;
+            const u64 frac = __ballot(lane < nvar && !(M.flag[lane] & F_UNIT) && M.den[lane] != 1);  // rows that may be fractional
+            for (i = frac ? first64(frac) : nvar; i < nvar; i++) {
+              if (!((frac >> i) & 1)) continue;
+              Cut qc = make_cut(M, i, nvar, ncol, bigparm, lane);
+              if (!qc.ok_parm && !qc.ok_const) continue;  // integral row
+              const i64 D = M.den[i];
+              i64 c = qc.c;
+              if (!qc.ok_parm) {
+                if (!qc.ok_var) {  // constant fractional, nothing to cut with
+                  nil = true;
+                  break;
+                }
+                if (w.deepest) c = deepen(c, D, nvar, lane, w);
+                if (lane >= ncol) c = 0;
+                if (!append_row(M, nligne, ni, c, D, lane)) w.bad |= Q_WHY_ROWS;
+                break;
+              }
+              // parametric cut, integrer.c:487-520; cutv = constant | parameters | divisor
+              if (lane >= nvar && lane < ncol) cutv[lane - nvar] = c;
+              if (lane == 0) cutv[1 + nparm] = D;
+              wsync();
+              int parm = -1;
+              if (cutv[1 + nparm - 1] == 0) {  // integrer.c:258-291 find_parm (uniform code on LDS)
+                // the function edits cut[0] in place; here on a local copy, published before each has_cut
+                i64 c0 = csub(cadd(cutv[0], D, w.bad), 1, w.bad);
+                for (int p = nparm - 1; p >= 0; --p) {
+                  if (cutv[1 + p] != 0) break;
+                  wsync();
+                  if (lane == 0) cutv[0] = c0;
+                  wsync();
+                  if (!ctx_has_cut(ctx, CW, nc, nparm, p, cutv)) continue;
+                  c0 = csub(cadd(c0, 1, w.bad), D, w.bad);
+                  wsync();
+                  {
+                    const i64 old = lane <= nparm + 1 ? cutv[lane] : 0;
+                    wsync();
+                    if (lane <= nparm + 1) cutv[lane] = lane == 0 ? cneg(c0, w.bad) : cneg(old, w.bad);
+                  }
+                  wsync();
+                  const bool found = ctx_has_cut(ctx, CW, nc, nparm, p, cutv);
+                  wsync();
+                  {
+                    const i64 old = lane <= nparm + 1 ? cutv[lane] : 0;
+                    wsync();
+                    if (lane <= nparm + 1) cutv[lane] = lane == 0 ? c0 : cneg(old, w.bad);
+                  }
+                  wsync();
+                  if (found) {
+                    parm = p;
+                    break;
+                  }
+                  c0 = csub(cadd(c0, D, w.bad), 1, w.bad);
+                }
+                if (parm < 0) c0 = csub(cadd(c0, 1, w.bad), D, w.bad);
+                wsync();
+                if (lane == 0) cutv[0] = c0;
+                wsync();
+              }
+              if (parm == -1) {
+                // integrer.c:156-227 add_parm: a new parameter q = floor(-(cut . (1,p)) / D)
+                if (nparm + 2 > CW || nc + 2 > cap.CR || ncol + 1 > W || nparm + 1 >= PIPAMD_MAXPARM ||
+                    tape.n + nparm + 5 >= tape.cap) {
+                  w.bad |= tape.n + nparm + 5 >= tape.cap ? Q_WHY_TAPE : (nparm + 1 >= PIPAMD_MAXPARM ? Q_WHY_OTHER : Q_WHY_ROWS);
+                  break;
+                }
+                const i64 c0 = cutv[0];
+                const i64 cp = lane < nparm ? cutv[1 + lane] : 0;
+                if (lane == 0) {
+                  tape_put(tape, tape.n, C_NEW, nparm, 0);
+                  tape_put(tape, tape.n + 1, C_DIV, 0, 0);
+                  tape_put(tape, tape.n + 2, C_FORM, nparm + 1, 0);
+                  tape_put(tape, tape.n + 3 + nparm, C_VAL, cneg(c0, w.bad), 1);
+                  tape_put(tape, tape.n + 4 + nparm, C_VAL, D, 1);
+                }
+                if (lane < nparm) tape_put(tape, tape.n + 3 + lane, C_VAL, cneg(cp, w.bad), 1);
+                tape.n += nparm + 5;
+                // the constant column moves one to the right in every context row
+                for (int base = 0; base < nc; base += 64) {
+                  const int k = base + lane;
+                  if (k < nc) {
+                    ctx[k * CW + nparm + 1] = ctx[k * CW + nparm];
+                    ctx[k * CW + nparm] = 0;
+                  }
+                }
+                if (lane < CW) {  // 0 <= -(cut . (1,p)) - D q  and  -(cut . (1,p)) - D q <= D - 1
+                  i64 a = 0, b = 0;
+                  if (lane < nparm) {
+                    b = cp;
+                    a = cneg(cp, w.bad);
+                  } else if (lane == nparm) {
+                    a = cneg(D, w.bad);
+                    b = D;
+                  } else if (lane == nparm + 1) {
+                    a = cneg(c0, w.bad);
+                    b = cadd(csub(c0, 1, w.bad), D, w.bad);
+                  }
+                  ctx[nc * CW + lane] = a;
+                  ctx[(nc + 1) * CW + lane] = b;
+                }
+                wsync();
+                parm = nparm;
+                nparm++;
+                nc += 2;
+              }
+              if (!qc.ok_var) {  // assert(ok_var), integrer.c:499
+                w.bad |= Q_WHY_OTHER;
+                break;
+              }
+              // the cut row: the first ncol columns of the cut, the divisor added in the quotient's column
+              if (lane >= ncol) c = 0;
+              if (lane == nvar + 1 + parm) c = cadd(c, D, w.bad);
+              if (!append_row(M, nligne, ni, c, D, lane)) w.bad |= Q_WHY_ROWS;
+              break;
+            }
+            if (BAD(w)) break;
+            if (i >= nvar)
+              solution = true;
+            else if (!nil) {
+              pivi = nligne;  // the fresh cut row is negative: pivot on it
+              ni++;
+              next = PIVOT;
+            }
+          }
+          if (nil) {
+            if (tape.n + 1 >= tape.cap) {
+              w.bad |= Q_WHY_TAPE;
+              break;
+            }
+            if (lane == 0) tape_put(tape, tape.n, C_NIL, 0, 0);
+            tape.n++;
+            next = LEAVE;
+          } else if (solution) {
+            // solution(), traiter.c:255-271
+            const int nc1 = nvar + nparm + 1;
+            const int need = 1 + nvar * (nparm + 2);
+            if (tape.n + need >= tape.cap) {
+              w.bad |= Q_WHY_TAPE;
+              break;
+            }
+            if (lane == 0) tape_put(tape, tape.n, C_LIST, nvar, 0);
+            for (int i = 0; i < nvar; i++) {
+              const int at = tape.n + 1 + i * (nparm + 2);
+              const i64 d = M.den[i];
+              const i64 v = row_at(M, i, lane, nc1);
+              if (lane == 0) tape_put(tape, at, C_FORM, nparm + 1, 0);
+              if (lane > nvar && lane < nc1) tape_put(tape, at + (lane - nvar), C_VAL, v, d);
+              if (lane == nvar) tape_put(tape, at + nparm + 1, C_VAL, v, d);
+            }
+            tape.n += need;
+            next = LEAVE;
+          }
+        }
+      }
+      if (next == PIVOT) {
+        next = DECIDE;
+        const long long tp0 = clock64();
+        const int pr = pivot_step(M, pivi, nvar, nvar + nparm + 1, nvar + ni, w);
+        w.t_piv += clock64() - tp0;
+        if (pr < 0) {
+          if (tape.n + 1 >= tape.cap) {
+            w.bad |= Q_WHY_TAPE;
+            break;
+          }
+          if (lane == 0) tape_put(tape, tape.n, C_NIL, 0, 0);
+          tape.n++;
+          next = LEAVE;
+        }
+      }
+      if (next == LEAVE) {
+        if (sp == 0) {
+          finished = true;
+          break;
+        }
+        sp--;
+        const i64 *src = my_stack + (size_t)sp * main_words;
+        wsync();
+        for (size_t k = lane; k < main_words; k += 64) ((i64 *)smem)[k] = src[k];
+        wsync();
+        nvar = st->nvar;
+        nparm = st->nparm;
+        ni = st->ni;
+        nc = st->nc;
+        pivi = st->pivi;
+        next = PIVOT;  // traiter.c:758: the caller goes on with `pirouette` on the row now negative
+      }
+    }
+    if (!finished) w.bad |= Q_WHY_OTHER;
+  }
+  int why = w.bad;
+  for (int o = 32; o; o >>= 1) why |= __shfl_xor(why, o);
+  if (why) result = Q_FALLBACK;
+  if (lane == 0) {
+    out[Q_OUT * pi] = result;
+    out[Q_OUT * pi + 1] = result == Q_DONE ? tape.n : 0;
+    out[Q_OUT * pi + 2] = w.pivots;
+    out[Q_OUT * pi + 3] = why;
+    out[Q_OUT * pi + 4] = (int)(wall_clock64() - t_start);  // 10 ns units (100 MHz), diagnostics
+    out[Q_OUT * pi + 5] = tape.n;
+    out[Q_OUT * pi + 6] = (int)(w.t_piv >> 4);
+    out[Q_OUT * pi + 7] = (int)(w.t_sub >> 4);
+    out[Q_OUT * pi + 8] = (int)(w.t_sort >> 4);
+    out[Q_OUT * pi + 9] = (int)((clock64() - c_start) >> 4);
+  }
+}
+
+// cells of every finished problem, packed back to back: off[i] .. off[i+1]
+__global__ void pip_quast_pack_kernel(const i64 *cells, const i64 *off, i64 *packed, int cells_cap) {
+  const int pi = blockIdx.x;
+  const i64 lo = off[pi], n = off[pi + 1] - lo;
+  const i64 *src = cells + (size_t)pi * cells_cap * 3;
+  for (i64 k = threadIdx.x; k < 3 * n; k += blockDim.x) packed[3 * lo + k] = src[k];
+}
+
+}  // namespace
+
+extern "C" size_t pipk_quast_lds_bytes(const QCaps *c) {
+  size_t b = 8 * (size_t)c->R + 8 * (size_t)c->S * c->W + 8 * (size_t)c->CR * c->CW + 8 * (size_t)c->R + sizeof(QState);
+  b += 8 * (size_t)c->SR + 8 * (size_t)c->SS * c->CW + 8 * MAXDET + 8 * (size_t)c->SR + 8;
+  b += 4 * 64 + 8 * ((size_t)c->CW + 2);
+  return (b + 15) & ~(size_t)15;
+}
+extern "C" size_t pipk_quast_frame_words(const QCaps *c) {
+  return (8 * (size_t)c->R + 8 * (size_t)c->S * c->W + 8 * (size_t)c->CR * c->CW + 8 * (size_t)c->R + sizeof(QState)) / 8;
+}
+
+static int g_quast_lds[64];  // per device: dynamic LDS the kernel has been allowed
+
+extern "C" hipError_t pipk_launch_quast(const QProb *probs, const long long *input, long long *stack, long long *cells,
+                                        int *out, int nprob, const QCaps *cap, hipStream_t stream) {
+  if (nprob <= 0) return hipSuccess;
+  const size_t shm = pipk_quast_lds_bytes(cap);
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64 || (size_t)g_quast_lds[dev] < shm) {  // opt in to more dynamic LDS, once per device and size
+    e = hipFuncSetAttribute((const void *)pip_quast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) g_quast_lds[dev] = (int)shm;
+  }
+  hipLaunchKernelGGL(pip_quast_kernel, dim3(nprob), dim3(64), shm, stream, probs, input, stack, cells, out, nprob, *cap);
+  return hipGetLastError();
+}
+extern "C" hipError_t pipk_launch_quast_pack(const long long *cells, const long long *off, long long *packed, int nprob,
+                                             int cells_cap, hipStream_t stream) {
+  if (nprob <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pip_quast_pack_kernel, dim3(nprob), dim3(128), 0, stream, cells, off, packed, cells_cap);
+  return hipGetLastError();
+}

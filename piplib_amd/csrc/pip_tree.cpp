@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "pip_host.h"
+#include "pip_quast.h"
 
 namespace {
 
@@ -1738,32 +1739,225 @@ class Forest {
 
 }  // namespace
 
-// Many problems in lock step (Forest); the few that need a rare path are finished by the Tree.
+// =========================================================================== device tree
+// Small problems: the whole traiter() call tree on the device (pip_quast.hip), one wave per problem.
+// Fills res[i] for the problems it finishes; the others keep rc == PIPAMD_E_TOOLARGE ("next path").
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+  template <class T>
+  T *get(size_t bytes) {
+    if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) {
+      p = nullptr;
+      throw (int)PIPAMD_E_HIP;
+    }
+    return (T *)p;
+  }
+};
+
+// capacities for one problem; false: not a shape for the device tree
+bool quast_caps(const pipamd_problem &p, QCaps &c) {
+  const int ncol = p.nvar + p.nparm + 1;
+  if (p.nvar < 0 || p.nparm < 0 || p.ni < 0 || p.nc < 0 || (p.ni && !p.ineq) || (p.nc && !p.ctx)) return false;
+  if (p.bigparm >= ncol || (p.bigparm >= 0 && p.bigparm <= p.nvar)) return false;
+  if (ncol > 64 || p.ni > 56 || p.ni + p.nvar == 0) return false;
+  const int newp = p.nparm ? std::min(6, 64 - ncol) : 0;  // room for quotients of parametric cuts
+  const int depth = p.nparm ? 24 : 0;
+  c.W = ncol + newp;
+  c.S = std::min(64, p.ni + 24);
+  c.R = p.nvar + c.S;
+  c.CW = p.nparm + newp + 1;
+  c.CR = p.nc + 2 * newp + depth + 2;
+  c.SS = std::min(64, c.CR + 1 + 16);
+  if (c.CR + 1 > c.SS) return false;
+  c.SR = c.CW - 1 + c.SS;
+  c.depth = depth;
+  c.cells = 4096;  // SOL_SIZE, type.h:33
+  return true;
+}
+void quast_caps_max(QCaps &a, const QCaps &b) {
+  a.R = std::max(a.R, b.R);
+  a.S = std::max(a.S, b.S);
+  a.W = std::max(a.W, b.W);
+  a.CR = std::max(a.CR, b.CR);
+  a.CW = std::max(a.CW, b.CW);
+  a.SR = std::max(a.SR, b.SR);
+  a.SS = std::max(a.SS, b.SS);
+  a.depth = std::max(a.depth, b.depth);
+  a.cells = std::max(a.cells, b.cells);
+}
+
+void device_tree_chunk(const std::vector<int> &idx, const pipamd_problem *probs, int simplify, const QCaps &cap,
+                       std::vector<FResult> &res, int *served, int *handed_back) {
+  const int n = (int)idx.size();
+  const bool stats = getenv("PIPAMD_FOREST_STATS") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  std::vector<QProb> qp(n);
+  std::vector<i64> in;
+  for (int k = 0; k < n; k++) {
+    const pipamd_problem &p = probs[idx[k]];
+    const int ncol = p.nvar + p.nparm + 1;
+    std::vector<i64> a((const i64 *)p.ineq, (const i64 *)p.ineq + (size_t)p.ni * ncol);
+    std::vector<i64> c((const i64 *)p.ctx, (const i64 *)p.ctx + (size_t)p.nc * (p.nparm + 1));
+    if (p.nq && simplify) {  // maind.c:190-196
+      simplify_rows(a, p.ni, ncol, p.nvar);
+      simplify_rows(c, p.nc, p.nparm + 1, p.nparm);
+    }
+    qp[k] = QProb{(long long)in.size(), p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq};
+    in.insert(in.end(), a.begin(), a.end());
+    in.insert(in.end(), c.begin(), c.end());
+  }
+  const size_t frame = pipk_quast_frame_words(&cap);
+  DevBuf b_prob, b_in, b_stack, b_cells, b_out, b_off, b_packed;
+  QProb *d_prob = b_prob.get<QProb>(sizeof(QProb) * n);
+  i64 *d_in = b_in.get<i64>(sizeof(i64) * in.size());
+  i64 *d_stack = b_stack.get<i64>(sizeof(i64) * frame * (size_t)cap.depth * n);
+  i64 *d_cells = b_cells.get<i64>(sizeof(i64) * 3 * (size_t)cap.cells * n);
+  int *d_out = b_out.get<int>(sizeof(int) * Q_OUT * n);
+  const double t1 = now();
+  HIPTHROW(hipMemcpy(d_prob, qp.data(), sizeof(QProb) * n, hipMemcpyHostToDevice));
+  HIPTHROW(hipMemcpy(d_in, in.data(), sizeof(i64) * in.size(), hipMemcpyHostToDevice));
+  HIPTHROW(pipk_launch_quast(d_prob, d_in, d_stack, d_cells, d_out, n, &cap, 0));
+  std::vector<int> out(Q_OUT * (size_t)n);
+  HIPTHROW(hipMemcpy(out.data(), d_out, sizeof(int) * Q_OUT * n, hipMemcpyDeviceToHost));
+  const double t2 = now();
+  std::vector<i64> off(n + 1, 0);
+  for (int k = 0; k < n; k++) off[k + 1] = off[k] + (out[Q_OUT * k] == Q_DONE ? out[Q_OUT * k + 1] : 0);
+  std::vector<i64> packed(3 * (size_t)off[n]);
+  if (off[n]) {
+    i64 *d_off = b_off.get<i64>(sizeof(i64) * (n + 1));
+    i64 *d_packed = b_packed.get<i64>(sizeof(i64) * 3 * (size_t)off[n]);
+    HIPTHROW(hipMemcpy(d_off, off.data(), sizeof(i64) * (n + 1), hipMemcpyHostToDevice));
+    HIPTHROW(pipk_launch_quast_pack(d_cells, d_off, d_packed, n, cap.cells, 0));
+    HIPTHROW(hipMemcpy(packed.data(), d_packed, sizeof(i64) * packed.size(), hipMemcpyDeviceToHost));
+  }
+  const double t3 = now();
+  if (stats) {
+    int why[5] = {0, 0, 0, 0, 0}, tmax = 0;
+    long long tsum = 0;
+    for (int k = 0; k < n; k++) {
+      for (int b = 0; b < 5; b++)
+        if (out[Q_OUT * k + 3] >> b & 1) why[b]++;
+      if (out[Q_OUT * k] != Q_FALLBACK) tmax = std::max(tmax, out[Q_OUT * k + 4]);
+      tsum += out[Q_OUT * k + 4];
+      if (out[Q_OUT * k] == Q_FALLBACK)
+        fprintf(stderr, "[device tree] problem %d handed back: why %d, %d pivots, %d cells, %.3f ms\n", idx[k], out[Q_OUT * k + 3],
+                out[Q_OUT * k + 2], out[Q_OUT * k + 5], out[Q_OUT * k + 4] * 1e-5);
+    }
+    {
+      double a[4] = {0, 0, 0, 0};
+      for (int k = 0; k < n; k++)
+        for (int q = 0; q < 4; q++) a[q] += out[Q_OUT * k + 6 + q];
+      fprintf(stderr, "[device tree] clock share: main pivots %.1f%%, compa sub-problems %.1f%%, sorts %.1f%%\n", 100 * a[0] / a[3],
+              100 * a[1] / a[3], 100 * a[2] / a[3]);
+    }
+    fprintf(stderr, "[device tree] handed back for: overflow %d, rows %d, tape %d, stack %d, other %d; wave time mean %.3f ms, longest finished %.3f ms\n",
+            why[0], why[1], why[2], why[3], why[4], tsum * 1e-5 / n, tmax * 1e-5);
+  }
+  if (stats)
+    fprintf(stderr, "[device tree] %d problems, LDS %zu B, frame %zu words x %d; pack+alloc %.2f ms, copy+kernel %.2f ms, tape %.2f ms (%lld cells)\n",
+            n, pipk_quast_lds_bytes(&cap), frame, cap.depth, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (long long)off[n]);
+  for (int k = 0; k < n; k++) {
+    FResult &r = res[idx[k]];
+    const int st = out[Q_OUT * k];
+    if (st == Q_FALLBACK) {
+      ++*handed_back;
+      continue;
+    }
+    ++*served;
+    r.rc = PIPAMD_OK;
+    r.status = 0;
+    r.pivots = out[Q_OUT * k + 2];
+    r.is_void = st == Q_VOID;
+    r.tape.clear();
+    if (st == Q_DONE) {
+      r.tape.resize((size_t)(off[k + 1] - off[k]));
+      const i64 *c = packed.data() + 3 * (size_t)off[k];
+      for (size_t t = 0; t < r.tape.size(); t++) r.tape[t] = Cell{(int)c[3 * t], c[3 * t + 1], c[3 * t + 2]};
+    }
+  }
+}
+
+void device_tree(int n, const pipamd_problem *probs, int simplify, int deepest_cut, std::vector<FResult> &res,
+                 int *served, int *handed_back) {
+  // chunks of problems whose stack + tape regions fit the budget (PIPAMD_FOREST_ARENA_MB, default 8192)
+  size_t budget = (size_t)8192 << 20;
+  if (const char *mb = getenv("PIPAMD_FOREST_ARENA_MB")) budget = (size_t)strtoull(mb, nullptr, 10) << 20;
+  std::vector<int> idx;
+  QCaps cap;
+  memset(&cap, 0, sizeof cap);
+  auto flush = [&]() {
+    if (idx.empty()) return;
+    cap.deepest = deepest_cut ? 1 : 0;
+    try {
+      device_tree_chunk(idx, probs, simplify, cap, res, served, handed_back);
+    } catch (int) {  // allocation or launch failure: the chunk's problems go to the next path
+      (void)hipGetLastError();
+    }
+    idx.clear();
+    memset(&cap, 0, sizeof cap);
+  };
+  for (int i = 0; i < n; i++) {
+    QCaps c;
+    memset(&c, 0, sizeof c);
+    if (!quast_caps(probs[i], c)) continue;
+    QCaps m = cap;
+    quast_caps_max(m, c);
+    if (pipk_quast_lds_bytes(&m) > 64 * 1024) {  // a shape that would cost every problem of the launch its occupancy
+      if (pipk_quast_lds_bytes(&c) > 64 * 1024) continue;
+      flush();
+      m = c;
+    }
+    const size_t per = sizeof(i64) * (pipk_quast_frame_words(&m) * (size_t)m.depth + 3 * (size_t)m.cells);
+    if (!idx.empty() && per * (idx.size() + 1) > budget) {
+      flush();
+      m = c;
+    }
+    cap = m;
+    idx.push_back(i);
+  }
+  flush();
+}
+}  // namespace
+
+// Many problems: the device tree first (small problems), then the lock-step Forest; the few that need
+// a rare path are finished by the Tree.
 extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify,
                                               int deepest_cut, pipamd_sol_cell **cells, size_t *n_cells, int *rcs,
                                               int *statuses, int64_t *pivots) {
   if (!e || n < 0 || (n && (!probs || !cells || !n_cells || !rcs))) return PIPAMD_E_INVALID;
   if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
   std::vector<FResult> res(n);
-  for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;  // until the forest has served it: "use the Tree path"
-  if (!deepest_cut) {
+  for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;  // until a path has served it
+  e->dt_served = e->dt_fallback = 0;
+  if (!e->no_device_tree && !getenv("PIPAMD_NO_DEVICE_TREE")) device_tree(n, probs, simplify, deepest_cut, res, &e->dt_served, &e->dt_fallback);
+  std::vector<int> rest;
+  for (int i = 0; i < n; i++)
+    if (res[i].rc == PIPAMD_E_TOOLARGE) rest.push_back(i);
+  if (!deepest_cut && !rest.empty()) {
+    std::vector<pipamd_problem> rp(rest.size());
+    for (size_t k = 0; k < rest.size(); k++) rp[k] = probs[rest[k]];
+    const int nr = (int)rest.size();
     // The forest reserves a worst-case region per problem; batches whose regions add up to more
     // than the arena budget go through it in chunks (PIPAMD_FOREST_ARENA_MB, default 8192).
     size_t budget = (size_t)8192 << 20;
     if (const char *mb = getenv("PIPAMD_FOREST_ARENA_MB")) budget = (size_t)strtoull(mb, nullptr, 10) << 20;
     try {
       Forest f(e->device);
-      for (int lo = 0; lo < n;) {
+      for (int lo = 0; lo < nr;) {
         size_t bytes = 0;
         int hi = lo;
-        while (hi < n && (hi == lo || bytes + Forest::region_words(probs[hi]) * sizeof(i64) <= budget))
-          bytes += Forest::region_words(probs[hi++]) * sizeof(i64);
+        while (hi < nr && (hi == lo || bytes + Forest::region_words(rp[hi]) * sizeof(i64) <= budget))
+          bytes += Forest::region_words(rp[hi++]) * sizeof(i64);
         std::vector<FResult> part;
         try {
-          f.solve(hi - lo, probs + lo, simplify, part);
-          for (int i = lo; i < hi; i++) res[i] = std::move(part[i - lo]);
+          f.solve(hi - lo, rp.data() + lo, simplify, part);
+          for (int i = lo; i < hi; i++) res[rest[i]] = std::move(part[i - lo]);
         } catch (int code) {
-          if (code != PIPAMD_E_HIP) code = PIPAMD_E_TOOLARGE;
           // an allocation or launch failure of this chunk: its problems go to the per-problem tree
           (void)hipGetLastError();
         }

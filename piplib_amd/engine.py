@@ -82,6 +82,18 @@ class Engine:
         lib().pipamd_engine_set_bulk_min.argtypes = [C.c_void_p, C.c_int]
         _check(lib().pipamd_engine_set_bulk_min(self._h, int(n)))
 
+    def set_device_tree(self, on):
+        """pipamd_solve_tableaux_lockstep: try the device-resident traiter() first (default on)"""
+        lib().pipamd_engine_set_device_tree.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().pipamd_engine_set_device_tree(self._h, int(bool(on))))
+
+    def last_device_tree(self):
+        """(problems the device tree finished, problems it handed back) in the last lock-step call"""
+        a, b = C.c_int(0), C.c_int(0)
+        lib().pipamd_last_device_tree.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _check(lib().pipamd_last_device_tree(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_tail_waves(self, n):
         lib().pipamd_engine_set_tail_waves.argtypes = [C.c_void_p, C.c_int]
         _check(lib().pipamd_engine_set_tail_waves(self._h, int(n)))

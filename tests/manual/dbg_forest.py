@@ -12,8 +12,13 @@ o = pb.run_batch(exe, probs, pb.F_NOTEXT)
 print(f"{len(probs)} problems shape {cfg['shape']}; CPU 1 core ({os.path.basename(exe)}): {o.solve_seconds*1e3:.1f} ms = {len(probs)/o.solve_seconds:.0f} problems/s, {o.total_pivots} pivots", flush=True)
 e = eng.Engine(0)
 eng.solve_tableaux(e, probs[:30], lockstep=True)
+for rep in range(2):
+    t = time.perf_counter(); d = eng.solve_tableaux(e, probs, lockstep=True); td = time.perf_counter() - t
+    print(f"device tree: {td*1e3:.1f} ms  {len(probs)/td:.0f} problems/s  pivots {sum(x[3] for x in d)}  (served, handed back) = {e.last_device_tree()}", flush=True)
+e.set_device_tree(False)
 t = time.perf_counter(); b = eng.solve_tableaux(e, probs, lockstep=True); tb = time.perf_counter() - t
 print(f"lockstep: {tb*1e3:.1f} ms  {len(probs)/tb:.0f} problems/s  pivots {sum(x[3] for x in b)}", flush=True)
+print("device tree vs lockstep mismatches", sum(x != y for x, y in zip(d, b)), [i for i, (x, y) in enumerate(zip(d, b)) if x != y][:10])
 t = time.perf_counter(); a = eng.solve_tableaux(e, probs, nthreads=16); ta = time.perf_counter() - t
 print(f"threads : {ta*1e3:.1f} ms  {len(probs)/ta:.0f} problems/s", flush=True)
 print("mismatches", sum(x != y for x, y in zip(a, b)))
