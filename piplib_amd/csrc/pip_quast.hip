@@ -216,7 +216,7 @@ __device__ void sort_rows(Tab &t, int nvar, int nligne, float *key, Wv &w) {
   const int lane = w.lane;
   const int n = nligne - nvar;  // rows to sort: at most 64 + the unit rows among them
   if (n > 64) {
-    w.bad |= Q_WHY_ROWS;
+    w.bad |= Q_WHY_ROWS | 256;
     return;
   }
   const int k = nvar + lane;
@@ -520,7 +520,7 @@ __device__ bool solve_plain(Tab &t, int nvar, int ni, float *key, Wv &w) {
         if (w.deepest) c = deepen(c, D, nvar, lane, w);
         if (lane >= ncol) c = 0;
         if (!append_row(t, nligne, ni, c, D, lane)) {
-          w.bad |= Q_WHY_ROWS;
+          w.bad |= Q_WHY_ROWS | 512;
           return false;
         }
         pivi = nligne;
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   if (nc) {
     const int sni = build_sub(S, ctx, CW, nparm, nc, false, 0, lane);
     if (sni < 0)
-      w.bad |= Q_WHY_ROWS;
+      w.bad |= Q_WHY_ROWS | 1024;
     else if (!solve_plain(S, nparm, sni, key, w) && !BAD(w))
       result = Q_VOID;
   }
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
             i64 ex = lane < nparm ? vp : (lane == nparm ? (critic ? vc : csub(vc, 1, w.bad)) : 0);
             int sni = build_sub(S, ctx, CW, nparm, nc, true, ex, lane);
             if (sni < 0) {
-              w.bad |= Q_WHY_ROWS;
+              w.bad |= Q_WHY_ROWS | 1024;
               break;
             }
             const long long ts0 = clock64();
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
           if (pivi < nligne) {
             // ---- the quast forks on the sign of row pivi, traiter.c:695-759
             if (nparm >= PIPAMD_MAXPARM || nc >= cap.CR || sp >= cap.depth || tape.n + nparm + 3 >= tape.cap) {
-              w.bad |= sp >= cap.depth ? Q_WHY_STACK : (nc >= cap.CR ? Q_WHY_ROWS : (nparm >= PIPAMD_MAXPARM ? Q_WHY_OTHER : Q_WHY_TAPE));
+              w.bad |= sp >= cap.depth ? Q_WHY_STACK : (nc >= cap.CR ? (Q_WHY_ROWS | 4096) : (nparm >= PIPAMD_MAXPARM ? Q_WHY_OTHER : Q_WHY_TAPE));
               break;
             }
             const i64 v = lane < ncol ? M.val[M.ref[pivi] * W + lane] : 0;
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
                 }
                 if (w.deepest) c = deepen(c, D, nvar, lane, w);
                 if (lane >= ncol) c = 0;
-                if (!append_row(M, nligne, ni, c, D, lane)) w.bad |= Q_WHY_ROWS;
+                if (!append_row(M, nligne, ni, c, D, lane)) w.bad |= Q_WHY_ROWS | 2048;
                 break;
               }
               // parametric cut, integrer.c:487-520; cutv = constant | parameters | divisor
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
                 // integrer.c:156-227 add_parm: a new parameter q = floor(-(cut . (1,p)) / D)
                 if (nparm + 2 > CW || nc + 2 > cap.CR || ncol + 1 > W || nparm + 1 >= PIPAMD_MAXPARM ||
                     tape.n + nparm + 5 >= tape.cap) {
-                  w.bad |= tape.n + nparm + 5 >= tape.cap ? Q_WHY_TAPE : (nparm + 1 >= PIPAMD_MAXPARM ? Q_WHY_OTHER : Q_WHY_ROWS);
+                  w.bad |= tape.n + nparm + 5 >= tape.cap ? Q_WHY_TAPE : (nparm + 1 >= PIPAMD_MAXPARM ? Q_WHY_OTHER : (Q_WHY_ROWS | 8192));
                   break;
                 }
                 const i64 c0 = cutv[0];
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
               // the cut row: the first ncol columns of the cut, the divisor added in the quotient's column
               if (lane >= ncol) c = 0;
               if (lane == nvar + 1 + parm) c = cadd(c, D, w.bad);
-              if (!append_row(M, nligne, ni, c, D, lane)) w.bad |= Q_WHY_ROWS;
+              if (!append_row(M, nligne, ni, c, D, lane)) w.bad |= Q_WHY_ROWS | 2048;
               break;
             }
             if (BAD(w)) break;

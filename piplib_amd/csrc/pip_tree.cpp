@@ -1764,7 +1764,7 @@ bool quast_caps(const pipamd_problem &p, QCaps &c) {
   if (p.nvar < 0 || p.nparm < 0 || p.ni < 0 || p.nc < 0 || (p.ni && !p.ineq) || (p.nc && !p.ctx)) return false;
   if (p.bigparm >= ncol || (p.bigparm >= 0 && p.bigparm <= p.nvar)) return false;
   if (ncol > 64 || p.ni > 56 || p.ni + p.nvar == 0) return false;
-  const int newp = p.nparm ? std::min(6, 64 - ncol) : 0;  // room for quotients of parametric cuts
+  const int newp = p.nparm ? std::min(10, 64 - ncol) : 0;  // room for quotients of parametric cuts
   const int depth = p.nparm ? 24 : 0;
   c.W = ncol + newp;
   c.S = std::min(64, p.ni + 24);
