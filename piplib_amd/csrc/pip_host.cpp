@@ -52,6 +52,8 @@ extern "C" void pipamd_engine_destroy(pipamd_engine *e) {
   if (e->d_q) hipFree(e->d_q);
   if (e->h_run) hipHostFree(e->h_run);
   if (e->d_scratch) hipFree(e->d_scratch);
+  for (void *b : e->dt_buf)
+    if (b) hipFree(b);
   free(e);
 }
 

