@@ -115,6 +115,47 @@ def cpu_baseline(rows, nvar, ni):
             "per_core": piv / sum(o.solve_seconds for o in outs)}
 
 
+def parametric_leg(local, no_cpu):
+    """Parametric problems (BASELINE names none; reported beside the headline): the screened set of
+    tests/manual/forest_good.json -- 1,327 random problems of 16 unknowns, 3 parameters, 20 inequalities,
+    3 context rows -- through pipamd_solve_tableaux_lockstep (the device-resident traiter() of
+    csrc/pip_quast.hip serves them; the time is the C call's), once as it is and once eight-fold for a
+    throughput figure, beside the reference on one host core."""
+    import pipbatch as pb
+    from piplib_amd import engine as eng
+    from piplib_amd import synth
+    cfg = json.load(open(os.path.join(ROOT, "tests", "manual", "forest_good.json")))
+    allp = synth.random_problems(cfg["seed"], cfg["count"], *cfg["shape"], 1, cmax=cfg["cmax"], bmax=cfg["bmax"])
+    probs = [allp[i] for i in cfg["good"]]
+    e = eng.Engine(local)
+    out = {"workload": "%d random parametric problems, (unknowns, parameters, inequalities, context rows) = %s, integer solve"
+                       % (len(probs), tuple(cfg["shape"]))}
+    for label, ps in (("set", probs), ("set_x8", probs * 8)):
+        best, piv = None, 0
+        for _ in range(4):
+            prep = eng.PreparedProblems(ps)
+            t0 = time.perf_counter()
+            eng.solve_prepared(e, prep, lockstep=True)
+            dt = time.perf_counter() - t0
+            res = prep.results()
+            piv = sum(r[3] for r in res)
+            best = dt if best is None else min(best, dt)
+        served, back = e.last_device_tree()
+        out[label] = {"problems": len(ps), "ms": best * 1e3, "problems_per_sec": len(ps) / best, "pivots_per_sec": piv / best,
+                      "served_on_device": served, "handed_back": back, "failed": sum(r[1] != 0 for r in res)}
+    if not no_cpu:
+        fast = pb.REFPIP + "_fast"
+        exe = fast if os.access(fast, os.X_OK) else (pb.REFPIP if pb.have_ref() else (pb.ORACLEPIP if pb.have_oracle() else None))
+        if exe:
+            pb.run_batch(exe, probs, pb.F_NOTEXT)
+            o = pb.run_batch(exe, probs, pb.F_NOTEXT)
+            out["cpu_one_core"] = {"problems_per_sec": len(probs) / o.solve_seconds, "ms": o.solve_seconds * 1e3,
+                                   "kind": "reference" if exe != pb.ORACLEPIP else "port"}
+            out["set"]["vs_one_cpu_core"] = out["set"]["problems_per_sec"] / out["cpu_one_core"]["problems_per_sec"]
+            out["set_x8"]["vs_one_cpu_core"] = out["set_x8"]["problems_per_sec"] / out["cpu_one_core"]["problems_per_sec"]
+    return out
+
+
 _STREAMS = {}  # device -> the lanes' HIP streams, kept for the whole process
 
 
@@ -491,6 +532,11 @@ def main():
             del ol, o1
             torch.cuda.empty_cache()
         out["other_configs"] = others
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            out["parametric"] = parametric_leg(local, args.no_cpu)
+        except Exception as ex:  # the leg is an extra: never lose the headline line over it
+            out["parametric"] = {"error": repr(ex)}
 
     if not args.no_cpu:
         rows_h = gen(seeds[0]) if gen else synth.lexmin_batch(seeds[0], args.batch, cfg["nvar"], cfg["ni"])

@@ -54,6 +54,7 @@ extern "C" void pipamd_engine_destroy(pipamd_engine *e) {
   if (e->d_scratch) hipFree(e->d_scratch);
   for (void *b : e->dt_buf)
     if (b) hipFree(b);
+  if (e->dt_host) hipHostFree(e->dt_host);
   free(e);
 }
 

@@ -28,6 +28,8 @@ struct pipamd_engine {
   int no_device_tree; /* 1: pipamd_solve_tableaux_lockstep skips the device-resident traiter() (pip_quast.hip) */
   void *dt_buf[8];     /* device tree: device buffers kept between calls (problems, rows, stacks, tapes, results, ...) */
   size_t dt_cap[8];
+  void *dt_host;       /* device tree: pinned staging buffer for the problems' rows */
+  size_t dt_host_cap;
   int dt_served, dt_fallback; /* problems the device tree finished / handed back in the last lock-step call */
   unsigned long long *d_prof; /* diagnostic builds only (-DPIP_PROFILE) */
   void *d_scratch;

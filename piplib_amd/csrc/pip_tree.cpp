@@ -1805,23 +1805,36 @@ void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipa
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   std::vector<QProb> qp(n);
-  std::vector<i64> in;
+  size_t words = 0;
   for (int k = 0; k < n; k++) {
     const pipamd_problem &p = probs[idx[k]];
-    const int ncol = p.nvar + p.nparm + 1;
-    qp[k] = QProb{(long long)in.size(), p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq};
-    in.insert(in.end(), (const i64 *)p.ineq, (const i64 *)p.ineq + (size_t)p.ni * ncol);
-    in.insert(in.end(), (const i64 *)p.ctx, (const i64 *)p.ctx + (size_t)p.nc * (p.nparm + 1));
+    qp[k] = QProb{(long long)words, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq};
+    words += (size_t)p.ni * (p.nvar + p.nparm + 1) + (size_t)p.nc * (p.nparm + 1);
+  }
+  if (words * sizeof(i64) > e->dt_host_cap) {  // pinned staging buffer, kept between calls
+    if (e->dt_host) hipHostFree(e->dt_host);
+    e->dt_host = nullptr;
+    e->dt_host_cap = 0;
+    const size_t want = words * sizeof(i64) + words * sizeof(i64) / 4 + 4096;
+    HIPTHROW(hipHostMalloc(&e->dt_host, want, hipHostMallocDefault));
+    e->dt_host_cap = want;
+  }
+  i64 *in = (i64 *)e->dt_host;
+  for (int k = 0; k < n; k++) {
+    const pipamd_problem &p = probs[idx[k]];
+    const size_t na = (size_t)p.ni * (p.nvar + p.nparm + 1), ncx = (size_t)p.nc * (p.nparm + 1);
+    if (na) memcpy(in + qp[k].in_off, p.ineq, na * sizeof(i64));
+    if (ncx) memcpy(in + qp[k].in_off + na, p.ctx, ncx * sizeof(i64));
   }
   const size_t frame = pipk_quast_frame_words(&cap);
   QProb *d_prob = dt_buffer<QProb>(e, 0, sizeof(QProb) * n);
-  i64 *d_in = dt_buffer<i64>(e, 1, sizeof(i64) * in.size());
+  i64 *d_in = dt_buffer<i64>(e, 1, sizeof(i64) * words);
   i64 *d_stack = dt_buffer<i64>(e, 2, sizeof(i64) * frame * (size_t)cap.depth * n);
   i64 *d_cells = dt_buffer<i64>(e, 3, sizeof(i64) * 3 * (size_t)cap.cells * n);
   int *d_out = dt_buffer<int>(e, 4, sizeof(int) * Q_OUT * n);
   const double t1 = now();
   HIPTHROW(hipMemcpy(d_prob, qp.data(), sizeof(QProb) * n, hipMemcpyHostToDevice));
-  HIPTHROW(hipMemcpy(d_in, in.data(), sizeof(i64) * in.size(), hipMemcpyHostToDevice));
+  HIPTHROW(hipMemcpyAsync(d_in, in, sizeof(i64) * words, hipMemcpyHostToDevice, 0));
   HIPTHROW(pipk_launch_quast(d_prob, d_in, d_stack, d_cells, d_out, n, &cap, 0));
   std::vector<int> out(Q_OUT * (size_t)n);
   HIPTHROW(hipMemcpy(out.data(), d_out, sizeof(int) * Q_OUT * n, hipMemcpyDeviceToHost));
