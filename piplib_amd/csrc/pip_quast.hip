@@ -785,7 +785,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   }
 
   // ---- maind.c:196-203 / piplib.c:813-823: is the context empty?
-  if (nc) {
+  if (nc && !(P.flags & Q_NO_CONTEXT_TEST)) {
     const int sni = build_sub(S, ctx, CW, nparm, nc, false, 0, lane);
     if (sni < 0)
       w.bad |= Q_WHY_ROWS | 1024;

@@ -876,6 +876,11 @@ void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) { simplify
 
 }  // namespace
 
+// One small 64-bit problem through the device-resident traiter() (defined with the device tree at the end
+// of this file): true when it was served there (tape / is_void / pivots filled), false: use the host tree.
+static bool device_tree_one(pipamd_engine *e, const pipamd_problem &p, int simplify, int deepest_cut, int qflags,
+                            std::vector<Cell> &tape, bool *is_void, int64_t *pivots);
+
 // the tape as the C ABI hands it out: (kind, param1, param2) cells, sol.c:52-59
 static int export_tape(const std::vector<Cell> &tape, pipamd_sol_cell **cells, size_t *n_cells) {
   *n_cells = tape.size();
@@ -964,6 +969,19 @@ extern "C" int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int n
   if (!e) return PIPAMD_E_INVALID;
   if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
   try {
+    if (cells && n_cells && valid_shape(nvar, nparm, ni, nc, bigparm, ineq, ctx)) {  // a small problem: wholly on the device
+      const pipamd_problem p{nvar, nparm, ni, nc, bigparm, nq, ineq, ctx};
+      std::vector<Cell> tape;
+      bool is_void = false;
+      int64_t pv = 0;
+      if (device_tree_one(e, p, simplify, deepest_cut, 0, tape, &is_void, &pv)) {
+        *cells = nullptr;
+        *n_cells = 0;
+        if (status) *status = 0;
+        if (pivots) *pivots = pv;
+        return is_void ? PIPAMD_OK : export_tape(tape, cells, n_cells);
+      }
+    }
     Tree t(e, deepest_cut);
     return solve_one(t, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify, deepest_cut, cells, n_cells, status, pivots);
   } catch (int code) {
@@ -988,6 +1006,18 @@ static int traiter_any(pipamd_engine *e, int nvar, int nparm, int ni, int nc, in
   if (pivots) *pivots = 0;
   int rc = PIPAMD_OK;
   try {
+    if constexpr (sizeof(E) == sizeof(i64)) {  // a small problem without the dual: wholly on the device
+      if (!(flags & PIPAMD_T_DUAL)) {
+        const pipamd_problem p{nvar, nparm, ni, nc, bigparm, (flags & PIPAMD_T_INT) ? 1 : 0, tableau, context};
+        std::vector<Cell> tape;
+        bool is_void = false;
+        int64_t pv = 0;
+        if (device_tree_one(e, p, 0, deepest_cut, Q_NO_CONTEXT_TEST, tape, &is_void, &pv)) {
+          if (pivots) *pivots = pv;
+          return export_tape(tape, cells, n_cells);
+        }
+      }
+    }
     TreeT<E> t(e, deepest_cut);
     try {
       t.traiter_call(nvar, nparm, ni, nc, bigparm, flags, (const i64 *)tableau, (const i64 *)context);
@@ -1798,7 +1828,7 @@ void quast_caps_max(QCaps &a, const QCaps &b) {
   a.cells = std::max(a.cells, b.cells);
 }
 
-void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipamd_problem *probs, const QCaps &cap,
+void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipamd_problem *probs, const QCaps &cap, int qflags,
                        std::vector<FResult> &res, int *served, int *handed_back) {
   const int n = (int)idx.size();
   const bool stats = getenv("PIPAMD_FOREST_STATS") != nullptr;
@@ -1808,7 +1838,7 @@ void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipa
   size_t words = 0;
   for (int k = 0; k < n; k++) {
     const pipamd_problem &p = probs[idx[k]];
-    qp[k] = QProb{(long long)words, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq};
+    qp[k] = QProb{(long long)words, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, qflags, 0};
     words += (size_t)p.ni * (p.nvar + p.nparm + 1) + (size_t)p.nc * (p.nparm + 1);
   }
   if (words * sizeof(i64) > e->dt_host_cap) {  // pinned staging buffer, kept between calls
@@ -1904,7 +1934,7 @@ void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipa
 }
 
 void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut, std::vector<FResult> &res,
-                 int *served, int *handed_back) {
+                 int *served, int *handed_back, int qflags = 0) {
   // chunks of problems whose stack + tape regions fit the budget (PIPAMD_FOREST_ARENA_MB, default 8192)
   size_t budget = (size_t)8192 << 20;
   if (const char *mb = getenv("PIPAMD_FOREST_ARENA_MB")) budget = (size_t)strtoull(mb, nullptr, 10) << 20;
@@ -1916,7 +1946,7 @@ void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simpl
     cap.deepest = deepest_cut ? 1 : 0;
     cap.simplify = simplify ? 1 : 0;  // the kernel simplifies the rows as it loads them
     try {
-      device_tree_chunk(e, idx, probs, cap, res, served, handed_back);
+      device_tree_chunk(e, idx, probs, cap, qflags, res, served, handed_back);
     } catch (int) {  // allocation or launch failure: the chunk's problems go to the next path
       (void)hipGetLastError();
     }
@@ -1945,6 +1975,20 @@ void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simpl
   flush();
 }
 }  // namespace
+
+static bool device_tree_one(pipamd_engine *e, const pipamd_problem &p, int simplify, int deepest_cut, int qflags,
+                            std::vector<Cell> &tape, bool *is_void, int64_t *pivots) {
+  if (e->no_device_tree || getenv("PIPAMD_NO_DEVICE_TREE")) return false;
+  std::vector<FResult> res(1);
+  res[0].rc = PIPAMD_E_TOOLARGE;
+  int served = 0, back = 0;
+  device_tree(e, 1, &p, simplify, deepest_cut, res, &served, &back, qflags);
+  if (res[0].rc != PIPAMD_OK) return false;
+  tape.swap(res[0].tape);
+  *is_void = res[0].is_void;
+  *pivots = res[0].pivots;
+  return true;
+}
 
 // Many problems: the device tree first (small problems), then the lock-step Forest; the few that need
 // a rare path are finished by the Tree.

@@ -17,9 +17,10 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 G = os.path.join(pb.ROOT, "tests", "golden")
 
 
-def solve_file(path, bits=64, **kw):
+def solve_file(path, bits=64, device_tree=True, **kw):
     from piplib_amd import engine as eng
     e = eng.Engine(0)
+    e.set_device_tree(device_tree)  # False: every problem through the host decision tree
     out = []
     status = None
     for p in read_dat(path):
@@ -35,18 +36,20 @@ def solve_file(path, bits=64, **kw):
     return "".join(out), status
 
 
+@pytest.mark.parametrize("device_tree", [True, False], ids=["device-tree", "host-tree"])
 @pytest.mark.parametrize("name", PIPTEST_DAT)
-def test_dat_golden_on_gpu(name):
-    got, status = solve_file(os.path.join(G, "test", name + ".dat"))
+def test_dat_golden_on_gpu(name, device_tree):
+    got, status = solve_file(os.path.join(G, "test", name + ".dat"), device_tree=device_tree)
     assert status is None
     want = open(os.path.join(G, "test", name + ".ll"), encoding="latin-1").read()
     assert pb.squash(got) == pb.squash(want)
 
 
+@pytest.mark.parametrize("device_tree", [True, False], ids=["device-tree", "host-tree"])
 @pytest.mark.parametrize("key", sorted(MANIFEST))
-def test_ref_generated_on_gpu(key):
+def test_ref_generated_on_gpu(key, device_tree):
     m = MANIFEST[key]
-    got, status = solve_file(os.path.join(G, key))
+    got, status = solve_file(os.path.join(G, key), device_tree=device_tree)
     want = open(os.path.join(G, "ref_dp", m["ll"]), encoding="latin-1").read()
     if m["rc"] != 0:  # the reference exit(1)s with "Integer overflow": same verdict, same partial output
         from piplib_amd import engine as eng
@@ -61,17 +64,22 @@ from test_oracle_golden import PIPTEST_PIP  # noqa: E402
 needs_hook = pytest.mark.skipif(not pb.have_ref_gpu(), reason="oracle/_ref/refpip_gpu not built (no /root/reference)")
 
 
-def ref_front_end(args, stdin=None, timeout=300):
-    """oracle/_ref/refpip_gpu: the reference's front end; every traiter() call goes to the GPU."""
+def ref_front_end(args, stdin=None, timeout=300, device_tree=True):
+    """oracle/_ref/refpip_gpu: the reference's front end; every traiter() call goes to the GPU
+    (small problems to the device-resident traiter() unless PIPAMD_NO_DEVICE_TREE is set)."""
     import subprocess
-    return subprocess.run([pb.REFPIP_GPU] + args, stdin=stdin, capture_output=True, timeout=timeout)
+    env = dict(os.environ)
+    if not device_tree:
+        env["PIPAMD_NO_DEVICE_TREE"] = "1"
+    return subprocess.run([pb.REFPIP_GPU] + args, stdin=stdin, capture_output=True, timeout=timeout, env=env)
 
 
 @needs_hook
+@pytest.mark.parametrize("device_tree", [True, False], ids=["device-tree", "host-tree"])
 @pytest.mark.parametrize("name", PIPTEST_DAT)
-def test_dat_golden_through_reference_front_end(name):
+def test_dat_golden_through_reference_front_end(name, device_tree):
     """test/*.dat: the reference's tab_get, tape and sol_edit around the GPU traiter vs test/*.ll."""
-    p = ref_front_end(["dat", os.path.join(G, "test", name + ".dat")])
+    p = ref_front_end(["dat", os.path.join(G, "test", name + ".dat")], device_tree=device_tree)
     assert p.returncode == 0, p.stderr.decode()[-300:]
     want = open(os.path.join(G, "test", name + ".ll"), encoding="latin-1").read()
     assert pb.squash(p.stdout.decode("latin-1")) == pb.squash(want)
