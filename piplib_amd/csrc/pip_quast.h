@@ -24,7 +24,7 @@ struct QCaps {
 // out[Q_OUT*i]: result; +1: cells; +2: pivots; +3: why a problem was handed back (Q_WHY_* bits);
 // +4: run time of the problem's wave in 10 ns units; +5: cells written when it stopped
 enum { Q_DONE = 0, Q_VOID = 1, Q_FALLBACK = 2 };
-enum { Q_OUT = 20 };  // +6..+9: diagnostics (clock ticks / 16: main pivots, compa sub-problems, sorts, total)
+enum { Q_OUT = 6 };
 enum {
   Q_WHY_OVERFLOW = 1,  // a 64-bit product / sum overflowed, or the determinant did ("Integer overflow")
   Q_WHY_ROWS = 2,      // rows, columns or context rows reserved for the problem ran out

@@ -38,8 +38,6 @@ struct Tab {
 };
 
 struct Wv {
-  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // diagnostics: clock ticks per phase of pivot_step
-  long long t_piv = 0, t_sub = 0, t_sort = 0, t_build = 0, t_spiv = 0, t_ssort = 0, t_scut = 0;  // diagnostics: clock64 ticks per phase
   int lane;
   int bad;  // sticky: an overflow or a capacity limit was hit (uniform when tested)
   int pivots;
@@ -52,18 +50,6 @@ struct QState {
   i64 det[MAXDET];
 };
 
-#ifdef PIP_PROFILE  // diagnostic build only: the clock reads wait for every outstanding LDS access
-#define PH(w, i)                          \
-  do {                                    \
-    const long long n_ = clock64();       \
-    (w).ph[i] += n_ - (w).ph_t;           \
-    (w).ph_t = n_;                        \
-  } while (0)
-#define CLK() clock64()
-#else
-#define PH(w, i)
-#define CLK() 0ll
-#endif
 #define BAD(w) (__any((w).bad) != 0)
 __device__ __forceinline__ void wsync() { __syncthreads(); }  // one wave per workgroup: orders its LDS traffic
 __device__ __forceinline__ i64 bcast(i64 x, int src) { return __shfl(x, src); }
@@ -89,22 +75,29 @@ __device__ __forceinline__ i64 cneg(i64 a, int &bad) { return csub(0, a, bad); }
 __device__ __forceinline__ bool fits32(i64 a) { return a == (i64)(int)a; }
 __device__ __forceinline__ i64 mul32(i64 a, i64 b) { return (i64)(int)a * (i64)(int)b; }
 __device__ __forceinline__ u64 uabs(i64 a) { return a < 0 ? 0ull - (u64)a : (u64)a; }
+// 64-bit division is a ~150-instruction sequence: one copy each, out of line (operands rarely need it)
+__device__ __noinline__ u64 umod_wide(u64 a, u64 b) { return a % b; }
+__device__ __noinline__ u64 udiv_wide(u64 a, u64 b) { return a / b; }
 __device__ __forceinline__ u64 umod(u64 a, u64 b) {
-  return ((a | b) >> 32) ? a % b : (u64)((unsigned)a % (unsigned)b);
+  return ((a | b) >> 32) ? umod_wide(a, b) : (u64)((unsigned)a % (unsigned)b);
 }
 __device__ __forceinline__ u64 udiv(u64 a, u64 b) {
-  return ((a | b) >> 32) ? a / b : (u64)((unsigned)a / (unsigned)b);
+  return ((a | b) >> 32) ? udiv_wide(a, b) : (u64)((unsigned)a / (unsigned)b);
 }
 // integrer.c:43-50 on true integers: gcd(|a|, |b|)
-__device__ __forceinline__ i64 gcd64(i64 a, i64 b) {
-  u64 x = uabs(a), y = uabs(b);
-  if (x == 1 || y == 1) return 1;
+__device__ __noinline__ u64 gcd_loop(u64 x, u64 y) {
   while (y) {
     const u64 t = umod(x, y);
     x = y;
     y = t;
   }
-  return (i64)x;
+  return x;
+}
+__device__ __forceinline__ i64 gcd64(i64 a, i64 b) {
+  const u64 x = uabs(a), y = uabs(b);
+  if (x == 1 || y == 1) return 1;
+  if (y == 0) return (i64)x;
+  return (i64)gcd_loop(x, y);
 }
 // C '/' and '%' (truncating) for a non-zero divisor
 __device__ __forceinline__ i64 quo(i64 a, i64 b) {
@@ -163,7 +156,7 @@ __device__ __forceinline__ int first_flagged(const Tab &t, int mask, int n, int 
 }
 
 // traiter.c:101-159 exam_coef: obvious signs of Unknown rows; stops at the first row proven negative
-__device__ int classify_rows(Tab &t, int nvar, int ncol, int bigparm, int nligne, int lane) {
+__device__ __noinline__ int classify_rows(Tab t, int nvar, int ncol, int bigparm, int nligne, int lane) {
   if (bigparm >= 0) {
     for (int base = 0; base < nligne; base += 64) {
       const int k = base + lane;
@@ -228,14 +221,9 @@ __device__ __forceinline__ int trunc_x86(double t) {
   return (!(t > -2147483649.0 && t < 2147483648.0)) ? (int)0x80000000 : (int)t;
 }
 __device__ __forceinline__ int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
-__device__ void sort_rows(Tab &t, int nvar, int nligne, float *key, Wv &w) {
-  (void)key;
-  const int lane = w.lane;
+__device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane) {
   const int n = nligne - nvar;  // rows to sort: at most 64 + the unit rows among them
-  if (n > 64) {
-    w.bad |= Q_WHY_ROWS | 256;
-    return;
-  }
+  if (n > 64) return Q_WHY_ROWS | 256;
   // lane l holds logical row nvar + l (flag, slot, denominator, key); the selection sort swaps lanes
   const int k = nvar + lane;
   int fl = 0, rf = 0, s = 0;
@@ -265,7 +253,7 @@ __device__ void sort_rows(Tab &t, int nvar, int nligne, float *key, Wv &w) {
   const double smax = (double)smx;
   int kb = __float_as_int((float)(double)s);  // non-negative floats order like their bit patterns
   u64 below = __ballot(real && (double)(float)(double)s < smax);
-  if (!below) return;  // no key below the maximum: no row moves
+  if (!below) return 0;  // no key below the maximum: no row moves
   bool moved = false;
   for (int i = 0; i < n; i++) {
     if (!((realm >> i) & 1)) continue;
@@ -309,14 +297,14 @@ __device__ void sort_rows(Tab &t, int nvar, int nligne, float *key, Wv &w) {
     }
     wsync();
   }
+  return 0;
 }
 
 // traiter.c:345-548 pivoter (with choisir_piv, traiter.c:297-341, as a tournament over the rows);
 // returns -1 when the pivot row has no positive entry among the unknowns
-__device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &w) {
-  const int lane = w.lane, W = t.W;
-  w.pivots++;
-  w.ph_t = CLK();
+__device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int ncol, int nligne, int lane) {
+  const int W = t.W;
+  int bad = 0;
   const int pslot = t.ref[pivi];
   const i64 p = lane < ncol ? t.val[pslot * W + lane] : 0;
   u64 tied = __ballot(lane < nvar && p > 0);
@@ -333,7 +321,7 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
     int c = first64(tied);
     for (;;) {
       const i64 pc = bcast(p, c), vc = bcast(v, c);
-      const i64 x = csub(cmul(pc, v, w.bad), cmul(vc, p, w.bad), w.bad);
+      const i64 x = csub(cmul(pc, v, bad), cmul(vc, p, bad), bad);
       const u64 less = __ballot(in && x < 0);
       if (!less) {
         tied = __ballot(in && x == 0);
@@ -344,7 +332,6 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
   }
   const int pivj = first64(tied);
   const i64 pivot = bcast(p, pivj), dpiv = t.den[pivi];
-  PH(w, 0);
   // the determinant in limbs, traiter.c:412-446 (uniform values; lane 0 publishes them).  A pivot of 1
   // over a denominator of 1 multiplies a limb that still has room by 1: nothing to do.
   if (pivot != 1 || dpiv != 1 || blen(t.det[0]) + 1 >= 64) {
@@ -364,7 +351,7 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
           dppiv = quo(dppiv, d);
         }
       }
-    if (dppiv != 1) w.bad |= Q_WHY_OVERFLOW;  // "Integer overflow", traiter.c:424
+    if (dppiv != 1) bad |= Q_WHY_OVERFLOW;  // "Integer overflow", traiter.c:424
     bool placed = false;
 #pragma unroll
     for (int i = 0; i < MAXDET; i++)
@@ -374,7 +361,7 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
       }
     if (!placed) {
       if (ldet + 1 >= MAXDET) {
-        w.bad |= Q_WHY_OVERFLOW;  // traiter.c:442
+        bad |= Q_WHY_OVERFLOW;  // traiter.c:442
       } else {
 #pragma unroll
         for (int i = 0; i < MAXDET; i++)
@@ -388,9 +375,8 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
       *t.ldet = ldet;
     }
     wsync();
-    if (BAD(w)) return 0;
+    if (__any(bad)) return bad;
   }
-  PH(w, 1);
   // eliminate column pivj from every other real row, traiter.c:467-502: lane k rewrites row k, every
   // row at once, walking the columns (the pivot row is read from LDS, the same address for every lane).
   // The same pass finds the unit row of column pivj and refreshes the sign hints (traiter.c:518-529):
@@ -413,12 +399,11 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
         const i64 d = gcd64(pivot, foo);
         lpiv = d == 1 ? pivot : quo(pivot, d);
         fo = d == 1 ? foo : quo(foo, d);
-        g = oden == 1 ? lpiv : cmul(lpiv, oden, w.bad);
+        g = oden == 1 ? lpiv : cmul(lpiv, oden, bad);
       }
       const int fff = sgn_flag(foo);
       if (fff != F_ZERO && fff != fl) t.flag[k] = fl == F_ZERO ? (fff == F_MINUS ? F_UNKNOWN : fff) : F_UNKNOWN;
     }
-    PH(w, 2);
     if (__ballot(act)) {
       const i64 *prow = t.val + pslot * W;
       // operands below 2^31: a product is below 2^62 and the difference of two fits, no check needed
@@ -432,11 +417,10 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
           if (small && fits32(v) && fits32(pj))
             z = j == pivj ? mul32(dpiv, fo) : mul32(v, lpiv) - mul32(pj, fo);
           else
-            z = j == pivj ? cmul(dpiv, fo, w.bad) : csub(cmul(v, lpiv, w.bad), cmul(pj, fo, w.bad), w.bad);
+            z = j == pivj ? cmul(dpiv, fo, bad) : csub(cmul(v, lpiv, bad), cmul(pj, fo, bad), bad);
           r[j] = z;
         }
       }
-      PH(w, 3);
       // gcd of g and the whole row (integrer.c:43-50 folds it the same way, entry by entry), four entries
       // at a time: usually g divides them all, or the gcd drops to 1 at once
       u64 G = uabs(g);
@@ -456,7 +440,6 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
           }
         }
       }
-      PH(w, 4);
       if (__ballot(act && G != 1)) {
         // exact division by G = 2^tz * odd: shift, then multiply by the inverse of the odd part modulo 2^64
         const int tz = __builtin_ctzll(G | (1ull << 63));
@@ -471,15 +454,13 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
         if (dv) g = (i64)((u64)(g >> tz) * inv);
       }
       if (act) t.den[k] = g;
-      PH(w, 5);
     }
   }
   if (ku < 0) {
-    w.bad |= Q_WHY_OTHER;
-    return 0;
+    return bad | Q_WHY_OTHER;
   }
   // swap roles, traiter.c:503-516: the unit row of pivj becomes real (in the pivot row's slot)
-  if (lane < ncol) t.val[pslot * W + lane] = lane == pivj ? dpiv : cneg(p, w.bad);
+  if (lane < ncol) t.val[pslot * W + lane] = lane == pivj ? dpiv : cneg(p, bad);
   if (lane == 0) {
     t.flag[ku] = F_PLUS;
     t.ref[ku] = pslot;
@@ -489,12 +470,11 @@ __device__ int pivot_step(Tab &t, int pivi, int nvar, int ncol, int nligne, Wv &
     t.ref[pivi] = pivj;
   }
   wsync();
-  PH(w, 6);
-  return 0;
+  return bad;
 }
 
 // integrer.c:98-150 bezout
-__device__ i64 bezout(i64 x, i64 y, i64 delta, int &bad) {
+__device__ __forceinline__ i64 bezout(i64 x, i64 y, i64 delta, int &bad) {
   i64 a = 1, b = 0, c = 0, d = 1, u = y, v = delta;
   for (int guard = 0; guard < 200; guard++) {
     const i64 q = floordiv(u, v, bad), r = pmod(u, v);
@@ -533,20 +513,20 @@ __device__ __forceinline__ Cut make_cut(const Tab &t, int i, int nvar, int ncol,
 }
 
 // deepest cut, integrer.c:417-438 (constant cuts only)
-__device__ __forceinline__ i64 deepen(i64 c, i64 D, int nvar, int lane, Wv &w) {
+__device__ __forceinline__ i64 deepen(i64 c, i64 D, int nvar, int lane, int &bad) {
   const i64 cst = bcast(c, nvar);
   i64 tt = -cst;
   const i64 delta = gcd64(tt, D), tau = quo(tt, delta), dd = quo(D, delta);
   tt = dd - 1;
-  i64 lambda = bezout(tt, tau, dd, w.bad);
+  i64 lambda = bezout(tt, tau, dd, bad);
   tt = gcd64(lambda, D);
   for (int guard = 0; tt != 1 && guard < 100000; guard++) {
-    lambda = cadd(lambda, dd, w.bad);
+    lambda = cadd(lambda, dd, bad);
     tt = gcd64(lambda, D);
   }
-  if (tt != 1) w.bad |= Q_WHY_OTHER;
-  if (lane < nvar) return pmod(cmul(lambda, c, w.bad), D);
-  if (lane == nvar) return -(D - pmod(cmul(c, lambda, w.bad), D));
+  if (tt != 1) bad |= Q_WHY_OTHER;
+  if (lane < nvar) return pmod(cmul(lambda, c, bad), D);
+  if (lane == nvar) return -(D - pmod(cmul(c, lambda, bad), D));
   return c;
 }
 
@@ -565,46 +545,49 @@ __device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i64 c, i6
 
 // traiter() of a tableau without parameters, integer solve (the sub-problems of compa_test and the
 // context test): true when the first cell of its tape would not be Nil
-__device__ bool solve_plain(Tab &t, int nvar, int ni, float *key, Wv &w) {
-  const int lane = w.lane, ncol = nvar + 1;
-  const long long tq = CLK();
-  sort_rows(t, nvar, nvar + ni, key, w);
-  w.t_ssort += CLK() - tq;
-  if (BAD(w)) return false;
-  for (int guard = 0; guard < 100000 && !BAD(w); guard++) {
+// Result word: bit 0 = a solution exists, bits 1..15 = reason bits (per lane), bits 16.. = pivots.
+__device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int deepest) {
+  const int ncol = nvar + 1;
+  int bad = sort_rows(t, nvar, nvar + ni, lane), pivots = 0, found = 0;
+  for (int guard = 0; guard < 60000 && !__any(bad); guard++) {
     const int nligne = nvar + ni;
     int pivi = first_flagged(t, F_MINUS, nligne, lane);
     if (pivi >= nligne) pivi = classify_rows(t, nvar, ncol, -1, nligne, lane);
     if (pivi >= nligne) {
       // integrer.c:305-534 with constant cuts only
       int i;
+      bool nil = false;
       const u64 frac = __ballot(lane < nvar && !(t.flag[lane] & F_UNIT) && t.den[lane] != 1);  // rows that may be fractional
       for (i = frac ? first64(frac) : nvar; i < nvar; i++) {
         if (!((frac >> i) & 1)) continue;
         Cut q = make_cut(t, i, nvar, ncol, -1, lane);
         if (!q.ok_const) continue;  // integral row
-        if (!q.ok_var) return false;  // constant fractional, nothing to cut with
+        if (!q.ok_var) {            // constant fractional, nothing to cut with
+          nil = true;
+          break;
+        }
         const i64 D = t.den[i];
         i64 c = q.c;
-        if (w.deepest) c = deepen(c, D, nvar, lane, w);
+        if (deepest) c = deepen(c, D, nvar, lane, bad);
         if (lane >= ncol) c = 0;
-        if (!append_row(t, nligne, ni, c, D, lane)) {
-          w.bad |= Q_WHY_ROWS | 512;
-          return false;
-        }
+        if (!append_row(t, nligne, ni, c, D, lane)) bad |= Q_WHY_ROWS | 512;
         pivi = nligne;
         ni++;
         break;
       }
-      if (i >= nvar) return true;  // every unknown integral: a solution
+      if (nil || __any(bad)) break;
+      if (i >= nvar) {  // every unknown integral: a solution
+        found = 1;
+        break;
+      }
     }
-    const long long tp = CLK();
-    const int pr = pivot_step(t, pivi, nvar, ncol, nvar + ni, w);
-    w.t_spiv += CLK() - tp;
-    if (pr < 0) return false;
+    pivots++;
+    const int pr = pivot_step(t, pivi, nvar, ncol, nvar + ni, lane);
+    if (__any(pr < 0)) break;  // no positive entry in the pivot row: Nil
+    bad |= pr;
+    if (guard == 59999) bad |= Q_WHY_OTHER;
   }
-  w.bad |= Q_WHY_OTHER;
-  return false;
+  return found | (bad << 1) | (pivots << 16);
 }
 
 // the tableau "context (+ one more row)" of compa_test / the context test (traiter.c:196-233,
@@ -672,7 +655,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   const int pi = blockIdx.x;
   if (pi >= nprob) return;
   const QProb P = probs[pi];
-  const long long t_start = wall_clock64(), c_start = CLK();
+  const long long t_start = wall_clock64();
   Wv w;
   w.lane = threadIdx.x;
   w.bad = 0;
@@ -680,7 +663,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   w.deepest = cap.deepest;
   const int lane = w.lane;
 
-  // ---- LDS carve-up: [main: den | val | ctx | flag | ref | state] [sub: den | val | flag | ref | det] [key] [cutv]
+  // ---- LDS carve-up: [main: den | val | ctx | flag | ref | state] [sub: den | val | det | flag | ref] [cutv]
   unsigned char *q = smem;
   Tab M, S;
   M.den = (i64 *)q;
@@ -716,8 +699,6 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   S.W = cap.CW;
   S.rows_cap = cap.SR;
   S.slots_cap = cap.SS;
-  float *key = (float *)q;
-  q += 4 * 64;
   i64 *cutv = (i64 *)q;  // [CW + 2]
 
   i64 *my_stack = stack + (size_t)pi * cap.depth * main_words;
@@ -789,8 +770,12 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
     const int sni = build_sub(S, ctx, CW, nparm, nc, false, 0, lane);
     if (sni < 0)
       w.bad |= Q_WHY_ROWS | 1024;
-    else if (!solve_plain(S, nparm, sni, key, w) && !BAD(w))
-      result = Q_VOID;
+    else {
+      const int r = solve_plain(S, nparm, sni, lane, w.deepest);
+      w.bad |= (r >> 1) & 0x7fff;
+      w.pivots += r >> 16;
+      if (!(r & 1) && !BAD(w)) result = Q_VOID;
+    }
   }
 
   // ---- traiter(), traiter.c:628-791, as a state machine: DECIDE (the head of the reference's loop) ->
@@ -803,9 +788,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
       if (BAD(w)) break;
       if (next == DECIDE) {
         if (enter) {
-          const long long tq0 = CLK();
-          sort_rows(M, nvar, nvar + ni, key, w);
-          w.t_sort += CLK() - tq0;
+          w.bad |= sort_rows(M, nvar, nvar + ni, lane);
           enter = false;
           if (BAD(w)) break;
         }
@@ -829,12 +812,19 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
               w.bad |= Q_WHY_ROWS | 1024;
               break;
             }
-            const long long ts0 = CLK();
-            const bool can_pos = solve_plain(S, nparm, sni, key, w);
-            ex = lane < nparm ? cneg(vp, w.bad) : (lane == nparm ? csub(cneg(vc, w.bad), 1, w.bad) : 0);
-            sni = build_sub(S, ctx, CW, nparm, nc, true, ex, lane);
-            const bool can_neg = solve_plain(S, nparm, sni, key, w);
-            w.t_sub += CLK() - ts0;
+            // "row >= 1" (>= 0 for a critical row), then "-row >= 1", over the context
+            bool can[2] = {false, false};
+            for (int sg = 0; sg < 2; sg++) {
+              if (sg) {
+                ex = lane < nparm ? cneg(vp, w.bad) : (lane == nparm ? csub(cneg(vc, w.bad), 1, w.bad) : 0);
+                sni = build_sub(S, ctx, CW, nparm, nc, true, ex, lane);
+              }
+              const int r = solve_plain(S, nparm, sni, lane, w.deepest);
+              w.bad |= (r >> 1) & 0x7fff;
+              w.pivots += r >> 16;
+              can[sg] = r & 1;
+            }
+            const bool can_pos = can[0], can_neg = can[1];
             int nf;
             if (can_pos && can_neg)
               nf = critic ? F_CRITIC : F_UNKNOWN;
@@ -922,7 +912,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
                   nil = true;
                   break;
                 }
-                if (w.deepest) c = deepen(c, D, nvar, lane, w);
+                if (w.deepest) c = deepen(c, D, nvar, lane, w.bad);
                 if (lane >= ncol) c = 0;
                 if (!append_row(M, nligne, ni, c, D, lane)) w.bad |= Q_WHY_ROWS | 2048;
                 break;
@@ -1065,10 +1055,10 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
       }
       if (next == PIVOT) {
         next = DECIDE;
-        const long long tp0 = CLK();
-        const int pr = pivot_step(M, pivi, nvar, nvar + nparm + 1, nvar + ni, w);
-        w.t_piv += CLK() - tp0;
-        if (pr < 0) {
+        w.pivots++;
+        const int pr = pivot_step(M, pivi, nvar, nvar + nparm + 1, nvar + ni, lane);
+        if (!__any(pr < 0)) w.bad |= pr;
+        if (__any(pr < 0)) {
           if (tape.n + 1 >= tape.cap) {
             w.bad |= Q_WHY_TAPE;
             break;
@@ -1108,13 +1098,6 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
     out[Q_OUT * pi + 3] = why;
     out[Q_OUT * pi + 4] = (int)(wall_clock64() - t_start);  // 10 ns units (100 MHz), diagnostics
     out[Q_OUT * pi + 5] = tape.n;
-    out[Q_OUT * pi + 6] = (int)(w.t_piv >> 4);
-    out[Q_OUT * pi + 7] = (int)(w.t_sub >> 4);
-    out[Q_OUT * pi + 8] = (int)(w.t_sort >> 4);
-    for (int q_ = 0; q_ < 7; q_++) out[Q_OUT * pi + 12 + q_] = (int)(w.ph[q_] >> 4);
-    out[Q_OUT * pi + 10] = (int)(w.t_spiv >> 4);
-    out[Q_OUT * pi + 11] = (int)(w.t_ssort >> 4);
-    out[Q_OUT * pi + 9] = (int)((CLK() - c_start) >> 4);
   }
 }
 
@@ -1131,7 +1114,7 @@ __global__ void pip_quast_pack_kernel(const i64 *cells, const i64 *off, i64 *pac
 extern "C" size_t pipk_quast_lds_bytes(const QCaps *c) {
   size_t b = 8 * (size_t)c->R + 8 * (size_t)c->S * c->W + 8 * (size_t)c->CR * c->CW + 8 * (size_t)c->R + sizeof(QState);
   b += 8 * (size_t)c->SR + 8 * (size_t)c->SS * c->CW + 8 * MAXDET + 8 * (size_t)c->SR + 8;
-  b += 4 * 64 + 8 * ((size_t)c->CW + 2);
+  b += 8 * ((size_t)c->CW + 2);
   return (b + 15) & ~(size_t)15;
 }
 extern "C" size_t pipk_quast_frame_words(const QCaps *c) {

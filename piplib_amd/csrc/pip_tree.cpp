@@ -1802,7 +1802,10 @@ bool quast_caps(const pipamd_problem &p, QCaps &c) {
   if (p.nvar < 0 || p.nparm < 0 || p.ni < 0 || p.nc < 0 || (p.ni && !p.ineq) || (p.nc && !p.ctx)) return false;
   if (p.bigparm >= ncol || (p.bigparm >= 0 && p.bigparm <= p.nvar)) return false;
   if (ncol > 64 || p.ni > 56 || p.ni + p.nvar == 0) return false;
-  const int newp = p.nparm ? std::min(10, 64 - ncol) : 0;  // room for quotients of parametric cuts
+  // Room for 10 quotients of parametric cuts, 24 cut rows and 24 nested forks.  (Smaller reserves -- 4 / 8 / 8:
+  // 11 KB of LDS instead of 26 KB, twice the problems per CU -- made the launch of 10k problems 27 % shorter,
+  // but every problem that then runs out of room costs the host schedulers milliseconds.)
+  const int newp = p.nparm ? std::min(10, 64 - ncol) : 0;
   const int depth = p.nparm ? 24 : 0;
   c.W = ncol + newp;
   c.S = std::min(64, p.ni + 24);
@@ -1891,20 +1894,6 @@ void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipa
       if (out[Q_OUT * k] == Q_FALLBACK)
         fprintf(stderr, "[device tree] problem %d handed back: why %d, %d pivots, %d cells, %.3f ms\n", idx[k], out[Q_OUT * k + 3],
                 out[Q_OUT * k + 2], out[Q_OUT * k + 5], out[Q_OUT * k + 4] * 1e-5);
-    }
-    {
-      double a[6] = {0, 0, 0, 0, 0, 0};
-      for (int k = 0; k < n; k++)
-        for (int q = 0; q < 6; q++) a[q] += out[Q_OUT * k + 6 + q];
-      double ph[7] = {0, 0, 0, 0, 0, 0, 0};
-      for (int k = 0; k < n; k++)
-        for (int q = 0; q < 7; q++) ph[q] += out[Q_OUT * k + 12 + q];
-      if (a[3] > 0)
-      fprintf(stderr, "[device tree] pivot_step: column %.1f%%, determinant %.1f%%, multipliers %.1f%%, rows %.1f%%, row gcd %.1f%%, division %.1f%%, swap+hints %.1f%% of all clocks\n",
-              100 * ph[0] / a[3], 100 * ph[1] / a[3], 100 * ph[2] / a[3], 100 * ph[3] / a[3], 100 * ph[4] / a[3], 100 * ph[5] / a[3], 100 * ph[6] / a[3]);
-      if (a[3] > 0)
-      fprintf(stderr, "[device tree] clock share: main pivots %.1f%%, compa sub-problems %.1f%% (their pivots %.1f%%, sorts %.1f%%), main sorts %.1f%%\n",
-              100 * a[0] / a[3], 100 * a[1] / a[3], 100 * a[4] / a[3], 100 * a[5] / a[3], 100 * a[2] / a[3]);
     }
     fprintf(stderr, "[device tree] handed back for: overflow %d, rows %d, tape %d, stack %d, other %d; wave time mean %.3f ms, longest finished %.3f ms\n",
             why[0], why[1], why[2], why[3], why[4], tsum * 1e-5 / n, tmax * 1e-5);
