@@ -26,14 +26,21 @@ enum { F_UNIT = 1, F_PLUS = 2, F_MINUS = 4, F_ZERO = 8, F_CRITIC = 16, F_UNKNOWN
 enum { C_NIL = 1, C_IF = 2, C_LIST = 3, C_FORM = 4, C_NEW = 5, C_DIV = 6, C_VAL = 7 };
 enum { MAXDET = 4 };  // tab.h:67
 
+// Every tableau lives in LDS: pointers carry the address space, so that the out-of-line functions
+// below get ds_read / ds_write instead of flat accesses (a generic pointer argument costs several times
+// the latency).
+#define LDS __attribute__((address_space(3)))
+typedef LDS i64 li64;
+typedef LDS int lint;
+
 // one tableau in LDS: logical rows (unit row on column `ref`, or real row in slot `ref`)
 struct Tab {
-  i64 *den;   // [rows]
-  i64 *val;   // [slots][W]
-  int *flag;  // [rows]
-  int *ref;   // [rows]
-  int *ldet;  // -> number of determinant limbs in use
-  i64 *det;   // -> MAXDET limbs
+  li64 *den;   // [rows]
+  li64 *val;   // [slots][W]
+  lint *flag;  // [rows]
+  lint *ref;   // [rows]
+  lint *ldet;  // -> number of determinant limbs in use
+  li64 *det;   // -> MAXDET limbs
   int W, rows_cap, slots_cap;
 };
 
@@ -180,7 +187,7 @@ __device__ __noinline__ int classify_rows(Tab t, int nvar, int ncol, int bigparm
     const int k = base + lane;
     int nf = 0;
     if (k < nligne && t.flag[k] == F_UNKNOWN) {
-      const i64 *r = t.val + t.ref[k] * t.W;
+      const li64 *r = t.val + t.ref[k] * t.W;
       int ff = F_ZERO;
       for (int j = nvar + 1; j < ncol; j++) {
         const int fj = sgn_flag(r[j]);
@@ -236,7 +243,7 @@ __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane) {
     real = !(fl & F_UNIT);
   }
   if (real) {
-    const i64 *r = t.val + rf * t.W;
+    const li64 *r = t.val + rf * t.W;
     const double d = (double)dn;
     for (int j = 0; j < nvar; j++) {
       const int q = trunc_x86((double)r[j] / d);
@@ -390,7 +397,7 @@ __device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int ncol, int 
     if (mu) ku = base + first64(mu);
     bool act = false;
     i64 lpiv = 1, fo = 0, g = 1;
-    i64 *r = t.val;
+    li64 *r = t.val;
     if (in && k != pivi && !(fl & F_UNIT)) {
       r = t.val + rfk * W;
       const i64 foo = r[pivj], oden = t.den[k];
@@ -405,7 +412,7 @@ __device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int ncol, int 
       if (fff != F_ZERO && fff != fl) t.flag[k] = fl == F_ZERO ? (fff == F_MINUS ? F_UNKNOWN : fff) : F_UNKNOWN;
     }
     if (__ballot(act)) {
-      const i64 *prow = t.val + pslot * W;
+      const li64 *prow = t.val + pslot * W;
       // operands below 2^31: a product is below 2^62 and the difference of two fits, no check needed
       const bool small = fits32(lpiv) && fits32(fo) && fits32(dpiv);
 #pragma unroll 4
@@ -592,7 +599,7 @@ __device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int d
 
 // the tableau "context (+ one more row)" of compa_test / the context test (traiter.c:196-233,
 // maind.c:196-203): nparm unit rows, the nc context rows, `extra` as the last row
-__device__ __forceinline__ int build_sub(Tab &s, const i64 *ctx, int CW, int nparm, int nc, bool has_extra, i64 extra,
+__device__ __forceinline__ int build_sub(Tab &s, const li64 *ctx, int CW, int nparm, int nc, bool has_extra, i64 extra,
                                          int lane) {
   const int ni = nc + (has_extra ? 1 : 0);
   if (nparm + ni > s.rows_cap || ni > s.slots_cap) return -1;
@@ -632,9 +639,9 @@ __device__ __forceinline__ void tape_put(Tape &tp, int at, int kind, i64 a, i64 
 }
 
 // integrer.c:230-254 has_cut on the context rows; cut = constant | parameters | divisor (uniform code)
-__device__ bool ctx_has_cut(const i64 *ctx, int CW, int nr, int nparm, int p, const i64 *cut) {
+__device__ bool ctx_has_cut(const li64 *ctx, int CW, int nr, int nparm, int p, const li64 *cut) {
   for (int row = 0; row < nr; row++) {
-    const i64 *v = ctx + row * CW;
+    const li64 *v = ctx + row * CW;
     if (v[p] != cut[1 + nparm]) continue;
     if (v[nparm] != cut[0]) continue;
     int col;
@@ -664,42 +671,43 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   const int lane = w.lane;
 
   // ---- LDS carve-up: [main: den | val | ctx | flag | ref | state] [sub: den | val | det | flag | ref] [cutv]
-  unsigned char *q = smem;
+  LDS unsigned char *q = (LDS unsigned char *)smem;
+  LDS unsigned char *const q0 = q;
   Tab M, S;
-  M.den = (i64 *)q;
+  M.den = (li64 *)q;
   q += 8 * (size_t)cap.R;
-  M.val = (i64 *)q;
+  M.val = (li64 *)q;
   q += 8 * (size_t)cap.S * cap.W;
-  i64 *ctx = (i64 *)q;
+  li64 *ctx = (li64 *)q;
   q += 8 * (size_t)cap.CR * cap.CW;
-  M.flag = (int *)q;
+  M.flag = (lint *)q;
   q += 4 * (size_t)cap.R;
-  M.ref = (int *)q;
+  M.ref = (lint *)q;
   q += 4 * (size_t)cap.R;
-  QState *st = (QState *)q;
+  LDS QState *st = (LDS QState *)q;
   q += sizeof(QState);
-  const size_t main_words = (size_t)(q - smem) / 8;
+  const size_t main_words = (size_t)(q - q0) / 8;
   M.ldet = &st->ldet;
   M.det = st->det;
   M.W = cap.W;
   M.rows_cap = cap.R;
   M.slots_cap = cap.S;
-  S.den = (i64 *)q;
+  S.den = (li64 *)q;
   q += 8 * (size_t)cap.SR;
-  S.val = (i64 *)q;
+  S.val = (li64 *)q;
   q += 8 * (size_t)cap.SS * cap.CW;
-  S.det = (i64 *)q;
+  S.det = (li64 *)q;
   q += 8 * MAXDET;
-  S.flag = (int *)q;
+  S.flag = (lint *)q;
   q += 4 * (size_t)cap.SR;
-  S.ref = (int *)q;
+  S.ref = (lint *)q;
   q += 4 * (size_t)cap.SR;
-  S.ldet = (int *)q;
+  S.ldet = (lint *)q;
   q += 8;
   S.W = cap.CW;
   S.rows_cap = cap.SR;
   S.slots_cap = cap.SS;
-  i64 *cutv = (i64 *)q;  // [CW + 2]
+  li64 *cutv = (li64 *)q;  // [CW + 2]
 
   i64 *my_stack = stack + (size_t)pi * cap.depth * main_words;
   Tape tape;
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   int result = Q_DONE;
 
   // ---- load: zero the main image, rows Unknown with denominator 1 under nvar unit rows (tab.c:158-248)
-  for (size_t k = lane; k < main_words; k += 64) ((i64 *)smem)[k] = 0;
+  for (size_t k = lane; k < main_words; k += 64) ((li64 *)q0)[k] = 0;
   wsync();
   {
     const int ncol = nvar + nparm + 1;
@@ -744,13 +752,13 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   wsync();
   if (cap.simplify && P.nq) {  // tab_simplify (tab.c:396-427, maind.c:190-196), a row per lane
     for (int pass = 0; pass < 2; pass++) {
-      i64 *rows = pass ? ctx : M.val;
+      li64 *rows = pass ? ctx : M.val;
       const int nrows = pass ? nc : ni, stride = pass ? CW : W, width = pass ? nparm + 1 : nvar + nparm + 1;
       const int cst = pass ? nparm : nvar;
       for (int base = 0; base < nrows; base += 64) {
         const int k = base + lane;
         if (k < nrows) {
-          i64 *r = rows + k * stride;
+          li64 *r = rows + k * stride;
           i64 g = 0;
           for (int j = 0; j < width; j++) {
             if (j == cst) continue;
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
             wsync();
             {
               i64 *dst = my_stack + (size_t)sp * main_words;
-              for (size_t k = lane; k < main_words; k += 64) dst[k] = ((const i64 *)smem)[k];
+              for (size_t k = lane; k < main_words; k += 64) dst[k] = ((const li64 *)q0)[k];
               sp++;
             }
             wsync();
@@ -1076,7 +1084,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
         sp--;
         const i64 *src = my_stack + (size_t)sp * main_words;
         wsync();
-        for (size_t k = lane; k < main_words; k += 64) ((i64 *)smem)[k] = src[k];
+        for (size_t k = lane; k < main_words; k += 64) ((li64 *)q0)[k] = src[k];
         wsync();
         nvar = st->nvar;
         nparm = st->nparm;
