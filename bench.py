@@ -211,8 +211,9 @@ class Lanes:
             self.lanes.append((e, b, lane_stream(torch, dev, i)))
         self.stagger = 0.0
         self.done = [0] * depth
+        self.workers, self.share, self.failed = None, None, None
 
-    def _lane(self, i, nsteps):
+    def _lane_steps(self, i, nsteps):
         _, bi, st = self.lanes[i]
         # lanes start a fraction of a step apart, so that one batch's under-filled last launch
         # coincides with another batch's bulk launch instead of with its last launch
@@ -225,15 +226,47 @@ class Lanes:
             st.synchronize()
         self.done[i] += nsteps
 
+    def _worker(self, i):
+        """lane i's host thread, alive for the life of the Lanes: starting a Python thread costs ~0.1 ms, which a
+        20-step timed region of a few tens of milliseconds would see 10-20 times over"""
+        while True:
+            self.go.wait()
+            if self.share is None:
+                return
+            try:
+                if self.share[i]:
+                    self._lane_steps(i, self.share[i])
+            except BaseException as ex:  # surfaced by run()
+                self.failed = ex
+            self.fin.wait()
+
     def run(self, nsteps):
         d = self.depth
-        share = [nsteps // d + (1 if i < nsteps % d else 0) for i in range(d)]
-        th = [threading.Thread(target=self._lane, args=(i, share[i])) for i in range(d) if share[i]]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        return share
+        if self.workers is None:
+            self.go, self.fin = threading.Barrier(d + 1), threading.Barrier(d + 1)
+            self.workers = [threading.Thread(target=self._worker, args=(i,), daemon=True) for i in range(d)]
+            for t in self.workers:
+                t.start()
+        self.share = [nsteps // d + (1 if i < nsteps % d else 0) for i in range(d)]
+        self.go.wait()   # releases every lane at once
+        self.fin.wait()  # every lane has synchronised its stream
+        if self.failed is not None:
+            raise self.failed
+        return self.share
+
+    def close(self):
+        if self.workers is not None:
+            self.share = None
+            self.go.wait()
+            for t in self.workers:
+                t.join()
+            self.workers = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def totals(self, share):
         """pivots, cuts, rows rewritten, tableaux, finished tableaux of `share[i]` steps of lane i"""
@@ -372,9 +405,12 @@ def main():
         cfg = dict(MAIN)
         cfg["batch"] = args.batch
         if scaling == "strong":
-            # BASELINE configs[3]: every 10k-tableau batch is sharded over the GPUs.  A GPU then holds
-            # 1/world of every batch in flight, so world x as many batches are kept in flight
-            depth = lane_count(args.pipeline * world, args.steps)
+            # BASELINE configs[3]: every 10k-tableau batch is sharded over the GPUs.  A GPU then holds 1/world
+            # of every batch in flight.  Shards below ~4,000 tableaux want twice the batches in flight, not
+            # world x as many (one MI355X, 16 host CPUs: a 1,250-tableau shard runs at 254 M pivots/s with 24
+            # batches in flight, 149 M with 96; 2,500: 270 M with 12-16; 5,000: 346 M with 12)
+            shard = (args.batch + world - 1) // world
+            depth = lane_count(args.pipeline * (2 if shard < 2000 else 1), args.steps)
             lo, hi = pdist.shard_range(args.batch, rank, world)
             cfg["batch"] = hi - lo
             seeds = [1000 + 7919 * i for i in range(depth)]
@@ -404,6 +440,7 @@ def main():
     if world > 1:  # the other scaling mode, same steps (every rank takes part)
         mode2 = "weak" if args.scaling == "strong" else "strong"
         rows_keep = b.rows
+        lanes.close()
         del lanes
         torch.cuda.empty_cache()
         cfg2, lanes2, depth2, _, _ = build_lanes(mode2)
@@ -411,6 +448,7 @@ def main():
         gt2, dt2_max = pdist.gather_totals(lanes2.totals(share2), dt2, dev)
         other = {"scaling": mode2, "value": gt2[0] / dt2_max, "unit": "pivots/s", "ms_per_step": dt2_max / args.steps * 1e3,
                  "batch_per_gpu": cfg2["batch"], "pipeline_depth": depth2, "problems_per_sec": gt2[3] / dt2_max}
+        lanes2.close()
         del lanes2
         torch.cuda.empty_cache()
         lanes = None
@@ -493,6 +531,8 @@ def main():
 
     if not args.no_others and world == 1:
         # one batch at a time (what a caller gets from a single pipamd_batch_load + pipamd_batch_solve)
+        if lanes is not None:
+            lanes.close()
         del lanes
         torch.cuda.empty_cache()
         one = Lanes(cfg, 1, dev, local, seeds[:1], args, gen)  # a fresh engine with its defaults for a lone batch
@@ -501,6 +541,7 @@ def main():
         t1 = one.totals(sh1)
         out["pipeline1_value"] = t1[0] / dt1
         out["pipeline1_ms_per_step"] = dt1 / n1 * 1e3
+        one.close()
         del one
         torch.cuda.empty_cache()
         others = []
@@ -529,6 +570,8 @@ def main():
                 "finished_fraction": ot[4] / max(1, ot[3]),
                 "pipeline1_value": ot1[0] / odt1, "pipeline1_ms_per_step": odt1 / 16 * 1e3,
                 "roofline": roofline_of(ob, oe, okm, oc)})
+            ol.close()
+            o1.close()
             del ol, o1
             torch.cuda.empty_cache()
         out["other_configs"] = others

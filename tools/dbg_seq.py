@@ -30,5 +30,6 @@ for item in sys.argv[1:]:
     tot = lanes.totals(share)
     print(f"{cfg['key']} depth {depth}: {tot[0] / dt / 1e6:.1f} Mpiv/s  {dt / steps * 1e3:.3f} ms/step  stagger {lanes.stagger*1e3:.3f} ms", flush=True)
     last = lanes.lanes[0]
+    lanes.close()
     del lanes
     torch.cuda.empty_cache()
