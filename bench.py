@@ -203,6 +203,9 @@ class Lanes:
             if tw:
                 e.set_tail_waves(tw)
             e.set_timing(False)  # no HIP events in the timed region (kernel_ms_of switches them on)
+            bw = getattr(args, "blocking_wait", -1)
+            if bw > 0 or (bw < 0 and depth > host_cpus()):  # more polling threads than CPUs only take turns
+                e.set_blocking_wait(True)
             bulk_min = args.bulk_min if args.bulk_min > 0 else (256 if depth > 1 else 0)  # depth = this Lanes' lane count
             if bulk_min:
                 e.set_bulk_min(bulk_min)
@@ -281,6 +284,18 @@ class Lanes:
             tot[3] += n * b.desc.batch
             tot[4] += n * c["finished"]
         return tot
+
+
+def host_cpus():
+    """CPUs this process may use: the affinity mask, capped by the container's cgroup quota"""
+    n = max(1, len(os.sched_getaffinity(0)))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def lane_count(pipeline, steps):
@@ -365,6 +380,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (streams/threads)")
     ap.add_argument("--stagger", type=float, default=0.0,
                     help="ms between the lanes' starts (0 = none, <0 = step latency / lanes, measured in warm-up)")
+    ap.add_argument("--blocking-wait", type=int, default=-1,
+                    help="1: host threads sleep while the device works, 0: they poll; -1: sleep when there are more lanes than CPUs")
     ap.add_argument("--no-dense", action="store_true", help="skip the row-skipping-off measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-others", action="store_true", help="skip other_configs and pipeline1_value")
@@ -406,11 +423,12 @@ def main():
         cfg["batch"] = args.batch
         if scaling == "strong":
             # BASELINE configs[3]: every 10k-tableau batch is sharded over the GPUs.  A GPU then holds 1/world
-            # of every batch in flight.  Shards below ~4,000 tableaux want twice the batches in flight, not
-            # world x as many (one MI355X, 16 host CPUs: a 1,250-tableau shard runs at 254 M pivots/s with 24
-            # batches in flight, 149 M with 96; 2,500: 270 M with 12-16; 5,000: 346 M with 12)
+            # of every batch in flight.  Shards below 4,000 tableaux want twice the batches in flight, not
+            # world x as many (one MI355X, 16 host CPUs, host threads napping instead of spinning: a 1,250-tableau
+            # shard runs at 262 M pivots/s with 24 batches in flight, 240 M with 48; 2,500: 304 M with 24,
+            # 278 M with 16; 5,000: 350 M with 12)
             shard = (args.batch + world - 1) // world
-            depth = lane_count(args.pipeline * (2 if shard < 2000 else 1), args.steps)
+            depth = lane_count(args.pipeline * (2 if shard < 4000 else 1), args.steps)
             lo, hi = pdist.shard_range(args.batch, rank, world)
             cfg["batch"] = hi - lo
             seeds = [1000 + 7919 * i for i in range(depth)]

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "pip_host.h"
 
@@ -235,7 +236,14 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
     rc = launch(tail_waves, e->iter_limit, lay.S, upper);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (e->blocking_wait) {  // sleep between looks at the stream instead of spinning on it (pipamd_engine_set_blocking_wait)
+      hipError_t q;
+      const struct timespec nap = {0, 40000};
+      while ((q = hipStreamQuery(st)) == hipErrorNotReady) nanosleep(&nap, nullptr);
+      HIPCHK(q);
+    } else {
+      HIPCHK(hipStreamSynchronize(st));
+    }
     if (e->h_run[0] <= 0 || e->single_launch) break;
     upper = e->h_run[0];
   }
@@ -286,6 +294,11 @@ extern "C" int pipamd_engine_set_tail_waves(pipamd_engine *e, int waves) {
   return PIPAMD_OK;
 }
 
+extern "C" int pipamd_engine_set_blocking_wait(pipamd_engine *e, int on) {
+  if (!e) return PIPAMD_E_INVALID;
+  e->blocking_wait = on ? 1 : 0;
+  return PIPAMD_OK;
+}
 extern "C" int pipamd_engine_set_device_tree(pipamd_engine *e, int on) {
   if (!e) return PIPAMD_E_INVALID;
   e->no_device_tree = on ? 0 : 1;

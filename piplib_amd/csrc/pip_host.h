@@ -25,6 +25,7 @@ struct pipamd_engine {
   int iter_limit;
   int waves_per_job; /* 0 = choose by batch size */
   int tail_waves;    /* waves per tableau of the tail launch when waves_per_job is 0 (0 = default 4) */
+  int blocking_wait;   /* 1: pipamd_batch_solve naps between looks at its stream instead of spinning on it */
   int no_device_tree; /* 1: pipamd_solve_tableaux_lockstep skips the device-resident traiter() (pip_quast.hip) */
   void *dt_buf[8];     /* device tree: device buffers kept between calls (problems, rows, stacks, tapes, results, ...) */
   size_t dt_cap[8];

@@ -94,6 +94,10 @@ class Engine:
         _check(lib().pipamd_last_device_tree(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_blocking_wait(self, on):
+        lib().pipamd_engine_set_blocking_wait.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().pipamd_engine_set_blocking_wait(self._h, int(bool(on))))
+
     def set_tail_waves(self, n):
         lib().pipamd_engine_set_tail_waves.argtypes = [C.c_void_p, C.c_int]
         _check(lib().pipamd_engine_set_tail_waves(self._h, int(n)))
