@@ -638,22 +638,39 @@ __device__ __forceinline__ void tape_put(Tape &tp, int at, int kind, i64 a, i64 
   }
 }
 
-// integrer.c:230-254 has_cut on the context rows; cut = constant | parameters | divisor (uniform code)
-__device__ bool ctx_has_cut(const li64 *ctx, int CW, int nr, int nparm, int p, const li64 *cut) {
-  for (int row = 0; row < nr; row++) {
-    const li64 *v = ctx + row * CW;
-    if (v[p] != cut[1 + nparm]) continue;
-    if (v[nparm] != cut[0]) continue;
-    int col;
-    for (col = p + 1; col < nparm; col++)
-      if (v[col] != 0) break;
-    if (col < nparm) continue;
-    for (col = 0; col < p; col++)
-      if (v[col] != cut[1 + col]) break;
-    if (col < p) continue;
-    return true;
+// Which parameter, if any, is already the quotient a parametric cut needs (find_parm, integrer.c:258-291)?
+// Parameter p is floor(-(c . (1, params)) / D) when the context holds the two rows that defined it
+// (integrer.c:156-227): +(c_params | D at p | c0 + D - 1) and -(c_params | D at p | c0), nothing right of p.
+// cutv = c0 | c_params | D in LDS; a lane per context row; the highest such p, -1 if none.
+__device__ __forceinline__ int find_quotient(const li64 *ctx, int CW, int nc, int nparm, const li64 *cutv, int lane,
+                                             int &bad) {
+  if (cutv[nparm] != 0) return -1;  // the last parameter takes part in the cut: it cannot be the quotient's
+  const i64 c0 = cutv[0], D = cutv[1 + nparm];
+  const i64 cplus = csub(cadd(c0, D, bad), 1, bad), cminus = cneg(c0, bad), Dm = cneg(D, bad);
+  for (int p = nparm - 1; p >= 0; --p) {
+    if (cutv[1 + p] != 0) break;
+    u64 has_plus = 0, has_minus = 0;
+    for (int base = 0; base < nc; base += 64) {
+      const int k = base + lane;
+      bool mp = k < nc, mm = mp;
+      if (mp) {
+        const li64 *v = ctx + k * CW;
+        for (int col = 0; col < p; col++) {
+          const i64 a = v[col], c = cutv[1 + col];
+          mp = mp && a == c;
+          mm = mm && a == cneg(c, bad);
+        }
+        bool tail = true;
+        for (int col = p + 1; col < nparm; col++) tail = tail && v[col] == 0;
+        mp = mp && tail && v[p] == D && v[nparm] == cplus;
+        mm = mm && tail && v[p] == Dm && v[nparm] == cminus;
+      }
+      has_plus |= __ballot(mp);
+      has_minus |= __ballot(mm);
+    }
+    if (has_plus && has_minus) return p;
   }
-  return false;
+  return -1;
 }
 
 __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const i64 *input, i64 *stack, i64 *cells,
@@ -929,43 +946,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
               if (lane >= nvar && lane < ncol) cutv[lane - nvar] = c;
               if (lane == 0) cutv[1 + nparm] = D;
               wsync();
-              int parm = -1;
-              if (cutv[1 + nparm - 1] == 0) {  // integrer.c:258-291 find_parm (uniform code on LDS)
-                // the function edits cut[0] in place; here on a local copy, published before each has_cut
-                i64 c0 = csub(cadd(cutv[0], D, w.bad), 1, w.bad);
-                for (int p = nparm - 1; p >= 0; --p) {
-                  if (cutv[1 + p] != 0) break;
-                  wsync();
-                  if (lane == 0) cutv[0] = c0;
-                  wsync();
-                  if (!ctx_has_cut(ctx, CW, nc, nparm, p, cutv)) continue;
-                  c0 = csub(cadd(c0, 1, w.bad), D, w.bad);
-                  wsync();
-                  {
-                    const i64 old = lane <= nparm + 1 ? cutv[lane] : 0;
-                    wsync();
-                    if (lane <= nparm + 1) cutv[lane] = lane == 0 ? cneg(c0, w.bad) : cneg(old, w.bad);
-                  }
-                  wsync();
-                  const bool found = ctx_has_cut(ctx, CW, nc, nparm, p, cutv);
-                  wsync();
-                  {
-                    const i64 old = lane <= nparm + 1 ? cutv[lane] : 0;
-                    wsync();
-                    if (lane <= nparm + 1) cutv[lane] = lane == 0 ? c0 : cneg(old, w.bad);
-                  }
-                  wsync();
-                  if (found) {
-                    parm = p;
-                    break;
-                  }
-                  c0 = csub(cadd(c0, D, w.bad), 1, w.bad);
-                }
-                if (parm < 0) c0 = csub(cadd(c0, 1, w.bad), D, w.bad);
-                wsync();
-                if (lane == 0) cutv[0] = c0;
-                wsync();
-              }
+              int parm = find_quotient(ctx, CW, nc, nparm, cutv, lane, w.bad);
               if (parm == -1) {
                 // integrer.c:156-227 add_parm: a new parameter q = floor(-(cut . (1,p)) / D)
                 if (nparm + 2 > CW || nc + 2 > cap.CR || ncol + 1 > W || nparm + 1 >= PIPAMD_MAXPARM ||

@@ -104,6 +104,36 @@ def test_unsimplified_inputs_vs_oracle():
         assert pb.squash(text) == pb.squash("void\n" if r.status == pb.ST_VOID else r.text)
 
 
+def _quotient_family():
+    """problems in which several unknowns need the same quotient floor(p / D): the second cut must find the
+    parameter the first one declared (find_parm, integrer.c:258-291) instead of declaring it again (a build with
+    a counter saw 70 such finds over the family, and none in the random families above)"""
+    def prob(rows, ctx, nvar, nparm):
+        rows = np.array(rows, dtype=np.int64)
+        ctx = np.array(ctx, dtype=np.int64).reshape(-1, nparm + 1)
+        return pb.Problem(nvar, nparm, rows.shape[0], ctx.shape[0], -1, 1, rows, ctx)
+    out = []
+    for D in (2, 3, 4, 5, 7):
+        for shift in (0, 1, 2):
+            # D x1 >= p + shift, D x2 >= p + shift [, D x3 >= p + shift]
+            out.append(prob([[D, 0, -shift, -1], [0, D, -shift, -1]], [[1, 0]], 2, 1))
+            out.append(prob([[D, 0, 0, -shift, -1], [0, D, 0, -shift, -1], [0, 0, D, -shift, -1]], [[1, 0]], 3, 1))
+        # two parameters, one quotient shared by two unknowns and another one on its own
+        out.append(prob([[D, 0, 0, 0, -1, 0], [0, D, 0, 0, -1, 0], [0, 0, 3, 0, 0, -1], [-1, 0, 3, 1, 0, -1]],
+                        [[1, 0, 0], [0, 1, 0]], 3, 2))
+        out.append(prob([[D, 0, 0, -1, -1], [0, D, 0, -1, -1], [1, 1, -3, 0, 0]], [[1, 0, 0], [0, 1, 0]], 2, 2))
+    return out
+
+
+def test_quotient_parameter_found_again():
+    keep = _screen(_quotient_family())
+    assert len(keep) >= 35
+    # the family does what it is for: fewer parameters declared than rows cut in at least most problems
+    assert sum(r.text.count("newparm") == 1 for _, r in keep) >= 10
+    served, back = _check(keep, 1.0)
+    assert back == 0
+
+
 def test_overflowing_problems_are_handed_back():
     """coefficients that overflow 64 bits: the device tree must notice (it computes on true integers)
     and the fallback reproduces the reference's wrap-around / "Integer overflow" behaviour"""
