@@ -56,16 +56,19 @@ def _check(keep, min_served, deepest=False):
     return served, back
 
 
-@pytest.mark.parametrize("seed,shape,nq,count,served", [
-    (141, (5, 2, 7, 2), 1, 120, 0.9), (142, (4, 3, 6, 3), 1, 120, 0.9), (143, (6, 1, 8, 1), 1, 120, 0.9),
-    (144, (16, 3, 20, 3), 1, 60, 0.6), (145, (8, 2, 10, 2), 0, 120, 0.9), (146, (6, 0, 9, 0), 1, 120, 0.9),
-    (147, (10, 4, 14, 1), 1, 60, 0.6), (148, (3, 5, 6, 4), 1, 120, 0.8)])
-def test_random_problems_vs_oracle(seed, shape, nq, count, served):
+@pytest.mark.parametrize("seed,shape,nq,count,served,cmax", [
+    (141, (5, 2, 7, 2), 1, 120, 0.9, 4), (142, (4, 3, 6, 3), 1, 120, 0.9, 4), (143, (6, 1, 8, 1), 1, 120, 0.9, 4),
+    (144, (16, 3, 20, 3), 1, 60, 0.6, 4), (145, (8, 2, 10, 2), 0, 120, 0.9, 4), (146, (6, 0, 9, 0), 1, 120, 0.9, 4),
+    (147, (10, 4, 14, 1), 1, 60, 0.6, 4), (148, (3, 5, 6, 4), 1, 120, 0.8, 4),
+    # more than 64 logical rows (two passes of every lane-per-row loop) and tableaux 60+ columns wide; entries of
+    # magnitude 1 (with 4 three quarters of such problems leave 64 bits and are handed back)
+    (149, (30, 2, 45, 2), 0, 40, 0.5, 1), (150, (50, 3, 40, 2), 0, 40, 0.3, 1), (157, (28, 1, 44, 1), 1, 30, 0.3, 1)])
+def test_random_problems_vs_oracle(seed, shape, nq, count, served, cmax):
     """integer and rational solves, with and without parameters / context rows.  (Unscreened random
     16x20 problems run to hundreds of cuts and new parameters; a quarter of them overflow 64 bits --
     the reference wraps -- and are handed back, hence the lower share asked of the device tree there.)"""
     from piplib_amd import synth
-    keep = _screen(synth.random_problems(seed, count, *shape, nq))
+    keep = _screen(synth.random_problems(seed, count, *shape, nq, cmax=cmax))
     assert len(keep) >= 0.4 * count  # (the 10x14 family has many problems the reference itself does not finish)
     _check(keep, served)
 
