@@ -43,6 +43,7 @@ extern "C" int pipamd_engine_create(pipamd_engine **out, int device) {
   if (!e) return PIPAMD_E_NOMEM;
   e->device = device;
   e->iter_limit = 1 << 20;
+  pthread_mutex_init(&e->dt_lock, nullptr);
   *out = e;
   return PIPAMD_OK;
 }
@@ -56,6 +57,7 @@ extern "C" void pipamd_engine_destroy(pipamd_engine *e) {
   for (void *b : e->dt_buf)
     if (b) hipFree(b);
   if (e->dt_host) hipHostFree(e->dt_host);
+  pthread_mutex_destroy(&e->dt_lock);
   free(e);
 }
 

@@ -2,6 +2,7 @@
 #ifndef PIP_HOST_H
 #define PIP_HOST_H
 #include <hip/hip_runtime.h>
+#include <pthread.h>
 
 #include "pip_job.h"
 
@@ -29,6 +30,7 @@ struct pipamd_engine {
   int no_device_tree; /* 1: pipamd_solve_tableaux_lockstep skips the device-resident traiter() (pip_quast.hip) */
   void *dt_buf[8];     /* device tree: device buffers kept between calls (problems, rows, stacks, tapes, results, ...) */
   size_t dt_cap[8];
+  pthread_mutex_t dt_lock; /* the device-tree buffers below serve one call at a time */
   void *dt_host;       /* device tree: pinned staging buffer for the problems' rows */
   size_t dt_host_cap;
   int dt_served, dt_fallback; /* problems the device tree finished / handed back in the last lock-step call */

@@ -880,6 +880,10 @@ void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) { simplify
 // of this file): true when it was served there (tape / is_void / pivots filled), false: use the host tree.
 static bool device_tree_one(pipamd_engine *e, const pipamd_problem &p, int simplify, int deepest_cut, int qflags,
                             std::vector<Cell> &tape, bool *is_void, int64_t *pivots);
+// The same for many problems: fills the outputs of every problem it serves and marks it in `served`.
+static void device_tree_many(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
+                             std::vector<char> &served, pipamd_sol_cell **cells, size_t *n_cells, int *rcs, int *statuses,
+                             int64_t *pivots);
 
 // the tape as the C ABI hands it out: (kind, param1, param2) cells, sol.c:52-59
 static int export_tape(const std::vector<Cell> &tape, pipamd_sol_cell **cells, size_t *n_cells) {
@@ -1077,6 +1081,9 @@ extern "C" int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_probl
     if (statuses) statuses[i] = 0;
     if (pivots) pivots[i] = 0;
   }
+  std::vector<char> served(n > 0 ? n : 1, 0);
+  if (hipSetDevice(e->device) == hipSuccess)  // small problems: wholly on the device, in one launch
+    device_tree_many(e, n, probs, simplify, deepest_cut, served, cells, n_cells, rcs, statuses, pivots);
   std::atomic<int> next(0);
   const int device = e->device;
   auto worker = [&]() {
@@ -1086,6 +1093,7 @@ extern "C" int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_probl
       for (;;) {
         const int i = next.fetch_add(1);
         if (i >= n) break;
+        if (served[i]) continue;
         const pipamd_problem &p = probs[i];
         int st = 0;
         int64_t pv = 0;
@@ -1924,6 +1932,11 @@ void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipa
 
 void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut, std::vector<FResult> &res,
                  int *served, int *handed_back, int qflags = 0) {
+  struct Hold {  // the engine's device-tree buffers serve one call at a time
+    pthread_mutex_t *m;
+    explicit Hold(pthread_mutex_t *mm) : m(mm) { pthread_mutex_lock(m); }
+    ~Hold() { pthread_mutex_unlock(m); }
+  } hold(&e->dt_lock);
   // chunks of problems whose stack + tape regions fit the budget (PIPAMD_FOREST_ARENA_MB, default 8192)
   size_t budget = (size_t)8192 << 20;
   if (const char *mb = getenv("PIPAMD_FOREST_ARENA_MB")) budget = (size_t)strtoull(mb, nullptr, 10) << 20;
@@ -1977,6 +1990,25 @@ static bool device_tree_one(pipamd_engine *e, const pipamd_problem &p, int simpl
   *is_void = res[0].is_void;
   *pivots = res[0].pivots;
   return true;
+}
+
+static void device_tree_many(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
+                             std::vector<char> &served, pipamd_sol_cell **cells, size_t *n_cells, int *rcs, int *statuses,
+                             int64_t *pivots) {
+  e->dt_served = e->dt_fallback = 0;
+  if (e->no_device_tree || getenv("PIPAMD_NO_DEVICE_TREE") || n <= 0) return;
+  std::vector<FResult> res(n);
+  for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;
+  device_tree(e, n, probs, simplify, deepest_cut, res, &e->dt_served, &e->dt_fallback);
+  for (int i = 0; i < n; i++) {
+    if (res[i].rc != PIPAMD_OK) continue;
+    served[i] = 1;
+    cells[i] = nullptr;
+    n_cells[i] = 0;
+    if (statuses) statuses[i] = 0;
+    if (pivots) pivots[i] = res[i].pivots;
+    rcs[i] = res[i].is_void ? PIPAMD_OK : export_tape(res[i].tape, &cells[i], &n_cells[i]);
+  }
 }
 
 // Many problems: the device tree first (small problems), then the lock-step Forest; the few that need

@@ -288,16 +288,22 @@ def test_many_parametric_problems_multithreaded():
                 keep.append(p)
         except subprocess.TimeoutExpired:
             pass
-    e = eng.Engine(0)
-    many = eng.solve_tableaux(e, keep, nthreads=8)
-    # the lock-step scheduler (one launch per step for all problems) must agree entry by entry
-    assert eng.solve_tableaux(e, keep, lockstep=True) == many
-    for p, (text, rc, st, piv) in zip(keep, many):
-        try:
-            t1, p1 = eng.solve_tableau(e, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx)
-            assert rc == 0 and text == t1 and piv == p1
-        except eng.SolverError as ex:
-            assert rc == -5 and st == ex.status
+    first = None
+    for device_tree in (False, True):  # the host schedulers alone, then with the device-resident traiter() in front
+        e = eng.Engine(0)
+        e.set_device_tree(device_tree)
+        many = eng.solve_tableaux(e, keep, nthreads=8)
+        assert (e.last_device_tree()[0] > 0) == device_tree
+        # the lock-step scheduler (one launch per step for all problems) must agree entry by entry
+        assert eng.solve_tableaux(e, keep, lockstep=True) == many
+        for p, (text, rc, st, piv) in zip(keep, many):
+            try:
+                t1, p1 = eng.solve_tableau(e, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx)
+                assert rc == 0 and text == t1 and piv == p1
+            except eng.SolverError as ex:
+                assert rc == -5 and st == ex.status
+        assert first is None or many == first
+        first = many
 
 
 @pytest.mark.parametrize("seed", [51, 52, 53])
