@@ -209,8 +209,11 @@ class Lanes:
             bulk_min = args.bulk_min if args.bulk_min > 0 else (256 if depth > 1 else 0)  # depth = this Lanes' lane count
             if bulk_min:
                 e.set_bulk_min(bulk_min)
+            # the input rows stay resident and untouched in HBM for the whole run: T_ROWS_STAY lets the first pivot
+            # launch read them where they are instead of a copy pass (--copy-rows switches that off)
+            stay = 0 if getattr(args, "copy_rows", False) else eng.T_ROWS_STAY
             b = eng.Batch(e, torch.as_tensor(gen(seeds[i]), dtype=torch.int64).to(dev), cfg["nvar"], 0,
-                          tflags=eng.T_INT if cfg["integer"] else 0, entier_bits=cfg["ebits"])
+                          tflags=(eng.T_INT if cfg["integer"] else 0) | stay, entier_bits=cfg["ebits"])
             self.lanes.append((e, b, lane_stream(torch, dev, i)))
         self.stagger = 0.0
         self.done = [0] * depth
@@ -382,6 +385,7 @@ def main():
                     help="ms between the lanes' starts (0 = none, <0 = step latency / lanes, measured in warm-up)")
     ap.add_argument("--blocking-wait", type=int, default=-1,
                     help="1: host threads sleep while the device works, 0: they poll; -1: sleep when there are more lanes than CPUs")
+    ap.add_argument("--copy-rows", action="store_true", help="load copies the input rows into the job blocks (no PIPAMD_T_ROWS_STAY)")
     ap.add_argument("--no-dense", action="store_true", help="skip the row-skipping-off measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-others", action="store_true", help="skip other_configs and pipeline1_value")

@@ -48,6 +48,11 @@ extern "C" {
 #define PIPAMD_T_DEEPEST 512 /* deepest-cut option (integrer.c:417-438) */
 #define PIPAMD_T_NOSKIP 2048 /* measurement aid: rewrite every real row on every pivot, as the
                                reference's loop does (traiter.c:467-502); results are identical */
+#define PIPAMD_T_ROWS_STAY 8192 /* pipamd_batch_desc.tflags: the caller keeps the `rows` array of pipamd_batch_load alive
+                                  and unchanged until the batch's next pipamd_batch_solve has returned.  The load then
+                                  only builds the row tables; the first pivot launch reads the rows from the caller's
+                                  array in the pass that builds its summaries anyway (64-bit entries, an even number
+                                  of columns, a 16-byte aligned array; otherwise the rows are copied as usual). */
 #define PIPAMD_T_STATE 1024  /* a paused job's LDS summaries are saved in its state block */
 
 /* ---- per-problem status written by the engine ---- */

@@ -82,7 +82,8 @@ int pipamd_batch_layout(const pipamd_batch_desc *d, PipBatchLayout *lay, size_t 
   lay->nparm = d->nparm;
   lay->ni = d->ni;
   lay->bigparm = d->bigparm;
-  lay->tflags = d->tflags;
+  lay->tflags = d->tflags & ~(PIPAMD_T_ROWS_STAY | PIPAMD_T_FRESHROWS);  // the load sets FRESHROWS itself
+  lay->pad = 0;
   lay->S = d->ni + d->cap_cuts;
   lay->L = round_even(d->nvar + lay->S);
   lay->W = ebits == 128 ? ncol + d->cap_newparm : round_even(ncol + d->cap_newparm);
@@ -135,6 +136,9 @@ extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batc
   if (rc) return rc;
   PipJob *jobs = (PipJob *)d_ws;
   long long *arena = (long long *)((char *)d_ws + jb);
+  // PIPAMD_T_ROWS_STAY: no copy pass, the first pivot launch reads the caller's rows (whole 16-byte units)
+  const int ncol = d->nvar + d->nparm + 1;
+  lay.pad = (d->tflags & PIPAMD_T_ROWS_STAY) && lay.ebits != 128 && ncol % 2 == 0 && ((uintptr_t)d_rows & 15) == 0;
   HIPCHK(pipk_launch_batch_load(jobs, arena, (const long long *)d_rows, lay, (hipStream_t)stream));
   return PIPAMD_OK;
 }

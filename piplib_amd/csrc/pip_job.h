@@ -29,6 +29,10 @@
  *   sol_off : nvar*(nparm+1) numerators | nvar denominators
  *   state_off: LDS summaries of a paused job: nzm[S][NM] (u64) | sig[L] (u16) | rbits[L] (u8)
  * Mirrors the reference's struct T / struct L (tab.h:36-85) without pointers. */
+/* internal tflags bit: the job's rows still sit in the caller's array (src_rows); the first pivot launch
+ * reads them from there while it builds its summaries and writes them into the block (PIPAMD_T_ROWS_STAY) */
+#define PIPAMD_T_FRESHROWS 4096
+
 typedef struct PipJob {
   int64_t vals_off, rows_off, sol_off, state_off;
   int64_t log_off; /* 2 * PIPAMD_DETLOG entries: the determinant log of the last launch */
@@ -42,6 +46,7 @@ typedef struct PipJob {
   uint64_t maxabs;
   int32_t nlog, pad_; /* entries of the determinant log not replayed yet */
   int32_t state_nch, ebits; /* ebits: 64 or 128 (0 = 64) */ /* row-chunk count (NCH) of the launch that saved the state block */
+  int64_t src_rows; /* PIPAMD_T_FRESHROWS: device address of the caller's ni x ncol input rows (not yet in the block) */
 } PipJob;
 
 typedef struct PipBatchLayout {

@@ -1277,11 +1277,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     // one pass over the tableau: sign summaries, bitmaps, magnitudes, sort keys (PF rows of a
     // wave in flight at a time)
     constexpr int PF0 = NCH <= 2 ? 4 : (NCH == 4 ? 2 : 1);
+    // a job loaded with PIPAMD_T_ROWS_STAY: its rows are still in the caller's array (slot s = input row s,
+    // pitch ncol) and move into the block in this pass
+    const T *fresh = nullptr;
+    if constexpr (ET<T>::EW == 1)
+      if (tflags & PIPAMD_T_FRESHROWS) fresh = (const T *)(uintptr_t)J->src_rows;
     for (int s0 = wave; s0 < ni; s0 += NW * PF0) {
       RowRegs<T, NCH> rr[PF0];
 #pragma unroll
       for (int q = 0; q < PF0; q++)
-        if (s0 + q * NW < ni) row_load<T, NCH>(rr[q], vals + (size_t)(s0 + q * NW) * W, ncolp, lane);
+        if (s0 + q * NW < ni) {
+          const int s = s0 + q * NW;
+          row_load<T, NCH>(rr[q], fresh ? fresh + (size_t)s * ncol : vals + (size_t)s * W, ncolp, lane);
+          if (fresh) row_store<T, NCH>(rr[q], vals + (size_t)s * W, ncolp, lane);
+        }
 #pragma unroll
       for (int q = 0; q < PF0; q++) {
         const int s = s0 + q * NW;
@@ -1333,6 +1342,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       }
     }
   }
+  tflags &= ~PIPAMD_T_FRESHROWS;
   bsync<NW>();
   PROF(14);
   if (tflags & PIPAMD_T_SORT) {
@@ -2035,13 +2045,25 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
   // input rows; spare slots only need their columns beyond ncol cleared (a cut row writes its
   // first ncol columns itself, a parametric cut relies on the new column being 0 elsewhere)
   const i64 *src = rows + (size_t)b * lay.ni * ncol;
-  for (int e = tid; e < lay.ni * lay.W; e += blockDim.x) {
-    int s = e / lay.W, j = e % lay.W;
-    vals[e] = j < ncol ? (T)src[(size_t)s * ncol + j] : (T)0;
-  }
   const int pad = lay.W - ncol;
-  for (int e = tid; e < (lay.S - lay.ni) * pad; e += blockDim.x) {
-    int s = lay.ni + e / pad, j = ncol + e % pad;
+  const bool defer = lay.pad != 0 && EW == 1;  // PIPAMD_T_ROWS_STAY: the first pivot launch fetches the rows itself
+  if (!defer) {
+    // (row, column) advance with the thread stride: no division per element
+    const int ds = (int)blockDim.x / lay.W, dj = (int)blockDim.x % lay.W;
+    int s = tid / lay.W, j = tid % lay.W;
+    for (int e = tid; e < lay.ni * lay.W; e += blockDim.x) {
+      vals[e] = j < ncol ? (T)src[(size_t)s * ncol + j] : (T)0;
+      s += ds;
+      j += dj;
+      if (j >= lay.W) {
+        j -= lay.W;
+        s++;
+      }
+    }
+  }
+  const int first_pad_row = defer ? 0 : lay.ni;
+  for (int e = tid; e < (lay.S - first_pad_row) * pad; e += blockDim.x) {
+    int s = first_pad_row + e / pad, j = ncol + e % pad;
     vals[(size_t)s * lay.W + j] = 0;
   }
   if (tid == 0) {
@@ -2055,7 +2077,8 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
     J->nparm = lay.nparm;
     J->ni = lay.ni;
     J->bigparm = lay.bigparm;
-    J->tflags = lay.tflags | PIPAMD_T_SORT;
+    J->tflags = lay.tflags | PIPAMD_T_SORT | (defer ? PIPAMD_T_FRESHROWS : 0);
+    J->src_rows = defer ? (int64_t)(uintptr_t)src : 0;
     J->L = lay.L;
     J->S = lay.S;
     J->W = lay.W;

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("PIPAMD_LIB") or os.path.join(HERE, "libpipamd.so")
 ST_RUN, ST_SOLUTION, ST_NIL, ST_NEED_COMPA, ST_NEED_PARMCUT, ST_OVERFLOW, ST_CAPACITY, ST_RANGE, ST_INTERNAL, ST_MAXCOL = range(10)
 T_INT, T_DUAL = 1, 2
 T_NOSKIP = 2048
+T_ROWS_STAY = 8192  # the rows of Batch.load stay valid until the next solve: no copy pass (include/piplib_amd.h)
 
 
 class BatchDesc(C.Structure):

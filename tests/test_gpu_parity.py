@@ -477,3 +477,38 @@ def test_tree_path_many_rows(ni):
     assert o.status == pb.ST_OK
     text, piv = eng.solve_tableau(eng.Engine(0), 12, 1, ni, 2, -1, 1, ineq, ctx)
     assert pb.squash(text) == pb.squash(o.text) and piv == o.pivots
+
+
+@pytest.mark.parametrize("nvar,ni,nq,waves", [(127, 64, 1, 0), (63, 32, 0, 0), (40, 30, 1, 4), (41, 30, 1, 1), (200, 90, 1, 0)])
+def test_rows_fetched_by_the_pivot_kernel(nvar, ni, nq, waves):
+    """PIPAMD_T_ROWS_STAY: pipamd_batch_load builds only the row tables and the first pivot launch reads the rows
+    from the caller's array (bulk and four-wave launches, one and two row chunks; 41 unknowns = an even number of
+    columns, 40 = odd: there the rows are copied as usual): statuses, pivot counts and solutions as without the flag,
+    and as the oracle has them."""
+    import torch
+    from gpu_common import oracle_batch, solution_text
+    import pipbatch as pb
+    from piplib_amd import engine as eng, synth
+    rows = synth.lexmin_batch(900 + nvar, 300 if nvar < 100 else 60, nvar, ni)
+    outs = []
+    for stay in (0, eng.T_ROWS_STAY):
+        e = eng.Engine(0)
+        if waves:
+            e.set_waves_per_job(waves)
+        e.set_bulk_min(64)
+        b = eng.Batch(e, rows, nvar, 0, tflags=(eng.T_INT if nq else 0) | stay)
+        for _ in range(2):  # the second load + solve reuses the workspace
+            b.load()
+            b.solve()
+        b.fetch()
+        torch.cuda.synchronize()
+        outs.append((b.status.cpu().numpy(), b.pivots.cpu().numpy(), b.cuts.cpu().numpy(), b.sol_num.cpu().numpy(),
+                     b.sol_den.cpu().numpy()))
+    for x, y in zip(*outs):
+        assert (x == y).all()
+    st, pv, _, num, den = outs[1]
+    o = oracle_batch(rows, nvar, 0, nq).results
+    for k, r in enumerate(o):
+        assert r.status != pb.ST_ABORT and pv[k] == r.pivots
+        got = "()" if st[k] == eng.ST_NIL else pb.squash(solution_text(num[k], den[k]))
+        assert got == pb.squash(r.text), k
