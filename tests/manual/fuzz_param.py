@@ -1,4 +1,5 @@
-"""Manual GPU fuzz (not a test): random parametric problems through the host decision tree
+"""Manual GPU fuzz (not a test): random parametric problems through the device-resident traiter()
+(csrc/pip_quast.hip, in front of both many-problem entries) and through the host decision tree alone
 (lock-step forest and per-problem trees) against the CPU oracle: same sol_edit text, same pivot
 count, same abort verdict.  Usage: python tests/manual/fuzz_param.py [seconds] [seed]"""
 import os, sys, time, subprocess
@@ -11,7 +12,7 @@ import pipbatch as pb
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 e = eng.Engine(0)
-t0 = time.time(); ncase = nprob = npiv = nsplit = 0
+t0 = time.time(); ncase = nprob = npiv = nsplit = nserved = nback = 0
 while time.time() - t0 < budget:
     nvar = int(rng.integers(2, 12)); nparm = int(rng.integers(0, 5)); ni = int(rng.integers(2, 14))
     nc = int(rng.integers(0, 4)) if nparm else 0
@@ -29,8 +30,20 @@ while time.time() - t0 < budget:
             probs.append(p); want.append(r)
     if not probs:
         continue
-    for mode in ("lockstep", "threads"):
+    if nparm and rng.random() < 0.3:  # a big parameter (any parameter column)
+        bp = nvar + 1 + int(rng.integers(0, nparm))
+        probs = [pb.Problem(p.nvar, p.nparm, p.ni, p.nc, bp, p.nq, p.ineq, p.ctx) for p in probs]
+        try:
+            want = [pb.run_batch(pb.ORACLEPIP, [p], pb.F_DEEPEST if deepest else 0, timeout=4).results[0] for p in probs]
+        except subprocess.TimeoutExpired:
+            continue
+        tag += f" bigparm={bp}"
+    for mode, dt in (("lockstep", True), ("threads", True), ("lockstep", False), ("threads", False)):
+        e.set_device_tree(dt)
         got = eng.solve_tableaux(e, probs, simplify=True, deepest_cut=deepest, lockstep=(mode == "lockstep"), nthreads=4)
+        if dt and mode == "lockstep":
+            sv, bk = e.last_device_tree()
+            nserved += sv; nback += bk
         for i, ((text, rc, st, piv), r) in enumerate(zip(got, want)):
             if r.status == pb.ST_ABORT:
                 bad = rc == 0
@@ -38,10 +51,10 @@ while time.time() - t0 < budget:
                 w = "void" if r.status == pb.ST_VOID else pb.squash(r.text)
                 bad = rc != 0 or pb.squash(text or "") != w or piv != r.pivots
             if bad:
-                print(f"MISMATCH ({mode}) problem {i}:", tag, "rc", rc, "status", st, "pivots", piv, r.pivots, flush=True)
+                print(f"MISMATCH ({mode}, device tree {dt}) problem {i}:", tag, "rc", rc, "status", st, "pivots", piv, r.pivots, flush=True)
                 print(" got ", (text or "")[:300]); print(" want", r.text[:300])
                 sys.exit(1)
     ncase += 1; nprob += len(probs); npiv += sum(r.pivots for r in want); nsplit += sum("if" in r.text for r in want)
     if ncase % 10 == 0:
-        print(f"{ncase} cases, {nprob} problems ({nsplit} with splits), {npiv} pivots, {time.time()-t0:.0f} s", flush=True)
-print(f"OK: {ncase} cases, {nprob} problems ({nsplit} with splits), {npiv} pivots checked")
+        print(f"{ncase} cases, {nprob} problems ({nsplit} with splits), {npiv} pivots, device tree served {nserved} / handed back {nback}, {time.time()-t0:.0f} s", flush=True)
+print(f"OK: {ncase} cases, {nprob} problems ({nsplit} with splits), {npiv} pivots checked; device tree served {nserved}, handed back {nback}")
