@@ -56,7 +56,7 @@ while time.time() - t0 < budget:
         sys.exit(1)
     # same batch with skipping off against the int64 engine ...
     ref = eng.Batch(e, rows, nvar, 0, tflags=eng.T_INT if nq else 0, cap_cuts=600); ref.load(); ref.solve(); ref.fetch()
-    b = eng.Batch(e, rows, nvar, 0, tflags=(eng.T_INT if nq else 0) | eng.T_NOSKIP, cap_cuts=600); b.load(); b.solve(); b.fetch()
+    b = eng.Batch(e, rows, nvar, 0, tflags=(eng.T_INT if nq else 0) | eng.T_NOSKIP | eng.T_ROWS_STAY, cap_cuts=600); b.load(); b.solve(); b.fetch()  # (rows fetched by the pivot kernel where the shape allows)
     torch.cuda.synchronize()
     st, st0 = b.status.cpu().numpy(), ref.status.cpu().numpy()
     fin = st0 == eng.ST_SOLUTION
