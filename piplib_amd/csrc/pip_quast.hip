@@ -326,7 +326,9 @@ __device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int ncol, int 
     const bool in = (tied >> lane) & 1;
     if (!__ballot(in && v != 0)) continue;
     int c = first64(tied);
-    for (;;) {
+    // each round moves to a strictly smaller ratio, so at most 64 rounds on true integers; products that
+    // overflowed compare as garbage and could go round in circles: the problem is handed back then
+    for (int round = 0;; round++) {
       const i64 pc = bcast(p, c), vc = bcast(v, c);
       const i64 x = csub(cmul(pc, v, bad), cmul(vc, p, bad), bad);
       const u64 less = __ballot(in && x < 0);
@@ -334,9 +336,19 @@ __device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int ncol, int 
         tied = __ballot(in && x == 0);
         break;
       }
+      if (round >= 64 || __any(bad)) {
+        bad |= Q_WHY_OVERFLOW;
+        tied = 1ull << c;
+        break;
+      }
       c = first64(less);
     }
+    if (!tied) {  // (only with garbage from an overflow)
+      bad |= Q_WHY_OVERFLOW;
+      tied = 1ull << c;
+    }
   }
+  if (__any(bad)) return bad;
   const int pivj = first64(tied);
   const i64 pivot = bcast(p, pivj), dpiv = t.den[pivi];
   // the determinant in limbs, traiter.c:412-446 (uniform values; lane 0 publishes them).  A pivot of 1
@@ -553,7 +565,7 @@ __device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i64 c, i6
 // traiter() of a tableau without parameters, integer solve (the sub-problems of compa_test and the
 // context test): true when the first cell of its tape would not be Nil
 // Result word: bit 0 = a solution exists, bits 1..15 = reason bits (per lane), bits 16.. = pivots.
-__device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int deepest) {
+__device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int deepest, long long deadline) {
   const int ncol = nvar + 1;
   int bad = sort_rows(t, nvar, nvar + ni, lane), pivots = 0, found = 0;
   for (int guard = 0; guard < 60000 && !__any(bad); guard++) {
@@ -592,7 +604,7 @@ __device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int d
     const int pr = pivot_step(t, pivi, nvar, ncol, nvar + ni, lane);
     if (__any(pr < 0)) break;  // no positive entry in the pivot row: Nil
     bad |= pr;
-    if (guard == 59999) bad |= Q_WHY_OTHER;
+    if (guard == 59999 || wall_clock64() > deadline) bad |= Q_WHY_OTHER;  // (the deadline: see the kernel)
   }
   return found | (bad << 1) | (pivots << 16);
 }
@@ -680,6 +692,10 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   if (pi >= nprob) return;
   const QProb P = probs[pi];
   const long long t_start = wall_clock64();
+  // No problem keeps its wave for more than two seconds (wall_clock64 ticks at 100 MHz): whatever is still
+  // running then is handed back to the host schedulers.  Every loop below is bounded on its own; this bounds
+  // their product.
+  const long long deadline = t_start + 200000000ll;
   Wv w;
   w.lane = threadIdx.x;
   w.bad = 0;
@@ -796,7 +812,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
     if (sni < 0)
       w.bad |= Q_WHY_ROWS | 1024;
     else {
-      const int r = solve_plain(S, nparm, sni, lane, w.deepest);
+      const int r = solve_plain(S, nparm, sni, lane, w.deepest, deadline);
       w.bad |= (r >> 1) & 0x7fff;
       w.pivots += r >> 16;
       if (!(r & 1) && !BAD(w)) result = Q_VOID;
@@ -810,6 +826,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
     int pivi = 0, next = DECIDE;
     bool enter = true, finished = false;
     for (int guard = 0; guard < 2000000 && !finished; guard++) {
+      if (wall_clock64() > deadline) w.bad |= Q_WHY_OTHER;
       if (BAD(w)) break;
       if (next == DECIDE) {
         if (enter) {
@@ -844,7 +861,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
                 ex = lane < nparm ? cneg(vp, w.bad) : (lane == nparm ? csub(cneg(vc, w.bad), 1, w.bad) : 0);
                 sni = build_sub(S, ctx, CW, nparm, nc, true, ex, lane);
               }
-              const int r = solve_plain(S, nparm, sni, lane, w.deepest);
+              const int r = solve_plain(S, nparm, sni, lane, w.deepest, deadline);
               w.bad |= (r >> 1) & 0x7fff;
               w.pivots += r >> 16;
               can[sg] = r & 1;

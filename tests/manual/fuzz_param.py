@@ -15,13 +15,17 @@ e = eng.Engine(0)
 t0 = time.time(); ncase = nprob = npiv = nsplit = nserved = nback = 0
 while time.time() - t0 < budget:
     nvar = int(rng.integers(2, 12)); nparm = int(rng.integers(0, 5)); ni = int(rng.integers(2, 14))
+    if os.environ.get("FUZZ_BIG"):  # larger tableaux: more than 64 logical rows, up to 50 columns
+        nvar = int(rng.integers(8, 40)); nparm = int(rng.integers(0, 7)); ni = int(rng.integers(6, 50))
     nc = int(rng.integers(0, 4)) if nparm else 0
     nq = int(rng.integers(0, 2)); deepest = bool(nq and rng.random() < 0.25)
     seed = int(rng.integers(1, 1 << 30))
     cmax = int(rng.choice([2, 4, 9])); bmax = int(rng.choice([5, 12, 40]))
+    if os.environ.get("FUZZ_BIG"):
+        cmax = int(rng.choice([1, 1, 2]))
     tag = f"nvar={nvar} nparm={nparm} ni={ni} nc={nc} nq={nq} deepest={deepest} seed={seed} cmax={cmax} bmax={bmax}"
     probs, want = [], []
-    for p in synth.random_problems(seed, 24, nvar, nparm, ni, nc, nq, cmax=cmax, bmax=bmax):
+    for p in synth.random_problems(seed, 8 if os.environ.get("FUZZ_BIG") else 24, nvar, nparm, ni, nc, nq, cmax=cmax, bmax=bmax):
         try:  # some random parametric problems make the reference itself cut forever
             r = pb.run_batch(pb.ORACLEPIP, [p], pb.F_DEEPEST if deepest else 0, timeout=2).results[0]
         except subprocess.TimeoutExpired:
@@ -40,6 +44,8 @@ while time.time() - t0 < budget:
         tag += f" bigparm={bp}"
     for mode, dt in (("lockstep", True), ("threads", True), ("lockstep", False), ("threads", False)):
         e.set_device_tree(dt)
+        if os.environ.get("FUZZ_VERBOSE"):
+            print(f"[{time.time()-t0:.1f} s] {mode} device tree {dt}: {len(probs)} problems, oracle pivots {[r.pivots for r in want]}", tag, flush=True)
         got = eng.solve_tableaux(e, probs, simplify=True, deepest_cut=deepest, lockstep=(mode == "lockstep"), nthreads=4)
         if dt and mode == "lockstep":
             sv, bk = e.last_device_tree()

@@ -137,6 +137,17 @@ def test_quotient_parameter_found_again():
     assert back == 0
 
 
+@pytest.mark.timeout(180)
+def test_overflow_in_the_pivot_column_tournament_terminates():
+    """found by tests/manual/fuzz_param.py (FUZZ_BIG): products that overflow in choisir_piv's cross-multiplication
+    compare as garbage and sent the tournament round in circles for ever; now the problem is handed back"""
+    from piplib_amd import synth
+    keep = _screen(synth.random_problems(998034085, 8, 34, 6, 45, 3, 1, cmax=2, bmax=12))
+    assert len(keep) >= 2
+    served, back = _check(keep, 0.0)
+    assert back >= 1
+
+
 def test_overflowing_problems_are_handed_back():
     """coefficients that overflow 64 bits: the device tree must notice (it computes on true integers)
     and the fallback reproduces the reference's wrap-around / "Integer overflow" behaviour"""
