@@ -608,7 +608,7 @@ def main():
         except Exception as ex:  # the leg is an extra: never lose the headline line over it
             out["parametric"] = {"error": repr(ex)}
 
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:  # the CPU baseline belongs to the one-GPU line
         rows_h = gen(seeds[0]) if gen else synth.lexmin_batch(seeds[0], args.batch, cfg["nvar"], cfg["ni"])
         cb = cpu_baseline(rows_h, cfg["nvar"], cfg["ni"])
         if cb:
