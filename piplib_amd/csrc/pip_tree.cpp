@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <string>
@@ -1955,14 +1956,33 @@ void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simpl
     idx.clear();
     memset(&cap, 0, sizeof cap);
   };
+  // Problems of similar size share a launch: every problem of a launch gets the LDS image of the largest, so a
+  // batch of tiny problems with one large one among them would run at the large one's occupancy.  Size classes
+  // of 8 KB of LDS, smallest first.
+  std::vector<std::pair<int, int>> order;  // (size class, problem)
+  order.reserve(n);
   for (int i = 0; i < n; i++) {
     QCaps c;
     memset(&c, 0, sizeof c);
     if (!quast_caps(probs[i], c)) continue;
+    const size_t lds = pipk_quast_lds_bytes(&c);
+    if (lds > 64 * 1024) continue;
+    order.emplace_back((int)(lds / 8192), i);
+  }
+  std::stable_sort(order.begin(), order.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+  int cls = -1;
+  for (const auto &oc : order) {
+    const int i = oc.second;
+    QCaps c;
+    memset(&c, 0, sizeof c);
+    quast_caps(probs[i], c);
+    if (oc.first != cls) {
+      flush();
+      cls = oc.first;
+    }
     QCaps m = cap;
     quast_caps_max(m, c);
-    if (pipk_quast_lds_bytes(&m) > 64 * 1024) {  // a shape that would cost every problem of the launch its occupancy
-      if (pipk_quast_lds_bytes(&c) > 64 * 1024) continue;
+    if (pipk_quast_lds_bytes(&m) > 64 * 1024) {  // (the maxima of several shapes of one class together)
       flush();
       m = c;
     }

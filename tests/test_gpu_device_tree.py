@@ -201,3 +201,17 @@ def test_goldens_mostly_run_on_the_device():
     eng.solve_tableaux(e, probs, lockstep=True)
     served, back = e.last_device_tree()
     assert served >= 0.8 * len(probs), (served, back, len(probs))
+
+
+def test_mixed_shapes_in_one_call():
+    """problems of very different sizes in one call: launches go by size class, answers stay in input order"""
+    from piplib_amd import synth
+    probs = []
+    for seed, shape, count, cmax in ((161, (3, 1, 4, 1), 60, 4), (162, (16, 3, 20, 3), 12, 4), (163, (30, 2, 45, 2), 6, 1),
+                                     (164, (5, 2, 7, 2), 60, 4)):
+        probs += synth.random_problems(seed, count, *shape, 1, cmax=cmax)
+    rng = np.random.default_rng(7)
+    probs = [probs[i] for i in rng.permutation(len(probs))]
+    keep = _screen(probs)
+    assert len(keep) >= 100
+    _check(keep, 0.7)
