@@ -568,7 +568,7 @@ __device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i64 c, i6
 __device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int deepest, long long deadline) {
   const int ncol = nvar + 1;
   int bad = sort_rows(t, nvar, nvar + ni, lane), pivots = 0, found = 0;
-  for (int guard = 0; guard < 60000 && !__any(bad); guard++) {
+  for (int guard = 0; guard < 30000 && !__any(bad); guard++) {  // (the pivot count has 15 bits of the result word)
     const int nligne = nvar + ni;
     int pivi = first_flagged(t, F_MINUS, nligne, lane);
     if (pivi >= nligne) pivi = classify_rows(t, nvar, ncol, -1, nligne, lane);
@@ -604,7 +604,7 @@ __device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int d
     const int pr = pivot_step(t, pivi, nvar, ncol, nvar + ni, lane);
     if (__any(pr < 0)) break;  // no positive entry in the pivot row: Nil
     bad |= pr;
-    if (guard == 59999 || wall_clock64() > deadline) bad |= Q_WHY_OTHER;  // (the deadline: see the kernel)
+    if (guard == 29999 || wall_clock64() > deadline) bad |= Q_WHY_OTHER;  // (the deadline: see the kernel)
   }
   return found | (bad << 1) | (pivots << 16);
 }
