@@ -6,13 +6,17 @@
 // (traiter.c:101-159), compa_test with its two integer feasibility sub-problems per undecided row
 // (traiter.c:162-243), the forks of the quast (traiter.c:695-759; the "else" state waits on a stack in
 // HBM while the "then" branch runs), Gomory cuts with new parameters (integrer.c:156-291,305-534)
-// and the solution tape (sol.c:104-209).  Lane j owns column j of the tableau, which lives in LDS.
+// and the solution tape (sol.c:104-209).  The tableaux live in LDS.  Column work (pivot-column tournament, cut
+// vectors, tape cells) has a lane per column; row work (multipliers, elimination, row gcd, exact division,
+// sign tests, the selection sort of tab_sort_rows) has a lane per row.
 //
 // The kernel computes on true integers: every product and sum is checked, and a problem in which a
 // 64-bit operation overflows (where the reference's `long long` build wraps or exits with "Integer
 // overflow"), or that outgrows the reserved rows / columns / stack / tape, ends with Q_FALLBACK and
 // is solved again by the host tree over pip_advance_kernel, which reproduces those cases bit for
-// bit.  Whatever this kernel does finish is, cell for cell, the reference's tape.
+// bit.  Whatever this kernel does finish is, cell for cell, the reference's tape.  Every loop is bounded (the
+// pivot-column tournament too: overflowed products compare as garbage) and a problem's wave gives up after two
+// seconds at the latest.
 #include <hip/hip_runtime.h>
 
 #include "pip_job.h"
