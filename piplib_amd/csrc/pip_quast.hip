@@ -248,11 +248,20 @@ __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane) {
   }
   if (real) {
     const li64 *r = t.val + rf * t.W;
-    const double d = (double)dn;
-    for (int j = 0; j < nvar; j++) {
-      const int q = trunc_x86((double)r[j] / d);
-      const int a = q < 0 ? (int)(0u - (unsigned)q) : q;  // abs() incl. INT_MIN
-      s = s > a ? s : a;  // (double)INT_MIN never wins against s >= 0
+    if (dn == 1) {  // x / 1.0 is x, and (int)x is x itself when it fits an int (every row of a fresh tableau)
+      for (int j = 0; j < nvar; j++) {
+        const i64 v = r[j];
+        const int q = v == (i64)(int)v ? (int)v : (int)0x80000000;
+        const int a = q < 0 ? (int)(0u - (unsigned)q) : q;
+        s = s > a ? s : a;
+      }
+    } else {
+      const double d = (double)dn;
+      for (int j = 0; j < nvar; j++) {
+        const int q = trunc_x86((double)r[j] / d);
+        const int a = q < 0 ? (int)(0u - (unsigned)q) : q;  // abs() incl. INT_MIN
+        s = s > a ? s : a;  // (double)INT_MIN never wins against s >= 0
+      }
     }
   }
   const u64 realm = __ballot(real);
