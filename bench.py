@@ -537,76 +537,82 @@ def main():
     # every pivot, which is the reference's access pattern (traiter.c:467-502) and the regime
     # in which the row-update path is HBM-bound.  Reported beside the main number.
     if not args.no_dense:
-        ed = eng.Engine(local)
-        ed.set_waves_per_job(4)  # streaming regime: four waves share a tableau's rows
-        bd = eng.Batch(ed, b.rows, cfg["nvar"], 0, tflags=eng.T_INT | eng.T_NOSKIP)
-        bd.load()
-        bd.solve()
-        dk = kernel_ms_of(bd)
-        cd = bd.counters()
-        # every real row (cut rows included, counted by the kernel) is read and written once per
-        # pivot, plus the pivot-row read and the write of the row that replaces the unit row
-        dbytes = 8.0 * (cfg["nvar"] + 1) * (2.0 * cd["rows_rewritten"] + 2.0 * cd["pivots"])
-        out["roofline_dense_mode"] = {
-            "bound": "hbm", "achieved": dbytes / (dk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dbytes / (dk * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": dk, "pivots": cd["pivots"],
-            "rows_rewritten_per_pivot": cd["rows_rewritten"] / max(1, cd["pivots"]),
-            "algorithmic_bytes_per_step": dbytes,
-            "note": "same batch with row skipping disabled (PIPAMD_T_NOSKIP, 4 waves per tableau): every real row "
-                    "is read and written on every pivot, the reference's access pattern"}
-        del bd, ed
+        try:  # an extra leg never costs the headline line
+            ed = eng.Engine(local)
+            ed.set_waves_per_job(4)  # streaming regime: four waves share a tableau's rows
+            bd = eng.Batch(ed, b.rows, cfg["nvar"], 0, tflags=eng.T_INT | eng.T_NOSKIP)
+            bd.load()
+            bd.solve()
+            dk = kernel_ms_of(bd)
+            cd = bd.counters()
+            # every real row (cut rows included, counted by the kernel) is read and written once per
+            # pivot, plus the pivot-row read and the write of the row that replaces the unit row
+            dbytes = 8.0 * (cfg["nvar"] + 1) * (2.0 * cd["rows_rewritten"] + 2.0 * cd["pivots"])
+            out["roofline_dense_mode"] = {
+                "bound": "hbm", "achieved": dbytes / (dk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dbytes / (dk * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": dk, "pivots": cd["pivots"],
+                "rows_rewritten_per_pivot": cd["rows_rewritten"] / max(1, cd["pivots"]),
+                "algorithmic_bytes_per_step": dbytes,
+                "note": "same batch with row skipping disabled (PIPAMD_T_NOSKIP, 4 waves per tableau): every real row "
+                        "is read and written on every pivot, the reference's access pattern"}
+            del bd, ed
+        except Exception as ex:
+            out["roofline_dense_mode_error"] = repr(ex)
 
     if not args.no_others and world == 1:
-        # one batch at a time (what a caller gets from a single pipamd_batch_load + pipamd_batch_solve)
-        if lanes is not None:
-            lanes.close()
-        del lanes
-        torch.cuda.empty_cache()
-        one = Lanes(cfg, 1, dev, local, seeds[:1], args, gen)  # a fresh engine with its defaults for a lone batch
-        n1 = max(8, min(24, args.steps))
-        dt1, sh1 = timed(one, n1, 2, barrier, 0)
-        t1 = one.totals(sh1)
-        out["pipeline1_value"] = t1[0] / dt1
-        out["pipeline1_ms_per_step"] = dt1 / n1 * 1e3
-        one.close()
-        del one
-        torch.cuda.empty_cache()
-        others = []
-        for oc in OTHERS:
-            # a 1k batch of small tableaux is a tenth of a millisecond of GPU work: twice the lanes keep the GPU fed
-            od = args.pipeline * (2 if oc["batch"] < 4096 and oc["nvar"] < 128 else 1)
-            ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args)
-            osteps = 16 * od
-            # 16 steps per lane: long enough for the lanes to start a fraction of a step apart (their tails
-            # then fall into other lanes' bulk phases; it costs the short headline runs more than it gives)
-            # The median of three timed regions: a region here is 35 ms to 1.4 s long, and the first region of a
-            # fresh set of lanes came out 2-3x slower than every later one on configs[1] (cause not found).
-            regions = sorted((timed(ol, osteps, od, barrier, args.stagger if args.stagger != 0 else -1.0) for _ in range(3)),
-                             key=lambda r: r[0])
-            odt, osh = regions[1]
-            ot = ol.totals(osh)
-            oe, ob, _ = ol.lanes[0]
-            okm = kernel_ms_of(ob)
-            o1 = Lanes(oc, 1, dev, local, [2000], args)
-            odt1, osh1 = timed(o1, 16, 2, barrier, 0)
-            ot1 = o1.totals(osh1)
-            others.append({
-                "config": oc["key"], "workload": oc["workload"], "dtype": "int128" if oc["ebits"] == 128 else "int64",
-                "value": ot[0] / odt, "unit": "pivots/s", "ms_per_step": odt / osteps * 1e3, "steps": osteps,
-                "pipeline_depth": od, "regions_ms": [round(r[0] * 1e3, 3) for r in regions], "problems_per_sec": ot[3] / odt, "pivots_per_step": ot[0] / osteps,
-                "finished_fraction": ot[4] / max(1, ot[3]),
-                "pipeline1_value": ot1[0] / odt1, "pipeline1_ms_per_step": odt1 / 16 * 1e3,
-                "roofline": roofline_of(ob, oe, okm, oc)})
-            ol.close()
-            o1.close()
-            del ol, o1
+        try:  # an extra leg never costs the headline line
+            # one batch at a time (what a caller gets from a single pipamd_batch_load + pipamd_batch_solve)
+            if lanes is not None:
+                lanes.close()
+            del lanes
             torch.cuda.empty_cache()
-        out["other_configs"] = others
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            out["parametric"] = parametric_leg(local, args.no_cpu)
-        except Exception as ex:  # the leg is an extra: never lose the headline line over it
-            out["parametric"] = {"error": repr(ex)}
+            one = Lanes(cfg, 1, dev, local, seeds[:1], args, gen)  # a fresh engine with its defaults for a lone batch
+            n1 = max(8, min(24, args.steps))
+            dt1, sh1 = timed(one, n1, 2, barrier, 0)
+            t1 = one.totals(sh1)
+            out["pipeline1_value"] = t1[0] / dt1
+            out["pipeline1_ms_per_step"] = dt1 / n1 * 1e3
+            one.close()
+            del one
+            torch.cuda.empty_cache()
+            others = []
+            for oc in OTHERS:
+                # a 1k batch of small tableaux is a tenth of a millisecond of GPU work: twice the lanes keep the GPU fed
+                od = args.pipeline * (2 if oc["batch"] < 4096 and oc["nvar"] < 128 else 1)
+                ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args)
+                osteps = 16 * od
+                # 16 steps per lane: long enough for the lanes to start a fraction of a step apart (their tails
+                # then fall into other lanes' bulk phases; it costs the short headline runs more than it gives)
+                # The median of three timed regions: a region here is 35 ms to 1.4 s long, and the first region of a
+                # fresh set of lanes came out 2-3x slower than every later one on configs[1] (cause not found).
+                regions = sorted((timed(ol, osteps, od, barrier, args.stagger if args.stagger != 0 else -1.0) for _ in range(3)),
+                                 key=lambda r: r[0])
+                odt, osh = regions[1]
+                ot = ol.totals(osh)
+                oe, ob, _ = ol.lanes[0]
+                okm = kernel_ms_of(ob)
+                o1 = Lanes(oc, 1, dev, local, [2000], args)
+                odt1, osh1 = timed(o1, 16, 2, barrier, 0)
+                ot1 = o1.totals(osh1)
+                others.append({
+                    "config": oc["key"], "workload": oc["workload"], "dtype": "int128" if oc["ebits"] == 128 else "int64",
+                    "value": ot[0] / odt, "unit": "pivots/s", "ms_per_step": odt / osteps * 1e3, "steps": osteps,
+                    "pipeline_depth": od, "regions_ms": [round(r[0] * 1e3, 3) for r in regions], "problems_per_sec": ot[3] / odt, "pivots_per_step": ot[0] / osteps,
+                    "finished_fraction": ot[4] / max(1, ot[3]),
+                    "pipeline1_value": ot1[0] / odt1, "pipeline1_ms_per_step": odt1 / 16 * 1e3,
+                    "roofline": roofline_of(ob, oe, okm, oc)})
+                ol.close()
+                o1.close()
+                del ol, o1
+                torch.cuda.empty_cache()
+            out["other_configs"] = others
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                out["parametric"] = parametric_leg(local, args.no_cpu)
+            except Exception as ex:  # the leg is an extra: never lose the headline line over it
+                out["parametric"] = {"error": repr(ex)}
+        except Exception as ex:
+            out["other_configs_error"] = repr(ex)
 
     if not args.no_cpu and world == 1:  # the CPU baseline belongs to the one-GPU line
         rows_h = gen(seeds[0]) if gen else synth.lexmin_batch(seeds[0], args.batch, cfg["nvar"], cfg["ni"])
