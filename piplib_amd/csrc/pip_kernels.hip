@@ -1237,6 +1237,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   u16 *g_sig = (u16 *)(g_nzm + (size_t)Sl * NM);
   u8 *g_rcls = (u8 *)(g_sig + Sl);
 
+  // A job loaded with PIPAMD_T_ROWS_STAY: its rows are still in the caller's array (slot s = input row s, pitch
+  // ncol).  The one-wave bulk kernels fetch them in the pass that builds the summaries (FUSE, below); the other
+  // instantiations copy them into the block first, a row per wave at a time, and read them back from L2 -- folded
+  // into their summary pass, the extra pointer cost the four-wave kernel 6 % with row skipping off.
+  constexpr bool FUSE = NW == 1 && SC > 0 && ET<T>::EW == 1;
+  if constexpr (ET<T>::EW == 1 && !FUSE) {
+    if (tflags & PIPAMD_T_FRESHROWS) {
+      const T *fresh = (const T *)(uintptr_t)J->src_rows;
+      for (int s = wave; s < ni; s += NW) {
+        RowRegs<T, NCH> r;
+        row_load<T, NCH>(r, fresh + (size_t)s * ncol, ncolp, lane);
+        row_store<T, NCH>(r, vals + (size_t)s * W, ncolp, lane);
+      }
+      tflags &= ~PIPAMD_T_FRESHROWS;
+      __threadfence_block();
+      bsync<NW>();
+    }
+  }
   // ---- stage the row tables in LDS -------------------------------------
   for (int j = tid; j < WP; j += NT) S.urow[j] = NOROW;  // prow is written whole by every phase A
   if (tid == 0) {
@@ -1277,10 +1295,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     // one pass over the tableau: sign summaries, bitmaps, magnitudes, sort keys (PF rows of a
     // wave in flight at a time)
     constexpr int PF0 = NCH <= 2 ? 4 : (NCH == 4 ? 2 : 1);
-    // a job loaded with PIPAMD_T_ROWS_STAY: its rows are still in the caller's array (slot s = input row s,
-    // pitch ncol) and move into the block in this pass
     const T *fresh = nullptr;
-    if constexpr (ET<T>::EW == 1)
+    if constexpr (FUSE)
       if (tflags & PIPAMD_T_FRESHROWS) fresh = (const T *)(uintptr_t)J->src_rows;
     for (int s0 = wave; s0 < ni; s0 += NW * PF0) {
       RowRegs<T, NCH> rr[PF0];
@@ -1288,8 +1304,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       for (int q = 0; q < PF0; q++)
         if (s0 + q * NW < ni) {
           const int s = s0 + q * NW;
-          row_load<T, NCH>(rr[q], fresh ? fresh + (size_t)s * ncol : vals + (size_t)s * W, ncolp, lane);
-          if (fresh) row_store<T, NCH>(rr[q], vals + (size_t)s * W, ncolp, lane);
+          if (FUSE && fresh) {
+            row_load<T, NCH>(rr[q], fresh + (size_t)s * ncol, ncolp, lane);
+            row_store<T, NCH>(rr[q], vals + (size_t)s * W, ncolp, lane);
+          } else {
+            row_load<T, NCH>(rr[q], vals + (size_t)s * W, ncolp, lane);
+          }
         }
 #pragma unroll
       for (int q = 0; q < PF0; q++) {
@@ -1342,7 +1362,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       }
     }
   }
-  tflags &= ~PIPAMD_T_FRESHROWS;
+  if constexpr (FUSE) tflags &= ~PIPAMD_T_FRESHROWS;
   bsync<NW>();
   PROF(14);
   if (tflags & PIPAMD_T_SORT) {
