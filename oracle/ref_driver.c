@@ -5,12 +5,20 @@
  * /root/reference/source/{piplib,traiter,integrer,tab,sol}.c with
  * -DPIPLIB_INT_DP, i.e. the reference's "pip64"/piplib64 build).
  *
+ * Flavour-generic: every reference name is spelled through the reference's own *_xx aliases
+ * (PIPLIB_NAME, include/piplib/piplib.h:40-88, source/funcall.h:37-47), so the same file compiled
+ * with -DPIPLIB_INT_GMP drives the arbitrary-precision build (oracle/_ref/refpip_gmp over
+ * libpiplib_ref_gmp.so: the authority for the 128-bit Entier engine beyond 2^63).  That build also
+ * interposes libgmp's mpz_mul / mpz_add / mpz_sub and reports, per problem, the widest value the
+ * reference produced in a tableau / cut / context computation and the widest determinant
+ * (batch_res.reserved), so that a fixture knows where a 128-bit run could wrap.
+ *
  * The reference's own command-line front end (source/maind.c) cannot be built
  * here because it includes a generated "version.h"; this file replaces it with
  * the minimum needed to (1) turn a .dat file into the .ll text the reference
  * test-suite diffs against (test/Makefile.am:62-87), (2) run the .pip examples
  * through pip_solve (example/example.c), and (3) solve a binary batch of
- * tableaux while counting calls to pivoter_dp, for the CPU baseline.
+ * tableaux while counting calls to pivoter_xx, for the CPU baseline.
  *
  * Modes
  *   refpip dat  <in.dat>            -> .ll text on stdout           [-z simplify]
@@ -36,10 +44,15 @@
 #include "pip.h" /* the reference's internal header, found via -I/root/reference/source */
 #include "batchfmt.h"
 
-extern int verbose_dp;
-extern int deepest_cut_dp;
+extern int verbose_xx;
+extern int deepest_cut_xx;
+#ifndef pivoter_xx
+#define pivoter_xx PIPLIB_NAME(pivoter) /* the alias is private to traiter.c:344 */
+#endif
+#define STR_(x) #x
+#define STR(x) STR_(x)
 
-/* ---- pivot counter: interposes the reference's pivoter_dp (traiter.c:345) ----
+/* ---- pivot counter: interposes the reference's pivoter_xx (traiter.c:345) ----
  * Not in the REF_NO_COUNT build (oracle/_ref/refpip_fast: this driver and the five reference
  * sources in one -O3 executable, the reference's calls bound directly): that one is only timed,
  * it reports 0 pivots and the caller takes the counts from a pass of the counting build. */
@@ -50,13 +63,42 @@ static long long g_pivots;
 extern long long pipamd_hook_pivots;
 #define g_pivots pipamd_hook_pivots
 #elif !defined(REF_NO_COUNT)
-static int (*real_pivoter)(Tableau_dp *, int, int, int, int);
-int pivoter_dp(Tableau_dp *tp, int pivi, int nvar, int nparm, int ni) {
+static int (*real_pivoter)(Tableau_xx *, int, int, int, int);
+#ifdef PIPLIB_INT_GMP
+static const void *g_det;                 /* the determinant of the tableau being pivoted (tab.h:76-81) */
+static unsigned g_entry_bits, g_det_bits; /* widest results since the last reset */
+#endif
+int pivoter_xx(Tableau_xx *tp, int pivi, int nvar, int nparm, int ni) {
   if (!real_pivoter)
-    real_pivoter = (int (*)(Tableau_dp *, int, int, int, int))dlsym(RTLD_NEXT, "pivoter_dp");
+    real_pivoter = (int (*)(Tableau_xx *, int, int, int, int))dlsym(RTLD_NEXT, STR(pivoter_xx));
   g_pivots++;
+#ifdef PIPLIB_INT_GMP
+  g_det = (const void *)tp->determinant;
+#endif
   return real_pivoter(tp, pivi, nvar, nparm, ni);
 }
+#endif
+
+#ifdef PIPLIB_INT_GMP
+/* ---- width tracker: the reference's arithmetic goes through libgmp's PLT entries; the main
+ * executable's definitions win, record the width of the result and call the real function ---- */
+static void track(mpz_srcptr r) {
+  const unsigned b = mpz_sgn(r) ? (unsigned)mpz_sizeinbase(r, 2) : 0;
+  if ((const void *)r == g_det) {
+    if (b > g_det_bits) g_det_bits = b;
+  } else if (b > g_entry_bits)
+    g_entry_bits = b;
+}
+#define TRACKED(name)                                                        \
+  void __gmpz_##name(mpz_ptr r, mpz_srcptr a, mpz_srcptr b) {                \
+    static void (*real)(mpz_ptr, mpz_srcptr, mpz_srcptr);                    \
+    if (!real) real = (void (*)(mpz_ptr, mpz_srcptr, mpz_srcptr))dlsym(RTLD_NEXT, "__gmpz_" #name); \
+    real(r, a, b);                                                           \
+    track(r);                                                                \
+  }
+TRACKED(mul)
+TRACKED(add)
+TRACKED(sub)
 #endif
 
 /* ---- exit() trap ---- */
@@ -82,25 +124,30 @@ static double now_s(void) {
 /* Solve one already-built (ineq, context) pair the way the reference front
  * ends do (maind.c:196-231 / piplib.c:813-871): empty-context test first, then
  * the main traiter call.  Returns 1 if a solution tree was produced at *xq. */
-static int run_traiter(Tableau_dp *ineq, Tableau_dp *context, int nvar, int nparm, int ni, int nc,
+static int run_traiter(Tableau_xx *ineq, Tableau_xx *context, int nvar, int nparm, int ni, int nc,
                        int bigparm, int nq, int p) {
   int non_vide = 1;
   if (nc) {
-    Tableau_dp *ctxt = expanser_dp(context, nparm, nc, nparm + 1, nparm, 0, 0);
-    traiter_dp(ctxt, NULL, nparm, 0, nc, 0, -1, TRAITER_INT);
-    non_vide = is_not_Nil_dp(p);
-    sol_reset_dp(p);
+    Tableau_xx *ctxt = expanser_xx(context, nparm, nc, nparm + 1, nparm, 0, 0);
+    traiter_xx(ctxt, NULL, nparm, 0, nc, 0, -1, TRAITER_INT);
+    non_vide = is_not_Nil_xx(p);
+    sol_reset_xx(p);
   }
-  if (non_vide) traiter_dp(ineq, context, nvar, nparm, ni, nc, bigparm, nq ? TRAITER_INT : 0);
+  if (non_vide) traiter_xx(ineq, context, nvar, nparm, ni, nc, bigparm, nq ? TRAITER_INT : 0);
   return non_vide;
 }
 
 /* ------------------------------------------------------------------ dat mode */
 static int read_int(FILE *in, int *v) {
-  long long x;
-  if (dscanf_dp(in, &x) < 0) return -1;
-  *v = (int)x;
-  return 0;
+  piplib_int_t_xx x;
+  int rc = 0;
+  piplib_int_init(x);
+  if (dscanf_xx(in, &x) < 0)
+    rc = -1;
+  else
+    *v = piplib_int_get_si(x);
+  piplib_int_clear(x);
+  return rc;
 }
 
 static int mode_dat(const char *path, int simplify) {
@@ -111,17 +158,17 @@ static int mode_dat(const char *path, int simplify) {
     fprintf(stderr, "%s unaccessible\n", path);
     return 1;
   }
-  verbose_dp = -1;
-  sol_init_dp();
-  tab_init_dp();
-  while ((c = dgetc_dp(in)) != EOF) {
+  verbose_xx = -1;
+  sol_init_xx();
+  tab_init_xx();
+  while ((c = dgetc_xx(in)) != EOF) {
     int nvar, nparm, ni, nc, bigparm, nq, level = 0, p, xq, q;
-    struct high_water_mark_dp hq;
-    Tableau_dp *ineq, *context;
+    struct high_water_mark_xx hq;
+    Tableau_xx *ineq, *context;
     if (c != '(') continue;
     /* echo the comment group, as the reference front end does */
     fputc('(', out);
-    while ((c = dgetc_dp(in)) != EOF) {
+    while ((c = dgetc_xx(in)) != EOF) {
       if (c == '(') level++;
       else if (c == ')' && --level == 0) break;
       fputc(c, out);
@@ -131,24 +178,24 @@ static int mode_dat(const char *path, int simplify) {
       fprintf(out, "\nSyntax error\n)\n");
       break;
     }
-    hq = tab_hwm_dp();
-    ineq = tab_get_dp(in, ni, nvar + nparm + 1, nvar);
+    hq = tab_hwm_xx();
+    ineq = tab_get_xx(in, ni, nvar + nparm + 1, nvar);
     if (!ineq) break;
-    if (nq) tab_simplify_dp(ineq, nvar);
-    context = tab_get_dp(in, nc, nparm + 1, 0);
+    if (nq) tab_simplify_xx(ineq, nvar);
+    context = tab_get_xx(in, nc, nparm + 1, 0);
     if (!context) break;
-    if (nq) tab_simplify_dp(context, nparm);
-    xq = p = sol_hwm_dp();
+    if (nq) tab_simplify_xx(context, nparm);
+    xq = p = sol_hwm_xx();
     if (run_traiter(ineq, context, nvar, nparm, ni, nc, bigparm, nq, p)) {
       fputs(")\n", out);
-      if (simplify) sol_simplify_dp(xq);
-      q = sol_hwm_dp();
-      while ((xq = sol_edit_dp(out, xq)) != q)
+      if (simplify) sol_simplify_xx(xq);
+      q = sol_hwm_xx();
+      while ((xq = sol_edit_xx(out, xq)) != q)
         ;
-      sol_reset_dp(p);
+      sol_reset_xx(p);
     } else
       fprintf(out, "void\n");
-    tab_reset_dp(hq);
+    tab_reset_xx(hq);
     fprintf(out, ")\n");
     fflush(out);
   }
@@ -161,20 +208,20 @@ static int mode_pip(void) {
   /* Same stdin protocol and stdout text as example/example.c:72-118. */
   int bignum;
   char s[1024];
-  PipMatrix_dp *domain, *context;
-  PipQuast_dp *solution;
-  PipOptions_dp *options;
+  PipMatrix_xx *domain, *context;
+  PipQuast_xx *solution;
+  PipOptions_xx *options;
   printf("[PIP2-like future input] Please enter:\n- the context matrix,\n");
-  context = pip_matrix_read_dp(stdin);
-  pip_matrix_print_dp(stdout, context);
+  context = pip_matrix_read_xx(stdin);
+  pip_matrix_print_xx(stdout, context);
   printf("- the bignum column (start at 0, -1 if no bignum),\n");
   if (fscanf(stdin, " %d", &bignum) != 1) return 1;
   printf("%d\n", bignum);
   printf("- the constraint matrix.\n");
-  domain = pip_matrix_read_dp(stdin);
-  pip_matrix_print_dp(stdout, domain);
+  domain = pip_matrix_read_xx(stdin);
+  pip_matrix_print_xx(stdout, domain);
   printf("\n");
-  options = pip_options_init_dp();
+  options = pip_options_init_xx();
   while (fgets(s, sizeof s, stdin)) {
     if (!strncasecmp(s, "Maximize", 8)) options->Maximize = 1;
     if (!strncasecmp(s, "Urs_parms", 9)) options->Urs_parms = 1;
@@ -183,8 +230,8 @@ static int mode_pip(void) {
     if (!strncasecmp(s, "Dual", 4)) options->Compute_dual = 1;
   }
   if (bignum > 0) bignum += domain->NbColumns - context->NbColumns;
-  solution = pip_solve_dp(domain, context, bignum, options);
-  pip_quast_print_dp(stdout, solution, 0);
+  solution = pip_solve_xx(domain, context, bignum, options);
+  pip_quast_print_xx(stdout, solution, 0);
   fprintf(stderr, "pivots %lld\n", g_pivots);
   return 0;
 }
@@ -203,15 +250,15 @@ static int mode_batch(const char *in_path, const char *out_path) {
   oh.magic = BATCH_MAGIC;
   oh.count = bh.count;
   fwrite(&oh, sizeof oh, 1, out);
-  verbose_dp = -1;
-  deepest_cut_dp = (bh.flags & BATCH_F_DEEPEST) ? 1 : 0;
-  sol_init_dp();
-  tab_init_dp();
+  verbose_xx = -1;
+  deepest_cut_xx = (bh.flags & BATCH_F_DEEPEST) ? 1 : 0;
+  sol_init_xx();
+  tab_init_xx();
   for (k = 0; k < bh.count; k++) {
     struct batch_prob ph;
     struct batch_res rh;
-    struct high_water_mark_dp hq;
-    Tableau_dp *ineq, *context;
+    struct high_water_mark_xx hq;
+    Tableau_xx *ineq, *context;
     long long *buf;
     char *txt = NULL;
     size_t txtlen = 0;
@@ -224,31 +271,35 @@ static int mode_batch(const char *in_path, const char *out_path) {
         (size_t)ph.ni * ncol + (size_t)ph.nc * (ph.nparm + 1))
       return 5;
     memset(&rh, 0, sizeof rh);
-    hq = tab_hwm_dp();
-    xq = p = sol_hwm_dp();
+    hq = tab_hwm_xx();
+    xq = p = sol_hwm_xx();
     g_pivots = 0;
-    /* tab_get_dp's effect (tab.c:222-248) without the text parsing: rows are
+#ifdef PIPLIB_INT_GMP
+    g_entry_bits = g_det_bits = 0;
+    g_det = NULL;
+#endif
+    /* tab_get_xx's effect (tab.c:222-248) without the text parsing: rows are
      * Unknown with denominator 1. */
-    ineq = tab_alloc_dp(ph.ni, ncol, ph.nvar);
+    ineq = tab_alloc_xx(ph.ni, ncol, ph.nvar);
     for (i = 0; i < ph.ni; i++) {
       Flag(ineq, ph.nvar + i) = Unknown;
-      Denom(ineq, ph.nvar + i) = 1;
-      for (j = 0; j < ncol; j++) Index(ineq, ph.nvar + i, j) = buf[(size_t)i * ncol + j];
+      piplib_int_set_si(Denom(ineq, ph.nvar + i), 1);
+      for (j = 0; j < ncol; j++) piplib_int_set_si(Index(ineq, ph.nvar + i, j), buf[(size_t)i * ncol + j]);
     }
-    context = tab_alloc_dp(ph.nc, ph.nparm + 1, 0);
+    context = tab_alloc_xx(ph.nc, ph.nparm + 1, 0);
     for (i = 0; i < ph.nc; i++) {
       Flag(context, i) = Unknown;
-      Denom(context, i) = 1;
+      piplib_int_set_si(Denom(context, i), 1);
       for (j = 0; j <= ph.nparm; j++)
-        Index(context, i, j) = buf[(size_t)ph.ni * ncol + (size_t)i * (ph.nparm + 1) + j];
+        piplib_int_set_si(Index(context, i, j), buf[(size_t)ph.ni * ncol + (size_t)i * (ph.nparm + 1) + j]);
     }
     t0 = now_s();
     g_trap_armed = 1;
     if (setjmp(g_trap) == 0) {
       int nv;
       if (ph.nq && !(bh.flags & BATCH_F_NOSIMPLIFY)) {
-        tab_simplify_dp(ineq, ph.nvar);
-        tab_simplify_dp(context, ph.nparm);
+        tab_simplify_xx(ineq, ph.nvar);
+        tab_simplify_xx(context, ph.nparm);
       }
       nv = run_traiter(ineq, context, ph.nvar, ph.nparm, ph.ni, ph.nc, ph.bigparm, ph.nq, p);
       g_trap_armed = 0;
@@ -256,8 +307,8 @@ static int mode_batch(const char *in_path, const char *out_path) {
       rh.status = nv ? BATCH_ST_OK : BATCH_ST_VOID;
       if (nv && !(bh.flags & BATCH_F_NOTEXT)) {
         FILE *ms = open_memstream(&txt, &txtlen);
-        q = sol_hwm_dp();
-        while ((xq = sol_edit_dp(ms, xq)) != q)
+        q = sol_hwm_xx();
+        while ((xq = sol_edit_xx(ms, xq)) != q)
           ;
         fclose(ms);
       }
@@ -269,14 +320,17 @@ static int mode_batch(const char *in_path, const char *out_path) {
     rh.pivots = g_pivots;
     total_pivots += g_pivots;
     rh.text_len = (unsigned)txtlen;
+#ifdef PIPLIB_INT_GMP
+    rh.reserved = (g_entry_bits > 0xffff ? 0xffffu : g_entry_bits) | ((g_det_bits > 0xffff ? 0xffffu : g_det_bits) << 16);
+#endif
     fwrite(&rh, sizeof rh, 1, out);
     if (txtlen) fwrite(txt, 1, txtlen, out);
     free(txt);
     free(buf);
     /* the abort path may have left the arenas above the marks; both resets
      * are idempotent (tab.c:106-156, sol.c:74-87). */
-    sol_reset_dp(p);
-    tab_reset_dp(hq);
+    sol_reset_xx(p);
+    tab_reset_xx(hq);
   }
   oh.solve_seconds = t_solve;
   oh.total_pivots = total_pivots;
@@ -291,7 +345,7 @@ int main(int argc, char **argv) {
   if (argc >= 3 && !strcmp(argv[1], "dat")) {
     int simplify = 0, a = 2;
     if (!strcmp(argv[a], "-d")) {
-      deepest_cut_dp = 1;
+      deepest_cut_xx = 1;
       a++;
     }
     if (!strcmp(argv[a], "-z")) {

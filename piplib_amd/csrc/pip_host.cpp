@@ -54,6 +54,9 @@ extern "C" void pipamd_engine_destroy(pipamd_engine *e) {
   if (e->d_q) hipFree(e->d_q);
   if (e->h_run) hipHostFree(e->h_run);
   if (e->d_scratch) hipFree(e->d_scratch);
+  for (void *b : e->d_side)
+    if (b) hipFree(b);
+  if (e->d_side_count) hipFree(e->d_side_count);
   for (void *b : e->dt_buf)
     if (b) hipFree(b);
   if (e->dt_host) hipHostFree(e->dt_host);
@@ -196,16 +199,67 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
   const int KA = !integer ? 0 : (e->round_rows > 0 ? e->round_rows : 48);
   int stage = 0;          // launches issued
   bool have_list = false; // the previous launch's out list is this launch's input
-  auto launch = [&](int waves, int budget, int smax, int upper) -> int {
+  int curS = lay.S;       // row capacity of the largest block in play (grows when tableaux are re-housed)
+  int grow_round = 0;
+  e->last_rehoused = 0;
+  auto next_stage = [&]() -> int {
     if (stage >= PIPAMD_MAX_ROUNDS) {
       pipamd_set_error("batch_solve: more than %d launches", PIPAMD_MAX_ROUNDS);
       return PIPAMD_E_SOLVER;
     }
-    if (smax > lay.S) smax = lay.S;
     if (stage >= Q_FAST && !over_zeroed) {
       HIPCHK(hipMemsetAsync(over, 0, (size_t)Q_CTRL * PIPAMD_MAX_ROUNDS * sizeof(int), st));
       over_zeroed = true;
     }
+    return PIPAMD_OK;
+  };
+  // expanser (traiter.c:55-88, called by integrer when the tableau is full, integrer.c:410-415) for the `n` jobs of
+  // the last launch's out list: those at PIPAMD_ST_CAPACITY move into blocks of twice the row capacity in a side arena
+  // of the engine and go on; the others are passed through.  A stage like a launch: it consumes the list and writes
+  // the next one.  When the engine's limits (16-bit row codes; 128-bit entries: the LDS image) allow no larger
+  // block, the pass only drops the jobs that are at the limit from the list: they keep PIPAMD_ST_CAPACITY.
+  auto rehouse = [&](int n) -> int {
+    pipamd_batch_desc d2 = *d;
+    int newS = curS * 2 > curS + 32 ? curS * 2 : curS + 32;
+    PipBatchLayout nl;
+    size_t jb2;
+    d2.batch = n;
+    for (;;) {
+      d2.cap_cuts = newS - d->ni;
+      if (pipamd_batch_layout(&d2, &nl, &jb2) == PIPAMD_OK) break;
+      if (newS <= curS) return PIPAMD_E_SOLVER;  // the shape the batch was loaded with: cannot fail
+      newS = curS + (newS - curS) / 2;
+    }
+    int rc2 = next_stage();
+    if (rc2) return rc2;
+    const bool room = grow_round < PIPAMD_MAX_GROW;
+    const size_t need = (size_t)nl.per_job * (size_t)n * sizeof(int64_t) + 16;
+    if (room && e->side_bytes[grow_round] < need) {
+      if (e->d_side[grow_round]) HIPCHK(hipFree(e->d_side[grow_round]));
+      e->d_side[grow_round] = nullptr;
+      e->side_bytes[grow_round] = 0;
+      HIPCHK(hipMalloc(&e->d_side[grow_round], need));
+      e->side_bytes[grow_round] = need;
+    }
+    if (!e->d_side_count) HIPCHK(hipMalloc((void **)&e->d_side_count, sizeof(int)));
+    HIPCHK(hipMemsetAsync(e->d_side_count, 0, sizeof(int), st));
+    // job offsets are in int64 units from `arena`, rows 16-byte aligned
+    const char *side = room ? (const char *)e->d_side[grow_round] : (const char *)arena;
+    if (((side - (const char *)arena) & 15) != 0) side += 8;
+    nl.arena_off = (int64_t)((side - (const char *)arena) / (ptrdiff_t)sizeof(int64_t));
+    int *c = ctrl_of(stage);
+    void *q5[5] = {list[(stage - 1) & 1], ctrl_of(stage - 1), list[stage & 1], c, c + 1};
+    HIPCHK(pipk_launch_rehouse(jobs, arena, q5, n, nl, e->d_side_count, room ? n : 0, st));
+    stage++;
+    if (room) grow_round++;
+    curS = newS;
+    e->last_rehoused += n;  // an upper bound: the list also carries the jobs still running
+    return PIPAMD_OK;
+  };
+  auto launch = [&](int waves, int budget, int smax, int upper) -> int {
+    int rcs = next_stage();
+    if (rcs) return rcs;
+    if (smax > curS) smax = curS;
     int *c = ctrl_of(stage);
     void *q5[5] = {nullptr, nullptr, list[stage & 1], c, c + 1};
     if (have_list) {
@@ -239,7 +293,7 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
   }
   int upper = lay.batch;  // what the host knows about the length of the next input list
   for (;;) {
-    rc = launch(tail_waves, e->iter_limit, lay.S, upper);
+    rc = launch(tail_waves, e->iter_limit, curS, upper);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     if (e->blocking_wait) {  // sleep between looks at the stream instead of spinning on it (pipamd_engine_set_blocking_wait)
@@ -252,7 +306,12 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
     }
     if (e->h_run[0] <= 0 || e->single_launch) break;
     upper = e->h_run[0];
+    if (e->h_run[1] & PIPAMD_Q_CAPFLAG) {  // some of them have spent their spare rows
+      rc = rehouse(upper);
+      if (rc) return rc;
+    }
   }
+  if (grow_round > 0) HIPCHK(pipk_launch_rehouse_finish(jobs, arena, lay.batch, lay.sol_words, st));
   e->timed = !e->no_timing;
   return PIPAMD_OK;
 }

@@ -7,6 +7,7 @@
 #include "pip_job.h"
 
 #define PIPAMD_MAX_ROUNDS 512
+#define PIPAMD_MAX_GROW 24 /* growth rounds of one solve: the row capacity at least doubles per round, up to PIPAMD_SMAX */
 
 struct pipamd_engine {
   int device;
@@ -37,6 +38,12 @@ struct pipamd_engine {
   unsigned long long *d_prof; /* diagnostic builds only (-DPIP_PROFILE) */
   void *d_scratch;
   size_t scratch_bytes;
+  /* expanser for the batch layer (pipamd_batch_solve): side arenas for tableaux that spent their spare rows, one
+   * per growth round of a solve (a round doubles the row capacity), kept between solves; the block counter */
+  void *d_side[PIPAMD_MAX_GROW];
+  size_t side_bytes[PIPAMD_MAX_GROW];
+  int *d_side_count;
+  int last_rehoused; /* tableaux the last pipamd_batch_solve re-housed (all rounds) */
 };
 
 void pipamd_set_error(const char *fmt, ...);
@@ -57,6 +64,9 @@ hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long lon
 hipError_t pipk_launch_batch_results(const PipJob *jobs, const long long *arena, int njobs, int nvar, int nparm,
                                      int ebits, int *status, int *pivots, int *cuts, void *sol_num, void *sol_den,
                                      hipStream_t stream);
+hipError_t pipk_launch_rehouse(PipJob *jobs, long long *arena, void *const *q5, int grid, PipBatchLayout nl, int *side_count,
+                               int side_cap, hipStream_t stream);
+hipError_t pipk_launch_rehouse_finish(PipJob *jobs, long long *arena, int njobs, int sol_words, hipStream_t stream);
 hipError_t pipk_launch_clone(long long *arena, const long long *list, int n, hipStream_t stream);
 hipError_t pipk_launch_patch(long long *arena, const int *buf, const long long *index, int n, hipStream_t stream);
 hipError_t pipk_launch_fresh(long long *arena, const long long *buf, const long long *index, int n, hipStream_t stream);

@@ -47,7 +47,13 @@ typedef struct PipJob {
   int32_t nlog, pad_; /* entries of the determinant log not replayed yet */
   int32_t state_nch, ebits; /* ebits: 64 or 128 (0 = 64) */ /* row-chunk count (NCH) of the launch that saved the state block */
   int64_t src_rows; /* PIPAMD_T_FRESHROWS: device address of the caller's ni x ncol input rows (not yet in the block) */
+  int64_t home_sol_off; /* != 0: the job was re-housed in a larger block outside its batch's workspace (expanser,
+                           pip_rehouse_kernel); its solution is copied back to this offset when the solve ends */
 } PipJob;
+
+/* pipamd_batch_solve's launch lists: a job that ran out of spare rows (PIPAMD_ST_CAPACITY) stays on the list, and
+ * the list's `maxni` word carries this bit, until the host has re-housed it in a larger block */
+#define PIPAMD_Q_CAPFLAG (1 << 30)
 
 typedef struct PipBatchLayout {
   int64_t arena_off; /* first job's block, int64 units */

@@ -1158,7 +1158,7 @@ struct PipQueue {
 template <class T, int NCH, int NW, bool GM, int SC, bool FULL>
 __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? PIP_MINWAVES : 1) void pip_advance_kernel(
     PipJob *jobs, i64 *arena, int njobs, int Lmax_, int Smax_, int Wmax, int iter_limit, PipQueue q, unsigned char *gimg,
-    size_t gimg_bytes, u64 *prof) {
+    size_t gimg_bytes, int gslots, u64 *prof) {
   const int Smax = SC > 0 ? SC : Smax_;
   const int Lmax = SC > 0 ? SC + NCH * 64 * ET<T>::CPL : Lmax_;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1168,7 +1168,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   if ((int)blockIdx.x >= nq) return;
   const int jb = q.in_list ? q.in_list[blockIdx.x] : (int)blockIdx.x;
   PipJob *J = &jobs[jb];
-  if (J->status != PIPAMD_ST_RUN) return;
+  if (J->status != PIPAMD_ST_RUN) {
+    // out of spare rows in an earlier launch: stays on the list until the host has re-housed it (pip_rehouse_kernel)
+    if (J->status == PIPAMD_ST_CAPACITY && q.out_count && threadIdx.x == 0) {
+      q.out_list[atomicAdd(q.out_count, 1)] = jb;
+      atomicMax(q.out_maxni, PIPAMD_Q_CAPFLAG | J->ni);
+    }
+    return;
+  }
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int WP = NCH * 64 * ET<T>::CPL;  // columns a wave's registers cover; prow/urow are padded to it
@@ -1177,28 +1184,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
 #ifdef PIP_PROFILE_EVENTS
   if (threadIdx.x == 0) pf_buf = prof;
 #endif
-
-  Shared<T> S;
-  {
-    unsigned char *p = smem;
-    if constexpr (GM) p = gimg + (size_t)blockIdx.x * gimg_bytes;
-    S.den = (T *)p;      p += sizeof(T) * Smax;
-    // the sort keys are dead once the rows are sorted (before the first pivot row is staged):
-    // they share prow's storage, which is sized for the larger of the two
-    S.prow = (T *)p;
-    S.size = (float *)p;
-    p += prow_bytes(sizeof(T) * WP, Smax);
-    S.cst = (T *)p;      p += sizeof(T) * Smax;
-    S.nzm = (u64 *)p;    p += sizeof(u64) * (size_t)Smax * NM;
-    S.sig = (u16 *)p;    p += sizeof(u16) * Smax;
-    S.srow = (u16 *)p;   p += sizeof(u16) * Smax;
-    S.work = (u16 *)p;   p += sizeof(u16) * Smax;
-    S.ref = (u16 *)p;    p += sizeof(u16) * Lmax;
-    S.urow = (u16 *)p;   p += sizeof(u16) * WP;
-    S.fl = (u8 *)p;      p += Smax;
-    S.nf = (u8 *)p;      p += Smax;
-    S.rcls = (u8 *)p;    p += Smax;
-  }
 
   if constexpr (FULL) {
     if (J->nvar != WP - 1 || J->nparm != 0 || J->bigparm >= 0 || J->W != WP) {  // the launcher's promise does not hold
@@ -1232,6 +1217,38 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     }
     return;
   }
+  Shared<T> S;
+  int gslot = 0;
+  (void)gslot;
+  {
+    unsigned char *p = smem;
+    if constexpr (GM) {
+      // the image lives in one of `gslots` HBM blocks behind an array of lock words: workgroup b takes block
+      // b % gslots and waits for an earlier holder to leave (a holder is resident and running, so it does)
+      gslot = (int)(blockIdx.x % (unsigned)gslots);
+      if (tid == 0)
+        while (atomicCAS((int *)gimg + gslot, 0, 1) != 0) __builtin_amdgcn_s_sleep(32);
+      __syncthreads();
+      p = gimg + (((size_t)gslots * sizeof(int) + 255) & ~(size_t)255) + (size_t)gslot * gimg_bytes;
+    }
+    S.den = (T *)p;      p += sizeof(T) * Smax;
+    // the sort keys are dead once the rows are sorted (before the first pivot row is staged):
+    // they share prow's storage, which is sized for the larger of the two
+    S.prow = (T *)p;
+    S.size = (float *)p;
+    p += prow_bytes(sizeof(T) * WP, Smax);
+    S.cst = (T *)p;      p += sizeof(T) * Smax;
+    S.nzm = (u64 *)p;    p += sizeof(u64) * (size_t)Smax * NM;
+    S.sig = (u16 *)p;    p += sizeof(u16) * Smax;
+    S.srow = (u16 *)p;   p += sizeof(u16) * Smax;
+    S.work = (u16 *)p;   p += sizeof(u16) * Smax;
+    S.ref = (u16 *)p;    p += sizeof(u16) * Lmax;
+    S.urow = (u16 *)p;   p += sizeof(u16) * WP;
+    S.fl = (u8 *)p;      p += Smax;
+    S.nf = (u8 *)p;      p += Smax;
+    S.rcls = (u8 *)p;    p += Smax;
+  }
+
   // saved LDS state of a paused job (bitmaps, sign summaries, magnitude classes)
   u64 *g_nzm = (u64 *)(arena + J->state_off);
   u16 *g_sig = (u16 *)(g_nzm + (size_t)Sl * NM);
@@ -1858,6 +1875,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
       atomicMax(q.out_maxni, ni);
     }
+    if (status == PIPAMD_ST_CAPACITY && q.out_count) {  // no spare row left: the host re-houses it (expanser)
+      q.out_list[atomicAdd(q.out_count, 1)] = jb;
+      atomicMax(q.out_maxni, PIPAMD_Q_CAPFLAG | ni);
+    }
+  }
+  if constexpr (GM) {  // give the HBM image back
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) atomicExch((int *)gimg + gslot, 0);
   }
   PROF(8);
   PROF_FLUSH(prof);
@@ -2099,6 +2125,7 @@ __global__ void pip_batch_load_kernel(PipJob *jobs, i64 *arena, const i64 *rows,
     J->bigparm = lay.bigparm;
     J->tflags = lay.tflags | PIPAMD_T_SORT | (defer ? PIPAMD_T_FRESHROWS : 0);
     J->src_rows = defer ? (int64_t)(uintptr_t)src : 0;
+    J->home_sol_off = 0;
     J->L = lay.L;
     J->S = lay.S;
     J->W = lay.W;
@@ -2144,6 +2171,96 @@ __global__ void pip_batch_counters_kernel(const PipJob *jobs, int njobs, unsigne
   atomicAdd(&out[1], (unsigned long long)J->ncut);
   atomicAdd(&out[2], (unsigned long long)J->nupd);
   if (J->status == PIPAMD_ST_SOLUTION || J->status == PIPAMD_ST_NIL) atomicAdd(&out[3], 1ull);
+}
+
+// ---------------------------------------------------------------- expanser for the batch layer
+// traiter.c:55-88 / integrer.c:410-415: a tableau whose spare rows are spent is copied into a larger one.  One
+// workgroup per entry of the launch list: a job still PIPAMD_ST_RUN is passed on as it is; a job at
+// PIPAMD_ST_CAPACITY gets block number atomicAdd(side_count) of the side arena (layout `nl`: same columns, more
+// rows; nl.arena_off = the arena-relative offset of the side arena's first block), its row tables and rows are
+// copied, the new spare rows zeroed, and it is passed on as PIPAMD_ST_RUN (summaries are rebuilt by the next
+// launch, as after the host tree's grow()).  Its determinant log is empty at this point (replayed after every
+// launch) and the limbs live in the PipJob.
+__global__ __launch_bounds__(256) void pip_rehouse_kernel(PipJob *jobs, i64 *arena, PipQueue q, PipBatchLayout nl,
+                                                          int *side_count, int side_cap) {
+  const int nq = *q.in_count;
+  if ((int)blockIdx.x >= nq) return;
+  const int jb = q.in_list[blockIdx.x], tid = threadIdx.x;
+  PipJob *J = &jobs[jb];
+  const int st = J->status;
+  if (st == PIPAMD_ST_RUN) {
+    if (tid == 0) {
+      q.out_list[atomicAdd(q.out_count, 1)] = jb;
+      atomicMax(q.out_maxni, J->ni);
+    }
+    return;
+  }
+  if (st != PIPAMD_ST_CAPACITY || nl.S <= J->S || nl.W != J->W) return;  // cannot grow: the status stands
+  __shared__ int s_idx;
+  if (tid == 0) s_idx = atomicAdd(side_count, 1);
+  __syncthreads();
+  if (s_idx >= side_cap) return;
+  const int EW = J->ebits == 128 ? 2 : 1;
+  const int oL = J->L, oS = J->S, W = J->W, nligne = J->nvar + J->ni;
+  const i64 base = nl.arena_off + (i64)s_idx * nl.per_job;
+  const i64 rows_words = (i64)nl.L * EW + nl.L;
+  const i64 *oden = arena + J->rows_off;
+  const int *oflag = (const int *)(oden + (i64)oL * EW), *oref = oflag + oL;
+  i64 *nden = arena + base;
+  int *nflag = (int *)(nden + (i64)nl.L * EW), *nref = nflag + nl.L;
+  for (int e = tid; e < nl.L * EW; e += blockDim.x) nden[e] = e < nligne * EW ? oden[e] : 0;
+  for (int k = tid; k < nl.L; k += blockDim.x) {
+    nflag[k] = k < nligne ? oflag[k] : 0;
+    nref[k] = k < nligne ? oref[k] : 0;
+  }
+  const i64 *ovals = arena + J->vals_off;
+  i64 *nvals = arena + base + rows_words;
+  const i64 ow = (i64)oS * W * EW, nw = (i64)nl.S * W * EW;
+  for (i64 e = tid; e < nw; e += blockDim.x) nvals[e] = e < ow ? ovals[e] : 0;
+  __syncthreads();
+  if (tid == 0) {
+    if (J->home_sol_off == 0) J->home_sol_off = J->sol_off;
+    J->rows_off = base;
+    J->vals_off = base + rows_words;
+    J->sol_off = J->vals_off + nw;
+    J->state_off = J->sol_off + nl.sol_words;
+    J->log_off = J->state_off + nl.state_words - 2 * PIPAMD_DETLOG * EW;
+    J->L = nl.L;
+    J->S = nl.S;
+    J->tflags &= ~PIPAMD_T_STATE;
+    J->status = PIPAMD_ST_RUN;
+    q.out_list[atomicAdd(q.out_count, 1)] = jb;
+    atomicMax(q.out_maxni, J->ni);
+  }
+}
+// when the solve ends: the solution of a re-housed job goes back into its own block of the caller's workspace
+// (the side arena belongs to the engine and serves the next solve)
+__global__ void pip_rehouse_finish_kernel(PipJob *jobs, i64 *arena, int njobs, int sol_words) {
+  const int b = blockIdx.x;
+  if (b >= njobs) return;
+  PipJob *J = &jobs[b];
+  const i64 home = J->home_sol_off;
+  if (home == 0) return;
+  const i64 *src = arena + J->sol_off;
+  i64 *dst = arena + home;
+  for (int e = threadIdx.x; e < sol_words; e += blockDim.x) dst[e] = src[e];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    J->sol_off = home;
+    J->home_sol_off = 0;
+  }
+}
+extern "C" hipError_t pipk_launch_rehouse(PipJob *jobs, i64 *arena, void *const *q5, int grid, PipBatchLayout nl,
+                                          int *side_count, int side_cap, hipStream_t stream) {
+  if (grid <= 0) return hipSuccess;
+  const PipQueue q{(const int *)q5[0], (const int *)q5[1], (int *)q5[2], (int *)q5[3], (int *)q5[4]};
+  hipLaunchKernelGGL(pip_rehouse_kernel, dim3(grid), dim3(256), 0, stream, jobs, arena, q, nl, side_count, side_cap);
+  return hipGetLastError();
+}
+extern "C" hipError_t pipk_launch_rehouse_finish(PipJob *jobs, i64 *arena, int njobs, int sol_words, hipStream_t stream) {
+  if (njobs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pip_rehouse_finish_kernel, dim3(njobs), dim3(64), 0, stream, jobs, arena, njobs, sol_words);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- forest helpers
@@ -2311,6 +2428,7 @@ struct AdvanceLaunch {
   unsigned long long *prof;
   size_t shm;
   unsigned char *gimg;  // HBM blocks for the row tables when they do not fit LDS (GM instantiation), else NULL
+  int gslots;           // number of those blocks (behind as many lock words)
   hipStream_t stream;
 };
 
@@ -2333,7 +2451,7 @@ static hipError_t launch_advance_t(const AdvanceLaunch &a) {
   }
   const int grid = a.grid > 0 && a.grid < a.njobs ? a.grid : a.njobs;
   hipLaunchKernelGGL((pip_advance_kernel<T, NCH, NW, GM, SC, FULL>), dim3(grid), dim3(64 * NW), GM ? 0 : a.shm, a.stream, a.jobs,
-                     a.arena, a.njobs, a.Lmax, a.Smax, a.Wmax, a.iter_limit, a.q, a.gimg, a.shm, a.prof);
+                     a.arena, a.njobs, a.Lmax, a.Smax, a.Wmax, a.iter_limit, a.q, a.gimg, a.shm, a.gslots, a.prof);
   return hipGetLastError();
 }
 // the one-wave kernel of <= 128 int64 columns with a compile-time row capacity (see SC above)
@@ -2411,11 +2529,19 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
   a.full = (hints & 1) != 0;
   a.shm = pipk_advance_lds_bytes(Lmax, Smax, Wmax, ebits);
   a.gimg = nullptr;
+  a.gslots = 0;
   if (a.shm > PIPAMD_LDS_BUDGET) {  // the row tables of this job mix do not fit a CU's LDS
     if (ebits != 64 || !big) return hipErrorInvalidConfiguration;
     void **buf = (void **)big[0];
     size_t *cap = (size_t *)big[1];
-    const size_t need = (size_t)(a.grid > 0 && a.grid < njobs ? a.grid : njobs) * a.shm;
+    // A pool of image blocks, not one per workgroup: a launch over a 10k-tableau list of which a handful are
+    // unfinished would otherwise pin (and possibly fail to get) gigabytes.  Workgroup b uses block b % slots
+    // behind a lock word; 1,024 blocks cover the workgroups a GPU keeps resident (256 CUs x at most 4 of these
+    // 256-thread, ~100-register workgroups), so a workgroup seldom waits.
+    const int wgs = a.grid > 0 && a.grid < njobs ? a.grid : njobs;
+    a.gslots = wgs < 1024 ? wgs : 1024;
+    const size_t locks = ((size_t)a.gslots * sizeof(int) + 255) & ~(size_t)255;
+    const size_t need = locks + (size_t)a.gslots * a.shm;
     if (*cap < need) {
       if (*buf) {
         hipError_t fe = hipFree(*buf);  // waits for the launches that may still use it
@@ -2426,8 +2552,12 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
       hipError_t me = hipMalloc(buf, need);
       if (me != hipSuccess) return me;
       *cap = need;
+      me = hipMemsetAsync(*buf, 0, need, stream);  // every lock free; re-zeroed below for a smaller pool
+      if (me != hipSuccess) return me;
     }
     a.gimg = (unsigned char *)*buf;
+    // the lock words sit at the head of the buffer whatever the pool size: all are free between launches
+    // (every workgroup releases its block before it ends), so nothing needs zeroing per launch
   }
   a.stream = stream;
   const bool one = waves_per_job == 1;

@@ -17,6 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFPIP = os.path.join(ROOT, "oracle", "_ref", "refpip")
 REFPIP_GPU = os.path.join(ROOT, "oracle", "_ref", "refpip_gpu")  # the reference's front ends over the GPU traiter hook
+REFPIP_GMP = os.path.join(ROOT, "oracle", "_ref", "refpip_gmp")  # the reference's arbitrary-precision flavour (build container only)
 ORACLEPIP = os.path.join(ROOT, "oracle", "oraclepip")
 ORACLEPIP128 = os.path.join(ROOT, "oracle", "oraclepip128")
 MAGIC = 0x50495042
@@ -43,6 +44,8 @@ class Result:
     abort_code: int
     pivots: int
     text: str
+    entry_bits: int = 0  # refpip_gmp only: widest value the reference formed outside the determinant ...
+    det_bits: int = 0    # ... and the widest determinant (oracle/ref_driver.c, width tracker)
 
 
 @dataclass
@@ -83,9 +86,9 @@ def read_batch_out(path: str) -> BatchOut:
     off = struct.calcsize("<IIdq")
     res = []
     for _ in range(count):
-        status, code, piv, tlen, _r = struct.unpack_from("<iiqII", data, off)
+        status, code, piv, tlen, r_ = struct.unpack_from("<iiqII", data, off)
         off += struct.calcsize("<iiqII")
-        res.append(Result(status, code, piv, data[off:off + tlen].decode()))
+        res.append(Result(status, code, piv, data[off:off + tlen].decode(), r_ & 0xffff, r_ >> 16))
         off += tlen
     return BatchOut(res, secs, total)
 

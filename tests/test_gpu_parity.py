@@ -155,6 +155,83 @@ def _oracle_all(rows, nvar, nq, exe=None, procs=16):
         return [r for part in ex.map(run, range(procs)) for r in part]
 
 
+def _compare_ids(g, rows, ids, nvar, nq, wide=False, exe=None):
+    """the tableaux `ids` of a solved batch against the oracle: status, pivot count, every numerator/denominator"""
+    from gpu_common import solution_text
+    import pipbatch as pb
+    from piplib_amd import engine as eng
+    st, pv = g.status.cpu().numpy(), g.pivots.cpu().numpy()
+    if wide:
+        num, den = eng.wide_to_int(g.sol_num.cpu().numpy()), eng.wide_to_int(g.sol_den.cpu().numpy())
+    else:
+        num, den = g.sol_num.cpu().numpy(), g.sol_den.cpu().numpy()
+    o = _oracle_all(rows[ids], nvar, nq, exe=exe)
+    for b, r in zip(ids, o):
+        assert r.status != pb.ST_ABORT and st[b] in (eng.ST_SOLUTION, eng.ST_NIL), (b, st[b], r.status)
+        assert pv[b] == r.pivots, (b, pv[b], r.pivots)
+        got = "()" if st[b] == eng.ST_NIL else pb.squash(solution_text(num[b], den[b]))
+        assert got == pb.squash(r.text), b
+
+
+@pytest.mark.parametrize("batch,nvar,ni,cap,ebits", [
+    (300, 31, 16, 1, 64),      # four-wave launches only; nearly every tableau outgrows one spare row, most several times
+    (2400, 31, 16, 2, 64),     # through the one-wave bulk launch (>= 2048 tableaux) first
+    (64, 127, 64, 3, 64),      # BASELINE configs[2]'s shape
+    (200, 31, 16, 1, 128),     # 128-bit entries
+])
+def test_batch_layer_rehouses_full_tableaux(batch, nvar, ni, cap, ebits):
+    """expanser (traiter.c:55-88) on cut overflow (integrer.c:410-415) in the batch layer: pipamd_batch_solve moves a
+    tableau that has spent its `cap_cuts` spare rows into a block of twice the row capacity and goes on, as often as
+    it takes -- no engine-only PIPAMD_ST_CAPACITY is left, and every answer and pivot count is the oracle's."""
+    import numpy as np
+    import torch
+    import pipbatch as pb
+    from piplib_amd import engine as eng, synth
+    rows = synth.lexmin_batch(4242, batch, nvar, ni)
+    e = eng.Engine(0)
+    g = eng.Batch(e, rows, nvar, 0, tflags=eng.T_INT, cap_cuts=cap, entier_bits=ebits)
+    for _ in range(2):  # twice: the second solve reuses the engine's side arenas
+        g.load()
+        g.solve()
+        g.fetch()
+        torch.cuda.synchronize()
+        st, ct = g.status.cpu().numpy(), g.cuts.cpu().numpy()
+        assert np.isin(st, [eng.ST_SOLUTION, eng.ST_NIL]).all(), np.unique(st, return_counts=True)
+        assert (ct > cap).sum() >= batch // 4      # the spare rows really were too few
+        if cap == 1:
+            assert (ct > ni + 33).any()             # ... and more than once for some tableau (17 -> 49 -> 98 rows)
+        _compare_ids(g, rows, np.arange(batch), nvar, 1, wide=ebits == 128,
+                     exe=pb.ORACLEPIP128 if ebits == 128 else None)
+
+
+def test_bench_lane_seeds_all_finish():
+    """bench.py's headline lanes draw their batches from seeds 1000 + 7919 * lane.  Every tableau of the first 12
+    lanes' batches must end with a status the reference has (solution or nil) -- tableaux that need more than the
+    default ni + 64 spare rows are re-housed -- and the oracle agrees on every tableau that needed more than ni + 64 cuts
+    plus 150 others per lane."""
+    import numpy as np
+    import torch
+    from piplib_amd import engine as eng, synth
+    nvar, ni = 127, 64
+    e = eng.Engine(0)
+    grown = 0
+    for lane in range(12):
+        rows = synth.lexmin_batch(1000 + 7919 * lane, 10000, nvar, ni)
+        g = eng.Batch(e, rows, nvar, 0, tflags=eng.T_INT)
+        g.load()
+        g.solve()
+        g.fetch()
+        torch.cuda.synchronize()
+        st, ct = g.status.cpu().numpy(), g.cuts.cpu().numpy()
+        assert np.isin(st, [eng.ST_SOLUTION, eng.ST_NIL]).all(), (lane, np.unique(st, return_counts=True))
+        big = np.nonzero(ct > ni + 64)[0]
+        grown += len(big)
+        ids = np.unique(np.concatenate([big, np.random.default_rng(lane).choice(10000, 150, replace=False)]))
+        _compare_ids(g, rows, ids, nvar, 1)
+        del g
+    assert grown >= 1   # about 3 tableaux per 100,000 need more than ni + 64 spare rows
+
+
 def _gpu128(rows, nvar, nq, cap_cuts):
     import torch
     from piplib_amd import engine as eng
