@@ -11,14 +11,18 @@ A "step" = tab_get-style load of the batch into the HBM row store + the whole tr
 pivot loop for every tableau (inputs are resident in HBM before the timed region).
 Steps are pipelined: up to --pipeline (default 12) batches are in flight on separate HIP streams,
 each lane with its own batch (own seed), engine and workspace (each step is a complete load +
-solve of its batch); ms_per_step is total time / steps.  `pipeline1_value` is the same workload
-with one batch at a time.  `other_configs` carries BASELINE configs[1] and configs[4] measured the
-same way (shorter runs).
+solve of its batch), all driven by ONE host thread through the asynchronous C ABI
+(pipamd_batch_solve_async / pipamd_batch_wait; `--threads` = round 2's one-host-thread-per-lane
+driver, measured beside it as `threaded_value`).  The timed region is run three times; ms_per_step is
+the median region / steps and all three are printed (`regions_ms`).  `pipeline1_value` is the same
+workload with one batch at a time.  `other_configs` carries BASELINE configs[1] and configs[4]
+measured the same way (shorter runs).
 Multi-GPU (--gpus N > 1): BASELINE configs[3] -- every 10k-tableau batch is sharded over the ranks
-(strong scaling; world x as many batches in flight so that a GPU holds as many tableaux as in the
-1-GPU run), no data-path collective; RCCL only sums the totals here (the results gather is
-piplib_amd.dist.gather_results).  The weak-scaling figure (10k tableaux per GPU and batch) is
-measured as well and reported as `other_scaling`.
+(strong scaling), no data-path collective; a rank fuses its shards of several batches in flight into
+one workspace (pipamd_batch_load_part) so that one launch sequence serves ~5,000 tableaux whatever N;
+RCCL only sums the totals here (the results gather is piplib_amd.dist.gather_results).  The
+weak-scaling figure (10k tableaux per GPU and batch) is measured as well and reported as
+`other_scaling`.
 
 Prints ONE JSON line (rank 0).
 """
@@ -34,6 +38,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+STATUS_NAMES = {0: "run", 1: "solution", 2: "nil", 3: "need_compa", 4: "need_parmcut", 5: "overflow", 6: "capacity",
+                7: "range", 8: "internal", 9: "maxcol"}
 
 # name, tableaux per batch, unknowns, rows, integer solve?, entry bits, generator keywords
 MAIN = dict(key="configs[2]", workload="10k-batch synthetic 64x128 tableaux, int64, integer solve with Gomory cuts",
@@ -45,7 +51,11 @@ OTHERS = [
     # on these ("Integer overflow", traiter.c:424,442), the 128-bit Entier build solves them
     dict(key="configs[4]", workload="1k-batch synthetic 128x256 tableaux, 128-bit Entier, integer solve "
                                     "(inputs on which the int64 build stops with 'Integer overflow')",
-         batch=1000, nvar=255, ni=128, integer=True, ebits=128, gen=dict(nnz=6, cmax=30)),
+         batch=1000, nvar=255, ni=128, integer=True, ebits=128, gen=dict(nnz=6, cmax=30),
+         # Gomory cuts converge slowly on about 8 tableaux per 10,000 of this family (tens of thousands of pivots over
+         # thousands of cut rows; the reference on the CPU takes seconds to minutes for each): the leg gives a tableau
+         # ni + 192 rows (pipamd_engine_set_max_rows) and reports the few that want more as `capacity`
+         max_rows=128 + 192),
 ]
 
 
@@ -177,15 +187,21 @@ def lane_stream(torch, dev, i):
 
 
 class Lanes:
-    """`depth` batches in flight, each with its own engine, workspace, input rows (own seed), HIP
-    stream and host thread: while one batch's last stragglers finish (a latency-bound tail that
-    leaves most CUs idle) the other batches' bulk launches run.  Every step is a full load + solve."""
+    """`depth` batches in flight, each with its own engine, workspace, input rows (own seed) and HIP
+    stream: while one batch's last stragglers finish (a latency-bound tail that leaves most CUs idle)
+    the other batches' bulk launches run.  Every step is a full load + solve.  One host thread drives
+    all lanes through pipamd_batch_solve_async / pipamd_batch_wait (threads=True: a host thread per
+    lane calling the synchronous pipamd_batch_solve, round 2's driver).
+    fuse = G > 1: a lane's workspace holds G batches' worth of tableaux (this rank's shards of G
+    batches in flight, loaded part by part with pipamd_batch_load_part): one launch sequence per G
+    steps; a lane pass counts as G steps."""
 
-    def __init__(self, cfg, depth, dev, local, seeds, args, gen=None):
+    def __init__(self, cfg, depth, dev, local, seeds, args, gen=None, threads=False, fuse=1):
         import torch
         from piplib_amd import engine as eng
         from piplib_amd import synth
         self.torch, self.eng, self.cfg, self.dev, self.depth = torch, eng, cfg, dev, depth
+        self.threads, self.fuse = threads, fuse
         self.lanes = []
         gen = gen or (lambda seed: synth.lexmin_batch(seed, cfg["batch"], cfg["nvar"], cfg["ni"], **cfg["gen"]))
         for i in range(depth):
@@ -202,9 +218,11 @@ class Lanes:
                                                     and cfg["batch"] >= 2048 else 0)
             if tw:
                 e.set_tail_waves(tw)
+            if cfg.get("max_rows"):
+                e.set_max_rows(cfg["max_rows"])
             e.set_timing(False)  # no HIP events in the timed region (kernel_ms_of switches them on)
             bw = getattr(args, "blocking_wait", -1)
-            if bw > 0 or (bw < 0 and depth > host_cpus()):  # more polling threads than CPUs only take turns
+            if bw > 0 or (bw < 0 and threads and depth > host_cpus()):  # more polling threads than CPUs only take turns
                 e.set_blocking_wait(True)
             bulk_min = args.bulk_min if args.bulk_min > 0 else (256 if depth > 1 else 0)  # depth = this Lanes' lane count
             if bulk_min:
@@ -212,12 +230,51 @@ class Lanes:
             # the input rows stay resident and untouched in HBM for the whole run: T_ROWS_STAY lets the first pivot
             # launch read them where they are instead of a copy pass (--copy-rows switches that off)
             stay = 0 if getattr(args, "copy_rows", False) else eng.T_ROWS_STAY
-            b = eng.Batch(e, torch.as_tensor(gen(seeds[i]), dtype=torch.int64).to(dev), cfg["nvar"], 0,
-                          tflags=(eng.T_INT if cfg["integer"] else 0) | stay, entier_bits=cfg["ebits"])
+            tf = (eng.T_INT if cfg["integer"] else 0) | stay
+            if fuse > 1:
+                # G row arrays (the shards of G different batches), one workspace of G x shard tableaux
+                parts = [torch.as_tensor(gen(seeds[i] + 104729 * k), dtype=torch.int64).to(dev) for k in range(fuse)]
+                b = eng.Batch(e, torch.cat(parts), cfg["nvar"], 0, tflags=tf, entier_bits=cfg["ebits"])
+                b.parts = parts
+            else:
+                b = eng.Batch(e, torch.as_tensor(gen(seeds[i]), dtype=torch.int64).to(dev), cfg["nvar"], 0,
+                              tflags=tf, entier_bits=cfg["ebits"])
+                b.parts = None
             self.lanes.append((e, b, lane_stream(torch, dev, i)))
         self.stagger = 0.0
         self.done = [0] * depth
         self.workers, self.share, self.failed = None, None, None
+
+    @staticmethod
+    def _load(bi):
+        if bi.parts is None:
+            bi.load()
+        else:  # the shards arrive from different batches: one load per part, one solve for all
+            off = 0
+            for part in bi.parts:
+                bi.load_part(part, off)
+                off += part.shape[0]
+
+    def _run_async(self, share):
+        """one host thread: round-robin over the lanes, `share[i]` passes on lane i"""
+        left, pending = list(share), [False] * self.depth
+        with self.torch.cuda.device(self.dev):
+            while any(left):
+                for i, (_, bi, st) in enumerate(self.lanes):
+                    if not left[i]:
+                        continue
+                    if pending[i]:
+                        bi.wait()
+                    with self.torch.cuda.stream(st):
+                        self._load(bi)
+                        bi.solve_async()
+                    pending[i] = True
+                    left[i] -= 1
+            for i, (_, bi, _) in enumerate(self.lanes):
+                if pending[i]:
+                    bi.wait()
+        for i, n in enumerate(share):
+            self.done[i] += n
 
     def _lane_steps(self, i, nsteps):
         _, bi, st = self.lanes[i]
@@ -227,7 +284,7 @@ class Lanes:
             time.sleep(i * self.stagger)
         with self.torch.cuda.stream(st):
             for _ in range(nsteps):
-                bi.load()
+                self._load(bi)
                 bi.solve()
             st.synchronize()
         self.done[i] += nsteps
@@ -247,7 +304,15 @@ class Lanes:
             self.fin.wait()
 
     def run(self, nsteps):
+        """`nsteps` steps (a pass of a lane with fused parts counts as `fuse` steps; nsteps is rounded up to whole
+        passes); returns the passes per lane"""
         d = self.depth
+        npass = (nsteps + self.fuse - 1) // self.fuse
+        if not self.threads:
+            share = [npass // d + (1 if i < npass % d else 0) for i in range(d)]
+            self._run_async(share)
+            return share
+        nsteps = npass
         if self.workers is None:
             self.go, self.fin = threading.Barrier(d + 1), threading.Barrier(d + 1)
             self.workers = [threading.Thread(target=self._worker, args=(i,), daemon=True) for i in range(d)]
@@ -274,8 +339,20 @@ class Lanes:
         except Exception:
             pass
 
+    def status_histogram(self):
+        """PIPAMD_ST_* -> tableaux, over the lanes' last solves"""
+        hist = {}
+        for _, b, st in self.lanes:
+            with self.torch.cuda.stream(st):
+                b.fetch()
+                h = self.torch.bincount(b.status.to(self.torch.int64), minlength=10).cpu().tolist()
+            for k, v in enumerate(h):
+                if v:
+                    hist[k] = hist.get(k, 0) + v
+        return hist
+
     def totals(self, share):
-        """pivots, cuts, rows rewritten, tableaux, finished tableaux of `share[i]` steps of lane i"""
+        """pivots, cuts, rows rewritten, tableaux, finished tableaux of `share[i]` passes of lane i"""
         tot = [0, 0, 0, 0, 0]
         for (e, b, _), n in zip(self.lanes, share):
             if not n:
@@ -287,6 +364,12 @@ class Lanes:
             tot[3] += n * b.desc.batch
             tot[4] += n * c["finished"]
         return tot
+
+
+def progress(msg):
+    """a line on stderr per leg: a long run shows where it is (and a hung one, where it stopped)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def host_cpus():
@@ -330,6 +413,18 @@ def timed(lanes, steps, warmup, barrier, stagger_arg):
     share = lanes.run(steps)
     barrier()
     return time.perf_counter() - t0, share
+
+
+def timed_regions(lanes, steps, warmup, barrier, stagger_arg, n=3):
+    """`n` timed regions of `steps` steps each behind one warm-up; sorted by duration: [(seconds, share)]"""
+    out = [timed(lanes, steps, warmup, barrier, stagger_arg)]
+    for _ in range(n - 1):
+        barrier()
+        t0 = time.perf_counter()
+        share = lanes.run(steps)
+        barrier()
+        out.append((time.perf_counter() - t0, share))
+    return sorted(out, key=lambda r: r[0])
 
 
 def roofline_of(b, e, k_ms, cfg, extra=None):
@@ -380,7 +475,13 @@ def main():
                     help="strong (default for --gpus > 1, BASELINE configs[3]): every --batch-tableau batch is sharded "
                          "over the ranks; weak (default for one GPU): --batch tableaux per GPU and batch.  The other "
                          "mode is measured too and reported as `other_scaling`.")
-    ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (streams/threads)")
+    ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (streams)")
+    ap.add_argument("--threads", action="store_true",
+                    help="one host thread per lane calling the synchronous pipamd_batch_solve (round 2's driver) instead of "
+                         "one thread over pipamd_batch_solve_async / pipamd_batch_wait")
+    ap.add_argument("--fuse", type=int, default=0,
+                    help="strong scaling: shards of this many batches share a workspace and a launch sequence (0 = enough "
+                         "for about 5,000 tableaux per launch sequence)")
     ap.add_argument("--stagger", type=float, default=0.0,
                     help="ms between the lanes' starts (0 = none, <0 = step latency / lanes, measured in warm-up)")
     ap.add_argument("--blocking-wait", type=int, default=-1,
@@ -426,18 +527,20 @@ def main():
     if args.scaling is None:
         args.scaling = "strong" if world > 1 else "weak"
 
-    def build_lanes(scaling):
+    def build_lanes(scaling, threads=False):
         """the lanes of one measurement: (cfg, lanes, depth, seeds, gen)"""
         cfg = dict(MAIN)
         cfg["batch"] = args.batch
+        fuse = 1
         if scaling == "strong":
-            # BASELINE configs[3]: every 10k-tableau batch is sharded over the GPUs.  A GPU then holds 1/world
-            # of every batch in flight.  Shards below 4,000 tableaux want twice the batches in flight, not
-            # world x as many (one MI355X, 16 host CPUs, host threads napping instead of spinning: a 1,250-tableau
-            # shard runs at 262 M pivots/s with 24 batches in flight, 240 M with 48; 2,500: 304 M with 24,
-            # 278 M with 16; 5,000: 350 M with 12)
-            shard = (args.batch + world - 1) // world
-            depth = lane_count(args.pipeline * (2 if shard < 4000 else 1), args.steps)
+            # BASELINE configs[3]: every 10k-tableau batch is sharded over the GPUs: a GPU holds 1/world of every
+            # batch in flight.  The shards are independent tableaux, so a rank loads its shards of `fuse` batches
+            # into ONE workspace (pipamd_batch_load_part) and one bulk + tail launch pair serves them: about 5,000
+            # tableaux per launch sequence whatever the world size, instead of 24 launch sequences of 1,250 tableaux
+            # (round 2: 262 M pivots/s per GPU at 1,250, 304 M at 2,500, 350 M at 5,000, 362 M at 10,000).
+            shard = max(1, (args.batch + world - 1) // world)
+            fuse = args.fuse if args.fuse > 0 else max(1, min(16, 5000 // shard))
+            depth = lane_count(args.pipeline, (args.steps + fuse - 1) // fuse)
             lo, hi = pdist.shard_range(args.batch, rank, world)
             cfg["batch"] = hi - lo
             seeds = [1000 + 7919 * i for i in range(depth)]
@@ -449,14 +552,22 @@ def main():
             # lane i of rank r draws its own batch: seed 1000 + r + 7919 * i
             seeds = [pdist.shard_seed(1000, rank) + 7919 * i for i in range(depth)]
             gen = None
-        return cfg, Lanes(cfg, depth, dev, local, seeds, args, gen), depth, seeds, gen
+        return cfg, Lanes(cfg, depth, dev, local, seeds, args, gen, threads=threads, fuse=fuse), depth, seeds, gen
 
-    cfg, lanes, depth, seeds, gen = build_lanes(args.scaling)
+    progress("building the lanes")
+    cfg, lanes, depth, seeds, gen = build_lanes(args.scaling, args.threads)
+    progress(f"{depth} lanes ready; timing")
     my_batch = cfg["batch"]
+    fuse = lanes.fuse
     e, b, _ = lanes.lanes[0]
 
-    dt, share = timed(lanes, args.steps, args.warmup, barrier, args.stagger)
+    # three timed regions of --steps steps each; the median is the line's value, all three are printed
+    regions = timed_regions(lanes, args.steps, args.warmup, barrier, args.stagger)
+    dt, share = regions[1]
+    steps_done = sum(share) * fuse   # == --steps unless shards are fused (whole passes of `fuse` steps)
+    progress(f"regions {[round(r[0] * 1e3, 2) for r in regions]} ms")
     tot = lanes.totals(share)
+    hist = lanes.status_histogram()
 
     # the advance kernel's own launch durations (HIP events on its stream), un-overlapped
     k_ms = kernel_ms_of(b)
@@ -470,11 +581,13 @@ def main():
         lanes.close()
         del lanes
         torch.cuda.empty_cache()
-        cfg2, lanes2, depth2, _, _ = build_lanes(mode2)
+        cfg2, lanes2, depth2, _, _ = build_lanes(mode2, args.threads)
         dt2, share2 = timed(lanes2, args.steps, args.warmup, barrier, args.stagger)
         gt2, dt2_max = pdist.gather_totals(lanes2.totals(share2), dt2, dev)
-        other = {"scaling": mode2, "value": gt2[0] / dt2_max, "unit": "pivots/s", "ms_per_step": dt2_max / args.steps * 1e3,
-                 "batch_per_gpu": cfg2["batch"], "pipeline_depth": depth2, "problems_per_sec": gt2[3] / dt2_max}
+        other = {"scaling": mode2, "value": gt2[0] / dt2_max, "unit": "pivots/s",
+                 "ms_per_step": dt2_max / (sum(share2) * lanes2.fuse) * 1e3,
+                 "batch_per_gpu": cfg2["batch"], "pipeline_depth": depth2, "fused_batches_per_launch_sequence": lanes2.fuse,
+                 "problems_per_sec": gt2[3] / dt2_max}
         lanes2.close()
         del lanes2
         torch.cuda.empty_cache()
@@ -485,7 +598,7 @@ def main():
         pdist.finish()
         return
 
-    ms_step = dt_max / args.steps * 1e3
+    ms_step = dt_max / steps_done * 1e3
     out = {
         "metric": "pivots/sec (batched 64x128 int64 tableaux, integer solve with Gomory cuts)",
         "value": gt[0] / dt_max,
@@ -503,13 +616,26 @@ def main():
                                                      " sharded over the ranks (BASELINE configs[3])"),
                    "batch_per_gpu": my_batch, "nvar": cfg["nvar"], "nparm": 0, "ni": cfg["ni"],
                    "parallelism": f"{world} x independent batches (one workgroup per tableau)",
-                   "pipeline_depth": depth, "lane_seeds": "1000 + rank + 7919 * lane (strong: 1000 + 7919 * lane)"},
+                   "pipeline_depth": depth, "lane_seeds": "1000 + rank + 7919 * lane (strong: 1000 + 7919 * lane)",
+                   "host_threads": depth if args.threads else 1,
+                   "driver": "one host thread per lane, pipamd_batch_solve" if args.threads else
+                             "one host thread, pipamd_batch_solve_async / pipamd_batch_wait",
+                   "fused_batches_per_launch_sequence": fuse},
+        "steps_timed": steps_done,
+        "regions_ms": [round(r[0] * 1e3, 3) for r in regions],
         "problems_per_sec": gt[3] / dt_max,
-        "pivots_per_step": gt[0] / args.steps,
-        "cuts_per_step": gt[1] / args.steps,
+        "pivots_per_step": gt[0] / steps_done,
+        "cuts_per_step": gt[1] / steps_done,
         "finished_fraction": gt[4] / max(1.0, gt[3]),
+        "status_histogram_rank0": {STATUS_NAMES.get(k, str(k)): v for k, v in sorted(hist.items())},
         "rows_rewritten_per_pivot": gt[2] / max(1.0, gt[0]),
     }
+    if out["finished_fraction"] < 1.0:
+        # a tableau without a final status of the reference's (solution / nil) voids the line
+        out["error"] = "finished_fraction < 1: the workload was not solved completely"
+        print(json.dumps(out), flush=True)
+        pdist.finish()
+        raise SystemExit(3)
     if other:
         out["other_scaling"] = other
     traffic = None
@@ -536,6 +662,7 @@ def main():
     # Same workload once more with row skipping off: every real row is read and written on
     # every pivot, which is the reference's access pattern (traiter.c:467-502) and the regime
     # in which the row-update path is HBM-bound.  Reported beside the main number.
+    progress("headline done: %.1f M pivots/s" % (out["value"] / 1e6))
     if not args.no_dense:
         try:  # an extra leg never costs the headline line
             ed = eng.Engine(local)
@@ -566,6 +693,7 @@ def main():
                 lanes.close()
             del lanes
             torch.cuda.empty_cache()
+            progress("one batch at a time")
             one = Lanes(cfg, 1, dev, local, seeds[:1], args, gen)  # a fresh engine with its defaults for a lone batch
             n1 = max(8, min(24, args.steps))
             dt1, sh1 = timed(one, n1, 2, barrier, 0)
@@ -577,6 +705,7 @@ def main():
             torch.cuda.empty_cache()
             others = []
             for oc in OTHERS:
+                progress(oc["key"])
                 # a 1k batch of small tableaux is a tenth of a millisecond of GPU work: twice the lanes keep the GPU fed
                 od = args.pipeline * (2 if oc["batch"] < 4096 and oc["nvar"] < 128 else 1)
                 ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args)
@@ -608,6 +737,7 @@ def main():
             out["other_configs"] = others
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
+                progress("parametric leg")
                 out["parametric"] = parametric_leg(local, args.no_cpu)
             except Exception as ex:  # the leg is an extra: never lose the headline line over it
                 out["parametric"] = {"error": repr(ex)}
@@ -615,6 +745,7 @@ def main():
             out["other_configs_error"] = repr(ex)
 
     if not args.no_cpu and world == 1:  # the CPU baseline belongs to the one-GPU line
+        progress("cpu baseline")
         rows_h = gen(seeds[0]) if gen else synth.lexmin_batch(seeds[0], args.batch, cfg["nvar"], cfg["ni"])
         cb = cpu_baseline(rows_h, cfg["nvar"], cfg["ni"])
         if cb:

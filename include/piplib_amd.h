@@ -32,6 +32,15 @@
 extern "C" {
 #endif
 
+/* Version of this interface, also returned by pipamd_version() of the library that was loaded: a binding checks
+ * the two against each other before it calls anything else (entry points were added and changed between versions
+ * without the symbols changing).  100: round 1.  200: round 2 -- pipamd_traiter / pipamd_solve_tableau* hand out
+ * tape cells (`cells, n_cells`) instead of text; the transliterated pip_solve front end (pipamd_pip_solve,
+ * pipamd_quast_*) is gone: pip_solve stays the reference's piplib.c over bindings/piplib_traiter_hook.c.
+ * 300: round 3 -- pipamd_batch_solve_async / _wait / _poll, pipamd_batch_load_part, unbounded row growth in the
+ * batch layer (no PIPAMD_ST_CAPACITY short of the engine's 16,000-row limit), the 128-bit lock-step entry. */
+#define PIPAMD_VERSION 300
+
 /* ---- error codes (return values) ---- */
 #define PIPAMD_OK 0
 #define PIPAMD_E_INVALID -1   /* bad argument / shape */
@@ -62,7 +71,8 @@ extern "C" {
 #define PIPAMD_ST_NEED_COMPA 3   /* parametric signs undecided: host runs compa_test (traiter.c:682) */
 #define PIPAMD_ST_NEED_PARMCUT 4 /* parametric Gomory cut on row `aux`: host runs find/add_parm */
 #define PIPAMD_ST_OVERFLOW 5     /* the reference's "Integer overflow" exit (traiter.c:424,442) */
-#define PIPAMD_ST_CAPACITY 6     /* spare rows/columns exhausted: reload with larger cap_* */
+#define PIPAMD_ST_CAPACITY 6     /* spare columns (cap_newparm) exhausted, or the engine's row limit (16,000 rows; 128-bit
+                                    entries: what fits a workgroup's LDS) reached; pipamd_batch_solve itself grows rows */
 #define PIPAMD_ST_RANGE 7        /* entries too large for the exact fast pivot-column choice */
 #define PIPAMD_ST_INTERNAL 8
 #define PIPAMD_ST_MAXCOL 9       /* "Too many variables" (integrer.c:324) */
@@ -81,8 +91,11 @@ typedef struct pipamd_engine pipamd_engine;
 int pipamd_engine_create(pipamd_engine **out, int device);
 void pipamd_engine_destroy(pipamd_engine *e);
 const char *pipamd_last_error(void);
-/* Upper bound on pivots per problem per launch (a problem still PIPAMD_ST_RUN afterwards is
- * simply resumed by the next pipamd_batch_solve); default 2^20. */
+/* Upper bound on pivots per problem per launch (a problem still PIPAMD_ST_RUN afterwards is resumed by the next
+ * launch of the same pipamd_batch_solve).  At most 512 (the default; larger values are clamped): a launch logs
+ * (pivot, denominator) per pivot for the determinant bookkeeping of traiter.c:412-446, which a replay kernel runs
+ * after the launch, and a job's log holds 512 entries.  pipamd_batch_solve gives up on a batch (PIPAMD_E_SOLVER)
+ * after 512 launches, i.e. a tableau may take 262,144 pivots. */
 int pipamd_engine_set_iter_limit(pipamd_engine *e, int pivots_per_launch);
 /* Waves (64 lanes each) that share one tableau: 1 keeps more tableaux in flight per CU (best for
  * large batches of sparse problems), 4 spreads a tableau's rows over four waves (few or dense
@@ -124,9 +137,38 @@ size_t pipamd_batch_workspace_bytes(const pipamd_batch_desc *d);
 int pipamd_batch_load(pipamd_engine *e, void *d_workspace, const pipamd_batch_desc *d,
                       const int64_t *d_rows, void *stream);
 
+/* The same for the tableaux first .. first + count - 1 of the batch only; `d_rows` holds those `count` tableaux.  A
+ * batch can thus be assembled from several row arrays -- e.g. one GPU's shards of the K batches a caller has in
+ * flight, fused into one workspace so that ONE launch sequence serves them all instead of K small ones (what
+ * bench.py's strong-scaling mode does; piplib_amd/dist.py).  Every tableau of the batch must have been loaded by
+ * some call before pipamd_batch_solve. */
+int pipamd_batch_load_part(pipamd_engine *e, void *d_workspace, const pipamd_batch_desc *d, const int64_t *d_rows,
+                           int first, int count, void *stream);
+
 /* traiter() on every tableau of the batch.  Launches on `stream` and returns when every
- * tableau has a final status (it synchronises the stream between rounds). */
+ * tableau has a final status (it synchronises the stream between rounds).  A tableau that spends its cap_cuts
+ * spare rows is moved to a block of twice the row capacity (the reference's expanser, traiter.c:55-88, as integrer
+ * calls it on a full tableau, integrer.c:410-415) as often as it takes, up to the engine's 16,000 rows: cap_cuts
+ * is a size hint, not a limit. */
 int pipamd_batch_solve(pipamd_engine *e, void *d_workspace, const pipamd_batch_desc *d, void *stream);
+
+/* The same in two halves, so that ONE host thread keeps many batches in flight: pipamd_batch_solve_async enqueues
+ * the launch sequence (bulk launch, tail launch, a copy of the tail's control words) on `stream` and returns without
+ * waiting; pipamd_batch_wait waits for it, issues whatever else the batch needs (further tail launches for tableaux
+ * beyond the per-launch pivot limit, re-housing of full tableaux) and returns when every tableau has a final status.
+ * pipamd_batch_poll: 1 when pipamd_batch_wait would not block on the launches enqueued so far (or nothing is in
+ * flight), 0 while they run.  One solve in flight per engine -- an engine is a small host object: a caller keeps K
+ * of them, each with its own stream and workspace, and goes round (load, solve_async on lane i; wait on lane i+1, ...):
+ * a lone batch leaves most of the GPU idle in its latency-bound tail, K batches in different phases fill it
+ * (bench.py: one thread, K = 12).  Results may be fetched after pipamd_batch_wait. */
+int pipamd_batch_solve_async(pipamd_engine *e, void *d_workspace, const pipamd_batch_desc *d, void *stream);
+/* Row budget of the growth above: a tableau is re-housed only while its row capacity stays within `rows` (at least
+ * ni + cap_cuts; 0 = the default, only the engine's own limit) and ends PIPAMD_ST_CAPACITY beyond it.  The reference
+ * grows without bound and so does the default; on inputs where Gomory cuts converge slowly (thousands of cut rows,
+ * every pivot then rewriting thousands of rows) a caller bounds the memory and time of a batch with it. */
+int pipamd_engine_set_max_rows(pipamd_engine *e, int rows);
+int pipamd_batch_wait(pipamd_engine *e);
+int pipamd_batch_poll(pipamd_engine *e);
 
 /* Copy out, device to device: status[b], pivots[b], cuts[b] (int32 each, may be NULL),
  * sol_num[b][i][0..nparm] (parameter coefficients then constant, as solution() emits them,

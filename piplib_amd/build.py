@@ -10,8 +10,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpipamd.so")
-SOURCES = ["pip_kernels.hip", "pip_quast.hip", "pip_host.cpp", "pip_tree.cpp"]
-HEADERS = ["pip_job.h", "pip_host.h", "pip_quast.h", os.path.join("..", "..", "include", "piplib_amd.h")]
+SOURCES = ["pip_adv_d.hip", "pip_adv_c.hip", "pip_adv_b.hip", "pip_adv_a.hip", "pip_kernels.hip", "pip_quast.hip", "pip_host.cpp",
+           "pip_tree.cpp"]
+HEADERS = ["pip_job.h", "pip_host.h", "pip_quast.h", "pip_advance.h", "pip_adv_inst.h", os.path.join("..", "..", "include", "piplib_amd.h")]
 
 
 def needs_build():
@@ -43,11 +44,29 @@ def build(force=False, verbose=True, profile=False):
 
 
 def _compile(out, extra, verbose):
+    """every source to its own object (side by side: the four take 20-50 s each), then one link; objects are kept under
+    piplib_amd/build/<variant>/ and reused while their source and the headers are older"""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-DNDEBUG",
-           "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-x", "hip"] + extra
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", out]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-Wall", "-Wno-unused-function",
+             "-Wno-unused-value"] + extra
+    tag = os.path.splitext(os.path.basename(out))[0] + ("_" + "_".join(x.strip("-").replace("=", "") for x in extra) if extra else "")
+    odir = os.path.join(HERE, "build", tag)
+    os.makedirs(odir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    jobs, objs = [], []
+    for src in SOURCES:
+        sp, obj = os.path.join(CSRC, src), os.path.join(odir, src + ".o")
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_t):
+            continue
+        cmd = [hipcc] + flags + ["-x", "hip", "-c", sp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

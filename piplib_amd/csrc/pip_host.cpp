@@ -19,7 +19,7 @@ void pipamd_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 extern "C" const char *pipamd_last_error(void) { return g_err; }
-extern "C" int pipamd_version(void) { return 100; }
+extern "C" int pipamd_version(void) { return PIPAMD_VERSION; }
 
 #define HIPCHK(call)                                                                    \
   do {                                                                                  \
@@ -42,7 +42,7 @@ extern "C" int pipamd_engine_create(pipamd_engine **out, int device) {
   pipamd_engine *e = (pipamd_engine *)calloc(1, sizeof *e);
   if (!e) return PIPAMD_E_NOMEM;
   e->device = device;
-  e->iter_limit = 1 << 20;
+  e->iter_limit = PIPAMD_DETLOG;
   pthread_mutex_init(&e->dt_lock, nullptr);
   *out = e;
   return PIPAMD_OK;
@@ -57,6 +57,7 @@ extern "C" void pipamd_engine_destroy(pipamd_engine *e) {
   for (void *b : e->d_side)
     if (b) hipFree(b);
   if (e->d_side_count) hipFree(e->d_side_count);
+  free(e->run);
   for (void *b : e->dt_buf)
     if (b) hipFree(b);
   if (e->dt_host) hipHostFree(e->dt_host);
@@ -129,21 +130,31 @@ extern "C" size_t pipamd_dense_pivot_bytes(const pipamd_batch_desc *d) {
   return 2ull * (size_t)d->ni * (size_t)(d->nvar + d->nparm + 1) * (d->entier_bits == 128 ? 16 : 8);
 }
 
-extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, const int64_t *d_rows,
-                                 void *stream) {
+extern "C" int pipamd_batch_load_part(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, const int64_t *d_rows,
+                                      int first, int count, void *stream) {
   if (e && hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;  // HIP's current device is per host thread
   PipBatchLayout lay;
   size_t jb;
   if (!e || !d_ws || !d_rows) return PIPAMD_E_INVALID;
   int rc = pipamd_batch_layout(d, &lay, &jb);
   if (rc) return rc;
+  if (first < 0 || count < 0 || first > lay.batch - count) {
+    pipamd_set_error("batch_load_part: tableaux %d..%d outside the batch of %d", first, first + count, lay.batch);
+    return PIPAMD_E_INVALID;
+  }
   PipJob *jobs = (PipJob *)d_ws;
   long long *arena = (long long *)((char *)d_ws + jb);
   // PIPAMD_T_ROWS_STAY: no copy pass, the first pivot launch reads the caller's rows (whole 16-byte units)
   const int ncol = d->nvar + d->nparm + 1;
   lay.pad = (d->tflags & PIPAMD_T_ROWS_STAY) && lay.ebits != 128 && ncol % 2 == 0 && ((uintptr_t)d_rows & 15) == 0;
-  HIPCHK(pipk_launch_batch_load(jobs, arena, (const long long *)d_rows, lay, (hipStream_t)stream));
+  HIPCHK(pipk_launch_batch_load(jobs, arena, (const long long *)d_rows, lay, first, count, (hipStream_t)stream));
   return PIPAMD_OK;
+}
+
+extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, const int64_t *d_rows,
+                                 void *stream) {
+  if (!d) return PIPAMD_E_INVALID;
+  return pipamd_batch_load_part(e, d_ws, d, d_rows, 0, d->batch, stream);
 }
 
 // traiter() for the whole batch, as a short sequence of launches without a host round trip in
@@ -159,50 +170,33 @@ extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batc
 // Only then the host looks at the number of tableaux still running (normally 0; tableaux that
 // hit the per-launch pivot limit `iter_limit` go through further tail launches).
 #define Q_CTRL 2 /* control words per launch: out_count, out_maxni */
-extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, void *stream) {
-  if (e && hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;  // HIP's current device is per host thread
+// Control words (out_count, out_maxni per launch) must be zero when a launch starts.  They come
+// from a pool of Q_POOL solves x Q_FAST launches that one memset zeroes every Q_POOL solves (a
+// solve of a small batch is a handful of runtime calls: this was a fifth of them); the rare
+// launches beyond Q_FAST of one solve use an overflow area zeroed on demand.
+enum { Q_POOL = 64, Q_FAST = 8, Q_NPOOL = Q_CTRL * Q_FAST * Q_POOL, Q_NCTRL = Q_NPOOL + Q_CTRL * PIPAMD_MAX_ROUNDS };
+
+// One pipamd_batch_solve in progress: everything the launch sequence needs between its asynchronous first part
+// (bulk + first tail launch + the copy of the tail's control words, pipamd_batch_solve_async) and its completion
+// (pipamd_batch_wait: further tail launches / re-housing while tableaux are left).
+struct BatchRun {
+  pipamd_engine *e;
+  pipamd_batch_desc d;
   PipBatchLayout lay;
-  size_t jb;
-  if (!e || !d_ws) return PIPAMD_E_INVALID;
-  int rc = pipamd_batch_layout(d, &lay, &jb);
-  if (rc) return rc;
-  PipJob *jobs = (PipJob *)d_ws;
-  long long *arena = (long long *)((char *)d_ws + jb);
-  hipStream_t st = (hipStream_t)stream;
-  if (!e->h_run) HIPCHK(hipHostMalloc((void **)&e->h_run, 2 * sizeof(int), hipHostMallocDefault));
-  // Control words (out_count, out_maxni per launch) must be zero when a launch starts.  They come
-  // from a pool of Q_POOL solves x Q_FAST launches that one memset zeroes every Q_POOL solves (a
-  // solve of a small batch is a handful of runtime calls: this was a fifth of them); the rare
-  // launches beyond Q_FAST of one solve use an overflow area zeroed on demand.
-  enum { Q_POOL = 64, Q_FAST = 8 };
-  const int npool = Q_CTRL * Q_FAST * Q_POOL, nctrl = npool + Q_CTRL * PIPAMD_MAX_ROUNDS;
-  if (!e->d_q || e->q_cap < lay.batch) {
-    if (e->d_q) HIPCHK(hipFree(e->d_q));
-    e->d_q = nullptr;
-    HIPCHK(hipMalloc((void **)&e->d_q, ((size_t)nctrl + 2 * (size_t)lay.batch) * sizeof(int)));
-    e->q_cap = lay.batch;
-    e->solve_seq = 0;
-  }
-  if (e->solve_seq % Q_POOL == 0 || e->pool_stream != st) {
-    HIPCHK(hipMemsetAsync(e->d_q, 0, (size_t)npool * sizeof(int), st));
-    e->solve_seq = 0;
-    e->pool_stream = st;
-  }
-  int *const pool = e->d_q + Q_CTRL * Q_FAST * (e->solve_seq % Q_POOL), *const over = e->d_q + npool;
-  e->solve_seq++;
-  bool over_zeroed = false;
-  auto ctrl_of = [&](int stage) -> int * { return stage < Q_FAST ? pool + Q_CTRL * stage : over + Q_CTRL * (stage - Q_FAST); };
-  int *list[2] = {e->d_q + nctrl, e->d_q + nctrl + e->q_cap};
-  e->nlaunch = 0;
-  const bool integer = (lay.tflags & PIPAMD_T_INT) != 0;
-  const int K1 = e->round_pivots > 0 ? e->round_pivots : 96;
-  const int KA = !integer ? 0 : (e->round_rows > 0 ? e->round_rows : 48);
-  int stage = 0;          // launches issued
-  bool have_list = false; // the previous launch's out list is this launch's input
-  int curS = lay.S;       // row capacity of the largest block in play (grows when tableaux are re-housed)
-  int grow_round = 0;
-  e->last_rehoused = 0;
-  auto next_stage = [&]() -> int {
+  PipJob *jobs;
+  long long *arena;
+  hipStream_t st;
+  int *pool, *over, *list[2];
+  bool over_zeroed, have_list, active;
+  int stage;       // launches issued
+  int curS;        // row capacity of the largest block in play (grows when tableaux are re-housed)
+  int grow_round;
+  int upper;       // what the host knows about the length of the next input list
+  int tail_waves;
+
+  int *ctrl_of(int stg) const { return stg < Q_FAST ? pool + Q_CTRL * stg : over + Q_CTRL * (stg - Q_FAST); }
+
+  int next_stage() {
     if (stage >= PIPAMD_MAX_ROUNDS) {
       pipamd_set_error("batch_solve: more than %d launches", PIPAMD_MAX_ROUNDS);
       return PIPAMD_E_SOLVER;
@@ -212,22 +206,28 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
       over_zeroed = true;
     }
     return PIPAMD_OK;
-  };
+  }
+
   // expanser (traiter.c:55-88, called by integrer when the tableau is full, integrer.c:410-415) for the `n` jobs of
   // the last launch's out list: those at PIPAMD_ST_CAPACITY move into blocks of twice the row capacity in a side arena
   // of the engine and go on; the others are passed through.  A stage like a launch: it consumes the list and writes
   // the next one.  When the engine's limits (16-bit row codes; 128-bit entries: the LDS image) allow no larger
   // block, the pass only drops the jobs that are at the limit from the list: they keep PIPAMD_ST_CAPACITY.
-  auto rehouse = [&](int n) -> int {
-    pipamd_batch_desc d2 = *d;
+  int rehouse(int n) {
+    pipamd_batch_desc d2 = d;
     int newS = curS * 2 > curS + 32 ? curS * 2 : curS + 32;
+    if (e->grow_step > 0) newS = curS + e->grow_step;  // testing aid: many small growth rounds
+    // the caller's row budget (pipamd_engine_set_max_rows); never below what the batch was loaded with
+    const int budget = e->max_rows > 0 ? (e->max_rows > lay.S ? e->max_rows : lay.S) : PIPAMD_SMAX;
+    if (newS > budget) newS = budget;
+    if (newS < curS) newS = curS;  // == curS: nothing larger is allowed -- the pass drops the jobs that are at the limit
     PipBatchLayout nl;
     size_t jb2;
     d2.batch = n;
     for (;;) {
-      d2.cap_cuts = newS - d->ni;
+      d2.cap_cuts = newS - d.ni;
       if (pipamd_batch_layout(&d2, &nl, &jb2) == PIPAMD_OK) break;
-      if (newS <= curS) return PIPAMD_E_SOLVER;  // the shape the batch was loaded with: cannot fail
+      if (newS <= curS) return PIPAMD_E_SOLVER;  // the shape the batch was loaded with (or grew to): cannot fail
       newS = curS + (newS - curS) / 2;
     }
     int rc2 = next_stage();
@@ -255,8 +255,9 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
     curS = newS;
     e->last_rehoused += n;  // an upper bound: the list also carries the jobs still running
     return PIPAMD_OK;
-  };
-  auto launch = [&](int waves, int budget, int smax, int upper) -> int {
+  }
+
+  int launch(int waves, int budget, int smax, int grid) {
     int rcs = next_stage();
     if (rcs) return rcs;
     if (smax > curS) smax = curS;
@@ -277,25 +278,79 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
     void *big[2] = {&e->d_scratch, &e->scratch_bytes};
     // a uniform batch without parameters whose rows fill a wave's 128 columns exactly: FULL kernels
     const int hints = (lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 && lay.W == 128) ? 1 : 0;
-    HIPCHK(pipk_launch_advance_q(jobs, arena, lay.batch, lay.nvar + smax, smax, lay.W, budget, waves, lay.ebits, q5, upper,
+    HIPCHK(pipk_launch_advance_q(jobs, arena, lay.batch, lay.nvar + smax, smax, lay.W, budget, waves, lay.ebits, q5, grid,
                                  big, hints, e->d_prof, st));
     if (!e->no_timing) HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
     e->nlaunch++;
     stage++;
     have_list = true;
     return PIPAMD_OK;
-  };
-  const int tail_waves = e->waves_per_job ? e->waves_per_job : (e->tail_waves ? e->tail_waves : 4);
-  if (lay.batch >= (e->bulk_min > 0 ? e->bulk_min : 2048) && e->waves_per_job != 4 && e->waves_per_job != 8 && !e->single_launch) {
-    const int budget = e->iter_limit < K1 ? e->iter_limit : K1;
-    rc = launch(1, budget, lay.ni + (KA < budget ? KA : budget), lay.batch);
-    if (rc) return rc;
   }
-  int upper = lay.batch;  // what the host knows about the length of the next input list
-  for (;;) {
-    rc = launch(tail_waves, e->iter_limit, curS, upper);
+
+  // a tail launch over what is left, and the copy of its control words to the host
+  int tail() {
+    int rc = launch(tail_waves, e->iter_limit, curS, upper);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    return PIPAMD_OK;
+  }
+
+  int begin(pipamd_engine *e_, void *d_ws, const pipamd_batch_desc *d_, void *stream) {
+    e = e_;
+    size_t jb;
+    int rc = pipamd_batch_layout(d_, &lay, &jb);
+    if (rc) return rc;
+    d = *d_;
+    jobs = (PipJob *)d_ws;
+    arena = (long long *)((char *)d_ws + jb);
+    st = (hipStream_t)stream;
+    if (!e->h_run) HIPCHK(hipHostMalloc((void **)&e->h_run, 2 * sizeof(int), hipHostMallocDefault));
+    if (!e->d_q || e->q_cap < lay.batch) {
+      if (e->d_q) HIPCHK(hipFree(e->d_q));
+      e->d_q = nullptr;
+      HIPCHK(hipMalloc((void **)&e->d_q, ((size_t)Q_NCTRL + 2 * (size_t)lay.batch) * sizeof(int)));
+      e->q_cap = lay.batch;
+      e->solve_seq = 0;
+    }
+    if (e->solve_seq % Q_POOL == 0 || e->pool_stream != st) {
+      HIPCHK(hipMemsetAsync(e->d_q, 0, (size_t)Q_NPOOL * sizeof(int), st));
+      e->solve_seq = 0;
+      e->pool_stream = st;
+    }
+    pool = e->d_q + Q_CTRL * Q_FAST * (e->solve_seq % Q_POOL);
+    over = e->d_q + Q_NPOOL;
+    e->solve_seq++;
+    over_zeroed = false;
+    list[0] = e->d_q + Q_NCTRL;
+    list[1] = e->d_q + Q_NCTRL + e->q_cap;
+    e->nlaunch = 0;
+    e->last_rehoused = 0;
+    stage = 0;
+    have_list = false;
+    curS = lay.S;
+    grow_round = 0;
+    const bool integer = (lay.tflags & PIPAMD_T_INT) != 0;
+    const int K1 = e->round_pivots > 0 ? e->round_pivots : 96;
+    const int KA = !integer ? 0 : (e->round_rows > 0 ? e->round_rows : 48);
+    tail_waves = e->waves_per_job ? e->waves_per_job : (e->tail_waves ? e->tail_waves : 4);
+    upper = lay.batch;
+    if (lay.batch >= (e->bulk_min > 0 ? e->bulk_min : 2048) && e->waves_per_job != 4 && e->waves_per_job != 8) {
+      const int budget = e->iter_limit < K1 ? e->iter_limit : K1;
+      rc = launch(1, budget, lay.ni + (KA < budget ? KA : budget), lay.batch);
+      if (rc) return rc;
+      if (e->single_launch) {  // measurement aid: the bulk launch on its own (its tableaux stay PIPAMD_ST_RUN)
+        HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        active = true;
+        return PIPAMD_OK;
+      }
+    }
+    rc = tail();
+    if (rc) return rc;
+    active = true;
+    return PIPAMD_OK;
+  }
+
+  int wait_stream() {
     if (e->blocking_wait) {  // sleep between looks at the stream instead of spinning on it (pipamd_engine_set_blocking_wait)
       hipError_t q;
       const struct timespec nap = {0, 40000};
@@ -304,15 +359,105 @@ extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_bat
     } else {
       HIPCHK(hipStreamSynchronize(st));
     }
-    if (e->h_run[0] <= 0 || e->single_launch) break;
-    upper = e->h_run[0];
-    if (e->h_run[1] & PIPAMD_Q_CAPFLAG) {  // some of them have spent their spare rows
-      rc = rehouse(upper);
+    return PIPAMD_OK;
+  }
+
+  int finish() {
+    active = false;
+    for (;;) {
+      int rc = wait_stream();
+      if (rc) return rc;
+      if (e->h_run[0] <= 0 || e->single_launch) break;
+      upper = e->h_run[0];
+      if (e->h_run[1] & PIPAMD_Q_CAPFLAG) {  // some of them have spent their spare rows
+        rc = rehouse(upper);
+        if (rc) return rc;
+      }
+      rc = tail();
       if (rc) return rc;
     }
+    if (grow_round > 0) {
+      HIPCHK(pipk_launch_rehouse_finish(jobs, arena, lay.batch, lay.sol_words, st));
+      int rc = wait_stream();  // the side arenas serve the engine's next solve
+      if (rc) return rc;
+    }
+    e->timed = !e->no_timing;
+    return PIPAMD_OK;
   }
-  if (grow_round > 0) HIPCHK(pipk_launch_rehouse_finish(jobs, arena, lay.batch, lay.sol_words, st));
-  e->timed = !e->no_timing;
+};
+
+static int batch_begin(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, void *stream) {
+  if (e && hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;  // HIP's current device is per host thread
+  if (!e || !d_ws || !d) return PIPAMD_E_INVALID;
+  if (!e->run) {
+    e->run = (BatchRun *)calloc(1, sizeof(BatchRun));
+    if (!e->run) return PIPAMD_E_NOMEM;
+  }
+  if (e->run->active) {
+    pipamd_set_error("this engine already has a batch solve in flight: pipamd_batch_wait first (one per engine; engines are cheap)");
+    return PIPAMD_E_INVALID;
+  }
+  return e->run->begin(e, d_ws, d, stream);
+}
+
+extern "C" int pipamd_batch_solve(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, void *stream) {
+  int rc = batch_begin(e, d_ws, d, stream);
+  if (rc) {
+    if (e && e->run) e->run->active = false;
+    return rc;
+  }
+  return e->run->finish();
+}
+
+extern "C" int pipamd_batch_solve_async(pipamd_engine *e, void *d_ws, const pipamd_batch_desc *d, void *stream) {
+  int rc = batch_begin(e, d_ws, d, stream);
+  if (rc && e && e->run) e->run->active = false;
+  return rc;
+}
+
+extern "C" int pipamd_batch_wait(pipamd_engine *e) {
+  if (e && hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
+  if (!e) return PIPAMD_E_INVALID;
+  if (!e->run || !e->run->active) return PIPAMD_OK;  // nothing in flight
+  return e->run->finish();
+}
+
+extern "C" int pipamd_batch_poll(pipamd_engine *e) {
+  if (!e) return PIPAMD_E_INVALID;
+  if (!e->run || !e->run->active) return 1;
+  hipError_t q = hipStreamQuery(e->run->st);
+  if (q == hipErrorNotReady) return 0;
+  if (q != hipSuccess) {
+    pipamd_set_error("hipStreamQuery failed: %s", hipGetErrorString(q));
+    return PIPAMD_E_HIP;
+  }
+  return 1;  // the launches enqueued so far have ended: pipamd_batch_wait will not block unless tableaux are left
+}
+
+// Row budget of pipamd_batch_solve: a tableau is re-housed (expanser) while its row capacity stays within `rows`
+// (0 = the default: only the engine's own limit); beyond it the tableau ends PIPAMD_ST_CAPACITY.  The reference grows
+// without bound, and so does the default here; a caller that feeds tableaux on which Gomory cuts converge slowly
+// (thousands of cut rows, each pivot then rewriting thousands of rows) bounds the memory and time of a batch with it.
+extern "C" int pipamd_engine_set_max_rows(pipamd_engine *e, int rows) {
+  if (!e || rows < 0) return PIPAMD_E_INVALID;
+  e->max_rows = rows;
+  return PIPAMD_OK;
+}
+
+// Testing aid: a tableau that has spent its spare rows is re-housed with `rows` more instead of twice as many, so
+// that a test sees many growth rounds on small inputs (0 = the default doubling).
+extern "C" int pipamd_debug_grow_step(pipamd_engine *e, int rows) {
+  if (!e || rows < 0) return PIPAMD_E_INVALID;
+  e->grow_step = rows;
+  return PIPAMD_OK;
+}
+
+// Measurement aid (bench.py's per-launch roofline): the solve stops after its first launch -- the one-wave bulk
+// launch when the batch has one -- leaving unfinished tableaux at PIPAMD_ST_RUN; pipamd_batch_counters then tells
+// what that launch alone did.
+extern "C" int pipamd_debug_single_launch(pipamd_engine *e, int on) {
+  if (!e) return PIPAMD_E_INVALID;
+  e->single_launch = on ? 1 : 0;
   return PIPAMD_OK;
 }
 
@@ -439,7 +584,8 @@ extern "C" int pipamd_engine_set_waves_per_job(pipamd_engine *e, int waves) {
 
 extern "C" int pipamd_engine_set_iter_limit(pipamd_engine *e, int pivots_per_launch) {
   if (!e || pivots_per_launch < 1) return PIPAMD_E_INVALID;
-  e->iter_limit = pivots_per_launch;
+  // a launch logs (pivot, denominator) per pivot for the determinant replay: PIPAMD_DETLOG entries per job
+  e->iter_limit = pivots_per_launch < PIPAMD_DETLOG ? pivots_per_launch : PIPAMD_DETLOG;
   return PIPAMD_OK;
 }
 

@@ -43,7 +43,10 @@ struct pipamd_engine {
   void *d_side[PIPAMD_MAX_GROW];
   size_t side_bytes[PIPAMD_MAX_GROW];
   int *d_side_count;
+  int max_rows;      /* row budget per tableau of pipamd_batch_solve's growth (0 = the engine's limit) */
+  int grow_step;     /* testing aid: rows added per growth round (0 = double) */
   int last_rehoused; /* tableaux the last pipamd_batch_solve re-housed (all rounds) */
+  struct BatchRun *run; /* the batch solve in progress (pipamd_batch_solve_async .. pipamd_batch_wait) */
 };
 
 void pipamd_set_error(const char *fmt, ...);
@@ -59,8 +62,8 @@ hipError_t pipk_launch_advance_q(PipJob *jobs, long long *arena, int njobs, int 
                                  int waves_per_job, int ebits, void *const *q5, int grid, void **big, int hints,
                                  unsigned long long *prof,
                                  hipStream_t stream);
-hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long long *rows, PipBatchLayout lay,
-                                  hipStream_t stream);
+hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long long *rows, PipBatchLayout lay, int first,
+                                  int count, hipStream_t stream);
 hipError_t pipk_launch_batch_results(const PipJob *jobs, const long long *arena, int njobs, int nvar, int nparm,
                                      int ebits, int *status, int *pivots, int *cuts, void *sol_num, void *sol_den,
                                      hipStream_t stream);

@@ -60,8 +60,9 @@ def gather_results(parts, total, device="cpu", dst=0):
     is the slice length (status, pivots, cuts int32; sol_num, sol_den int64 with any trailing
     shape).  Returns, on rank `dst`, the dict of full-length tensors in input order (None on the
     other ranks).  Slices differ in length by at most one tableau, so every rank pads its tensors
-    to the longest slice and a single all_gather per tensor moves them; a 1-rank job returns its
-    parts unchanged."""
+    to the longest slice and ONE `gather` per tensor moves them to `dst` -- only `dst` receives
+    (world - 1 slices over its xGMI links; an all_gather would deliver every slice to every rank,
+    world times the traffic); a 1-rank job returns its parts unchanged."""
     import torch
     if not _active():
         return parts
@@ -76,8 +77,8 @@ def gather_results(parts, total, device="cpu", dst=0):
         assert t.shape[0] == hi - lo, (key, t.shape, lo, hi)
         pad = torch.zeros((longest,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[:hi - lo] = t
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad)
+        bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, bufs, dst=dst)
         if rank == dst:
             out[key] = torch.cat([bufs[r][:spans[r][1] - spans[r][0]] for r in range(world)], dim=0)
     return out

@@ -21,6 +21,7 @@ class BatchDesc(C.Structure):
                 ("batch", "nvar", "nparm", "ni", "bigparm", "tflags", "cap_cuts", "cap_newparm", "entier_bits")]
 
 
+ABI_VERSION = 300  # include/piplib_amd.h PIPAMD_VERSION
 _lib = None
 
 
@@ -34,6 +35,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} missing: run `python -m piplib_amd.build` (HIP extension is mandatory)")
         L = C.CDLL(LIB_PATH)
+        if L.pipamd_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} is interface version {L.pipamd_version()}, this binding is written for "
+                               f"{ABI_VERSION} (include/piplib_amd.h PIPAMD_VERSION): rebuild with `python -m piplib_amd.build`")
         L.pipamd_last_error.restype = C.c_char_p
         L.pipamd_batch_workspace_bytes.restype = C.c_size_t
         L.pipamd_batch_workspace_bytes.argtypes = [C.POINTER(BatchDesc)]
@@ -49,6 +53,11 @@ def lib():
         L.pipamd_last_solve_launches.argtypes = [C.c_void_p]
         L.pipamd_batch_load.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p, C.c_void_p]
         L.pipamd_batch_solve.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p]
+        L.pipamd_batch_solve_async.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p]
+        L.pipamd_batch_wait.argtypes = [C.c_void_p]
+        L.pipamd_batch_poll.argtypes = [C.c_void_p]
+        L.pipamd_batch_load_part.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p, C.c_int, C.c_int,
+                                             C.c_void_p]
         L.pipamd_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc)] + [C.c_void_p] * 6
         L.pipamd_batch_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BatchDesc), C.c_void_p, C.c_void_p]
         L.pipamd_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -94,6 +103,10 @@ class Engine:
         lib().pipamd_last_device_tree.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _check(lib().pipamd_last_device_tree(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_max_rows(self, rows):
+        lib().pipamd_engine_set_max_rows.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().pipamd_engine_set_max_rows(self._h, int(rows)))
 
     def set_blocking_wait(self, on):
         lib().pipamd_engine_set_blocking_wait.argtypes = [C.c_void_p, C.c_int]
@@ -167,8 +180,26 @@ class Batch:
         _check(lib().pipamd_batch_load(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc),
                                        C.c_void_p(self.rows.data_ptr()), self._stream()))
 
+    def load_part(self, rows, first):
+        """tableaux first .. first + len(rows) - 1 of the batch from another resident row array (pipamd_batch_load_part)"""
+        assert rows.is_cuda and rows.is_contiguous() and rows.shape[1:] == self.rows.shape[1:]
+        _check(lib().pipamd_batch_load_part(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc),
+                                            C.c_void_p(rows.data_ptr()), int(first), int(rows.shape[0]), self._stream()))
+
     def solve(self):
         _check(lib().pipamd_batch_solve(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc), self._stream()))
+
+    def solve_async(self, stream=None):
+        """pipamd_batch_solve_async on `stream` (a raw hipStream_t handle; default: torch's current stream); one solve
+        in flight per engine -- wait() before the next one, and before fetch()."""
+        st = C.c_void_p(stream) if stream is not None else self._stream()
+        _check(lib().pipamd_batch_solve_async(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc), st))
+
+    def wait(self):
+        _check(lib().pipamd_batch_wait(self.e._h))
+
+    def poll(self):
+        return int(lib().pipamd_batch_poll(self.e._h))
 
     def fetch(self):
         _check(lib().pipamd_batch_results(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc),

@@ -173,22 +173,27 @@ def _compare_ids(g, rows, ids, nvar, nq, wide=False, exe=None):
         assert got == pb.squash(r.text), b
 
 
-@pytest.mark.parametrize("batch,nvar,ni,cap,ebits", [
-    (300, 31, 16, 1, 64),      # four-wave launches only; nearly every tableau outgrows one spare row, most several times
-    (2400, 31, 16, 2, 64),     # through the one-wave bulk launch (>= 2048 tableaux) first
-    (64, 127, 64, 3, 64),      # BASELINE configs[2]'s shape
-    (200, 31, 16, 1, 128),     # 128-bit entries
+@pytest.mark.parametrize("batch,nvar,ni,cap,ebits,step", [
+    (300, 31, 16, 1, 64, 0),      # four-wave launches only; nearly every tableau outgrows one spare row
+    (2400, 31, 16, 2, 64, 0),     # through the one-wave bulk launch (>= 2048 tableaux) first
+    (400, 127, 64, 1, 64, 0),     # BASELINE configs[2]'s shape
+    (400, 127, 64, 1, 64, 3),     # ... with three more rows per growth round: up to 14 rounds for the longest tableau
+    (200, 31, 16, 1, 128, 2),     # 128-bit entries, several rounds
 ])
-def test_batch_layer_rehouses_full_tableaux(batch, nvar, ni, cap, ebits):
+def test_batch_layer_rehouses_full_tableaux(batch, nvar, ni, cap, ebits, step):
     """expanser (traiter.c:55-88) on cut overflow (integrer.c:410-415) in the batch layer: pipamd_batch_solve moves a
     tableau that has spent its `cap_cuts` spare rows into a block of twice the row capacity and goes on, as often as
     it takes -- no engine-only PIPAMD_ST_CAPACITY is left, and every answer and pivot count is the oracle's."""
+    import ctypes as C
     import numpy as np
     import torch
     import pipbatch as pb
     from piplib_amd import engine as eng, synth
     rows = synth.lexmin_batch(4242, batch, nvar, ni)
     e = eng.Engine(0)
+    if step:
+        eng.lib().pipamd_debug_grow_step.argtypes = [C.c_void_p, C.c_int]
+        assert eng.lib().pipamd_debug_grow_step(e._h, step) == 0
     g = eng.Batch(e, rows, nvar, 0, tflags=eng.T_INT, cap_cuts=cap, entier_bits=ebits)
     for _ in range(2):  # twice: the second solve reuses the engine's side arenas
         g.load()
@@ -198,8 +203,8 @@ def test_batch_layer_rehouses_full_tableaux(batch, nvar, ni, cap, ebits):
         st, ct = g.status.cpu().numpy(), g.cuts.cpu().numpy()
         assert np.isin(st, [eng.ST_SOLUTION, eng.ST_NIL]).all(), np.unique(st, return_counts=True)
         assert (ct > cap).sum() >= batch // 4      # the spare rows really were too few
-        if cap == 1:
-            assert (ct > ni + 33).any()             # ... and more than once for some tableau (17 -> 49 -> 98 rows)
+        if step:
+            assert (ct > cap + 2 * step).sum() >= batch // 8   # ... in more than two rounds for many
         _compare_ids(g, rows, np.arange(batch), nvar, 1, wide=ebits == 128,
                      exe=pb.ORACLEPIP128 if ebits == 128 else None)
 
@@ -294,12 +299,49 @@ def _check_against_records(g, recs, lo=0):
     return checked, big
 
 
+def _check_against_gmp(g, name, lo=0, hi=None):
+    """the 128-bit engine's results for problems lo..hi of a GMP fixture family against the REFERENCE's own
+    arbitrary-precision build (tests/golden/gmp): status, number of pivoter calls and the whole solution (sha256 of the
+    squashed sol_edit text; the text itself where the fixture keeps it) on every record on which no value left the
+    signed 128-bit range.  Returns (compared, of them with entries beyond 2^63, limb-overflow verdicts)."""
+    import numpy as np
+    from gmpfix import gmp_fixture
+    from gpu_common import solution_text
+    import pipbatch as pb
+    from piplib_amd import engine as eng
+    probs, flags, recs, sha = gmp_fixture(name)
+    hi = len(recs) if hi is None else hi
+    st, pv = g.status.cpu().numpy(), g.pivots.cpu().numpy()
+    num, den = eng.wide_to_int(g.sol_num.cpu().numpy()), eng.wide_to_int(g.sol_den.cpu().numpy())
+    same = big = limb = 0
+    for i in range(lo, hi):
+        r, b = recs[i], i - lo
+        if "status" not in r or r["wrap128"]:
+            continue
+        assert r["status"] == pb.ST_OK, (name, i)   # no parameters, arbitrary precision: the reference always answers
+        if st[b] == eng.ST_OVERFLOW:
+            # the fixed-width flavours keep at most three determinant limbs (traiter.c:412-446), the GMP flavour one
+            # unbounded determinant: the only verdict that may differ, and the CPU restatement must share it
+            o = pb.run_batch(pb.ORACLEPIP128, [probs[i]], flags, timeout=120).results[0]
+            assert o.status == pb.ST_ABORT and o.abort_code == 2, (name, i)
+            limb += 1
+            continue
+        assert st[b] in (eng.ST_SOLUTION, eng.ST_NIL), (name, i, st[b])
+        assert pv[b] == r["pivots"], (name, i, pv[b], r["pivots"])
+        got = "()" if st[b] == eng.ST_NIL else solution_text(num[b], den[b])
+        assert sha(got) == r["sha"], (name, i)
+        if "text" in r:
+            assert pb.squash(got) == pb.squash(r["text"]), (name, i)
+        same += 1
+        big += r["entry_bits"] > 63
+    return same, big, limb
+
+
 @pytest.mark.parametrize("family,cap", [("dense10", 700), ("dense14", 700)])
 def test_int128_overflow_safe_path(family, cap):
-    """Dense large-coefficient tableaux: the int64 reference aborts ("Integer overflow") on many of
-    them.  The 128-bit engine is checked against the committed exact-arithmetic fixtures
-    (tests/golden/bigint, made by tests/golden/make_bigint_fixtures.py with Python ints): status,
-    pivot and cut counts, every numerator and denominator."""
+    """Dense large-coefficient tableaux: the int64 reference aborts ("Integer overflow") on many of them.  The
+    128-bit engine is held against what the reference's own GMP build computes for them (tests/golden/gmp): status,
+    pivot count, every numerator and denominator; and against the exact-arithmetic records of round 2 (cut counts)."""
     import numpy as np
     import pipbatch as pb
     from piplib_amd import synth
@@ -310,43 +352,27 @@ def test_int128_overflow_safe_path(family, cap):
     o64 = pb.run_batch(pb.ORACLEPIP, probs, pb.F_NOSIMPLIFY)
     assert sum(r.status == pb.ST_ABORT for r in o64.results) > 5      # int64 really overflows here
     g = _gpu128(rows, nvar, 1, cap)
+    same, big, limb = _check_against_gmp(g, family)
+    assert same >= 0.9 * len(recs) and big >= 10 and limb == 0, (same, big, limb)
     checked, _ = _check_against_records(g, recs)
     assert checked >= 0.6 * len(recs), checked
 
 
 def test_full_size_int128_config():
-    """BASELINE configs[4]: 1k-batch 128x256 tableaux on the 128-bit Entier path, with coefficients
-    that push tableau entries beyond 2^63 (16 non-zeros of magnitude <= 30 per row).  The first 24
-    tableaux are pinned by the exact-arithmetic fixture tests/golden/bigint/wide128.json (`entry_bits`
-    there says which of them go beyond 2^63); ALL 1,000 are compared with the 128-bit C oracle, which
-    tests/test_oracle_golden.py pins to the same fixture."""
-    import numpy as np
-    from gpu_common import solution_text
-    import pipbatch as pb
-    from piplib_amd import engine as eng
+    """BASELINE configs[4]: 1k-batch 128x256 tableaux on the 128-bit Entier path, with coefficients that push tableau
+    entries beyond 2^63 (16 non-zeros of magnitude <= 30 per row; 587 of the 1,000 tableaux go beyond 2^63, 5 beyond
+    2^127).  EVERY tableau is held against the output of the reference's own GMP build (tests/golden/gmp/wide128.json:
+    pivot count and the whole solution), and the first 24 also against round 2's exact-arithmetic records (cut counts)."""
     import make_bigint_fixtures as mk  # noqa: F401  (path set up by _bigint_family)
     rows24, recs = _bigint_family("wide128")
     rows = mk.rows_full("wide128")
     assert rows.shape[0] == 1000 and (rows[:len(recs)] == rows24).all()
     nvar = mk.FAMILIES["wide128"]["nvar"]
     g = _gpu128(rows, nvar, 1, None)
-    checked, big = _check_against_records(g, recs)
-    assert checked >= 12 and big >= 6, (checked, big)   # entries beyond 2^63 really occur
-    st, pv = g.status.cpu().numpy(), g.pivots.cpu().numpy()
-    num, den = eng.wide_to_int(g.sol_num.cpu().numpy()), eng.wide_to_int(g.sol_den.cpu().numpy())
-    o = _oracle_all(rows, nvar, 1, exe=pb.ORACLEPIP128)
-    same = 0
-    for b, r in enumerate(o):
-        if st[b] == eng.ST_CAPACITY:
-            continue
-        if r.status == pb.ST_ABORT:
-            assert st[b] == eng.ST_OVERFLOW, (b, st[b], r.abort_code)
-            continue
-        assert pv[b] == r.pivots, (b, pv[b], r.pivots)
-        got = "()" if st[b] == eng.ST_NIL else pb.squash(solution_text(num[b], den[b]))
-        assert got == pb.squash(r.text), b
-        same += 1
-    assert same >= 0.9 * rows.shape[0], same
+    same, big, limb = _check_against_gmp(g, "wide128")
+    assert same >= 990 and big >= 500 and limb == 0, (same, big, limb)
+    checked, big24 = _check_against_records(g, recs)
+    assert checked >= 12 and big24 >= 6, (checked, big24)
 
 
 def test_many_parametric_problems_multithreaded():
