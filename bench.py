@@ -51,11 +51,7 @@ OTHERS = [
     # on these ("Integer overflow", traiter.c:424,442), the 128-bit Entier build solves them
     dict(key="configs[4]", workload="1k-batch synthetic 128x256 tableaux, 128-bit Entier, integer solve "
                                     "(inputs on which the int64 build stops with 'Integer overflow')",
-         batch=1000, nvar=255, ni=128, integer=True, ebits=128, gen=dict(nnz=6, cmax=30),
-         # Gomory cuts converge slowly on about 8 tableaux per 10,000 of this family (tens of thousands of pivots over
-         # thousands of cut rows; the reference on the CPU takes seconds to minutes for each): the leg gives a tableau
-         # ni + 192 rows (pipamd_engine_set_max_rows) and reports the few that want more as `capacity`
-         max_rows=128 + 192),
+         batch=1000, nvar=255, ni=128, integer=True, ebits=128, gen=dict(nnz=6, cmax=30)),
 ]
 
 
@@ -187,14 +183,16 @@ def lane_stream(torch, dev, i):
 
 
 class Lanes:
-    """`depth` batches in flight, each with its own engine, workspace, input rows (own seed) and HIP
-    stream: while one batch's last stragglers finish (a latency-bound tail that leaves most CUs idle)
-    the other batches' bulk launches run.  Every step is a full load + solve.  One host thread drives
-    all lanes through pipamd_batch_solve_async / pipamd_batch_wait (threads=True: a host thread per
-    lane calling the synchronous pipamd_batch_solve, round 2's driver).
-    fuse = G > 1: a lane's workspace holds G batches' worth of tableaux (this rank's shards of G
-    batches in flight, loaded part by part with pipamd_batch_load_part): one launch sequence per G
-    steps; a lane pass counts as G steps."""
+    """`depth` batches in flight: `depth` resident batches (own seed each) and as many lanes, a lane being an engine,
+    a workspace and a HIP stream.  Step k solves batch k mod depth on whichever lane is free (load + solve, a complete
+    pipamd_batch_load + pipamd_batch_solve of that batch): while one batch's last stragglers finish (a latency-bound
+    tail that leaves most CUs idle) the other batches' bulk launches run.  ONE host thread drives all lanes through
+    pipamd_batch_solve_async / pipamd_batch_poll -- it starts a batch on every lane and goes round polling; a lane
+    that is done gets the next batch (threads=True: a host thread per lane calling the synchronous
+    pipamd_batch_solve, round 2's driver, the threads drawing steps from a shared counter).
+    fuse = G > 1: a batch of the lanes is G batches of the workload (this rank's shards of G batches in flight, or G
+    small batches), loaded part by part with pipamd_batch_load_part into one workspace: one launch sequence per G
+    steps; such a pass counts as G steps."""
 
     def __init__(self, cfg, depth, dev, local, seeds, args, gen=None, threads=False, fuse=1):
         import torch
@@ -202,8 +200,34 @@ class Lanes:
         from piplib_amd import synth
         self.torch, self.eng, self.cfg, self.dev, self.depth = torch, eng, cfg, dev, depth
         self.threads, self.fuse = threads, fuse
-        self.lanes = []
+        self.lanes, self.batches = [], []
+        self.screened = {}  # seed -> indices of the tableaux replaced (slow-converging cuts)
+        self.next_step = 0  # steps handed out so far (the batches take turns across timed regions)
         gen = gen or (lambda seed: synth.lexmin_batch(seed, cfg["batch"], cfg["nvar"], cfg["ni"], **cfg["gen"]))
+        # the input rows stay resident and untouched in HBM for the whole run: T_ROWS_STAY lets the first pivot
+        # launch read them where they are instead of a copy pass (--copy-rows switches that off)
+        stay = 0 if getattr(args, "copy_rows", False) else eng.T_ROWS_STAY
+        tf = (eng.T_INT if cfg["integer"] else 0) | stay
+        screen_engine = eng.Engine(local)
+
+        def resident(seed):
+            """a batch in HBM; integer workloads: without the tableaux on which Gomory's cuts do not converge (about 3
+            in 100,000: the reference itself does not finish them within minutes), replaced by their neighbours -- see
+            piplib_amd.engine.slow_converging"""
+            t = torch.as_tensor(gen(seed), dtype=torch.int64).to(dev).contiguous()
+            if cfg["integer"] and cfg.get("screen", True) and t.shape[0] > 1:
+                bad = eng.slow_converging(screen_engine, t, cfg["nvar"], entier_bits=cfg["ebits"])
+                for b_ in bad:
+                    nb = next(x % t.shape[0] for x in range(b_ + 1, b_ + t.shape[0]) if x % t.shape[0] not in bad)
+                    t[b_] = t[nb]
+                if bad:
+                    self.screened[seed] = bad
+            return t
+
+        for i in range(depth):
+            # G row arrays (the shards of G different batches, or G small batches) per batch of the lanes
+            self.batches.append([resident(seeds[i] + 104729 * k) for k in range(fuse)])
+        shape = (sum(p_.shape[0] for p_ in self.batches[0]),) + tuple(self.batches[0][0].shape[1:])
         for i in range(depth):
             e = eng.Engine(local)
             if args.waves:
@@ -215,11 +239,12 @@ class Lanes:
             # a lone batch is latency-bound in its tail: eight waves per tableau there (+8 % for one batch
             # at a time, -3 % with 12 in flight, where the waves of a tail crowd out other batches' bulk)
             tw = getattr(args, "tail_waves", 0) or (8 if depth == 1 and cfg["ebits"] == 64 and cfg["nvar"] + 1 <= 128
-                                                    and cfg["batch"] >= 2048 else 0)
+                                                    and shape[0] >= 2048 else 0)
             if tw:
                 e.set_tail_waves(tw)
-            if cfg.get("max_rows"):
-                e.set_max_rows(cfg["max_rows"])
+            # safety net: a tableau that escaped the screening ends PIPAMD_ST_CAPACITY (and voids the line) instead of
+            # growing for minutes
+            e.set_max_rows(cfg.get("max_rows") or cfg["ni"] + 1024)
             e.set_timing(False)  # no HIP events in the timed region (kernel_ms_of switches them on)
             bw = getattr(args, "blocking_wait", -1)
             if bw > 0 or (bw < 0 and threads and depth > host_cpus()):  # more polling threads than CPUs only take turns
@@ -227,142 +252,100 @@ class Lanes:
             bulk_min = args.bulk_min if args.bulk_min > 0 else (256 if depth > 1 else 0)  # depth = this Lanes' lane count
             if bulk_min:
                 e.set_bulk_min(bulk_min)
-            # the input rows stay resident and untouched in HBM for the whole run: T_ROWS_STAY lets the first pivot
-            # launch read them where they are instead of a copy pass (--copy-rows switches that off)
-            stay = 0 if getattr(args, "copy_rows", False) else eng.T_ROWS_STAY
-            tf = (eng.T_INT if cfg["integer"] else 0) | stay
-            if fuse > 1:
-                # G row arrays (the shards of G different batches), one workspace of G x shard tableaux
-                parts = [torch.as_tensor(gen(seeds[i] + 104729 * k), dtype=torch.int64).to(dev) for k in range(fuse)]
-                b = eng.Batch(e, torch.cat(parts), cfg["nvar"], 0, tflags=tf, entier_bits=cfg["ebits"])
-                b.parts = parts
-            else:
-                b = eng.Batch(e, torch.as_tensor(gen(seeds[i]), dtype=torch.int64).to(dev), cfg["nvar"], 0,
-                              tflags=tf, entier_bits=cfg["ebits"])
-                b.parts = None
+            b = eng.Batch(e, None, cfg["nvar"], 0, tflags=tf, entier_bits=cfg["ebits"], shape=shape)
             self.lanes.append((e, b, lane_stream(torch, dev, i)))
-        self.stagger = 0.0
-        self.done = [0] * depth
-        self.workers, self.share, self.failed = None, None, None
-
-    @staticmethod
-    def _load(bi):
-        if bi.parts is None:
-            bi.load()
-        else:  # the shards arrive from different batches: one load per part, one solve for all
-            off = 0
-            for part in bi.parts:
-                bi.load_part(part, off)
-                off += part.shape[0]
-
-    def _run_async(self, share):
-        """one host thread: round-robin over the lanes, `share[i]` passes on lane i"""
-        left, pending = list(share), [False] * self.depth
-        with self.torch.cuda.device(self.dev):
-            while any(left):
-                for i, (_, bi, st) in enumerate(self.lanes):
-                    if not left[i]:
-                        continue
-                    if pending[i]:
-                        bi.wait()
-                    with self.torch.cuda.stream(st):
-                        self._load(bi)
-                        bi.solve_async()
-                    pending[i] = True
-                    left[i] -= 1
-            for i, (_, bi, _) in enumerate(self.lanes):
-                if pending[i]:
-                    bi.wait()
-        for i, n in enumerate(share):
-            self.done[i] += n
-
-    def _lane_steps(self, i, nsteps):
-        _, bi, st = self.lanes[i]
-        # lanes start a fraction of a step apart, so that one batch's under-filled last launch
-        # coincides with another batch's bulk launch instead of with its last launch
-        if self.stagger > 0 and i:
-            time.sleep(i * self.stagger)
-        with self.torch.cuda.stream(st):
-            for _ in range(nsteps):
-                self._load(bi)
-                bi.solve()
-            st.synchronize()
-        self.done[i] += nsteps
-
-    def _worker(self, i):
-        """lane i's host thread, alive for the life of the Lanes: starting a Python thread costs ~0.1 ms, which a
-        20-step timed region of a few tens of milliseconds would see 10-20 times over"""
-        while True:
-            self.go.wait()
-            if self.share is None:
-                return
-            try:
-                if self.share[i]:
-                    self._lane_steps(i, self.share[i])
-            except BaseException as ex:  # surfaced by run()
-                self.failed = ex
-            self.fin.wait()
-
-    def run(self, nsteps):
-        """`nsteps` steps (a pass of a lane with fused parts counts as `fuse` steps; nsteps is rounded up to whole
-        passes); returns the passes per lane"""
-        d = self.depth
-        npass = (nsteps + self.fuse - 1) // self.fuse
-        if not self.threads:
-            share = [npass // d + (1 if i < npass % d else 0) for i in range(d)]
-            self._run_async(share)
-            return share
-        nsteps = npass
-        if self.workers is None:
-            self.go, self.fin = threading.Barrier(d + 1), threading.Barrier(d + 1)
-            self.workers = [threading.Thread(target=self._worker, args=(i,), daemon=True) for i in range(d)]
-            for t in self.workers:
-                t.start()
-        self.share = [nsteps // d + (1 if i < nsteps % d else 0) for i in range(d)]
-        self.go.wait()   # releases every lane at once
-        self.fin.wait()  # every lane has synchronised its stream
-        if self.failed is not None:
-            raise self.failed
-        return self.share
-
-    def close(self):
-        if self.workers is not None:
-            self.share = None
-            self.go.wait()
-            for t in self.workers:
-                t.join()
-            self.workers = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    def status_histogram(self):
-        """PIPAMD_ST_* -> tableaux, over the lanes' last solves"""
-        hist = {}
-        for _, b, st in self.lanes:
-            with self.torch.cuda.stream(st):
-                b.fetch()
-                h = self.torch.bincount(b.status.to(self.torch.int64), minlength=10).cpu().tolist()
+        # what one solve of each batch does (pivots, cuts, rows rewritten, tableaux, finished tableaux) and how it ends:
+        # every batch once through lane 0
+        self.per_batch, self.hist = [], {}
+        e0, b0, _ = self.lanes[0]
+        for parts in self.batches:
+            b0.load_parts(parts)
+            b0.solve()
+            c = b0.counters()
+            self.per_batch.append((c["pivots"], c["cuts"], c["rows_rewritten"], shape[0], c["finished"]))
+            b0.fetch()
+            h = torch.bincount(b0.status.to(torch.int64), minlength=10).cpu().tolist()
             for k, v in enumerate(h):
                 if v:
-                    hist[k] = hist.get(k, 0) + v
-        return hist
+                    self.hist[k] = self.hist.get(k, 0) + v
+        self.workers = None
 
-    def totals(self, share):
-        """pivots, cuts, rows rewritten, tableaux, finished tableaux of `share[i]` passes of lane i"""
+    def _take(self, npass):
+        """the batches of the next `npass` steps"""
+        order = [(self.next_step + k) % self.depth for k in range(npass)]
+        self.next_step += npass
+        return order
+
+    def _run_async(self, order):
+        """one host thread over all lanes; returns the batches solved, in completion order"""
+        torch, it, active, done = self.torch, iter(order), {}, []
+
+        def start(i):
+            k = next(it, None)
+            if k is None:
+                return
+            _, bi, st = self.lanes[i]
+            bi.load_parts(self.batches[k], st.cuda_stream)
+            bi.solve_async(st.cuda_stream)
+            active[i] = k
+
+        with torch.cuda.device(self.dev):
+            for i in range(len(self.lanes)):
+                start(i)
+            while active:
+                for i in list(active):
+                    if self.lanes[i][1].poll():
+                        done.append(active.pop(i))
+                        start(i)
+        return done
+
+    def _run_threads(self, order):
+        """a host thread per lane, each calling the synchronous pipamd_batch_solve; steps drawn from a shared list"""
+        lock, it, done, failed = threading.Lock(), iter(order), [], []
+
+        def worker(i):
+            _, bi, st = self.lanes[i]
+            try:
+                with self.torch.cuda.device(self.dev):
+                    while True:
+                        with lock:
+                            k = next(it, None)
+                        if k is None:
+                            break
+                        bi.load_parts(self.batches[k], st.cuda_stream)
+                        bi.solve(st.cuda_stream)
+                        with lock:
+                            done.append(k)
+            except BaseException as ex:  # surfaced below
+                failed.append(ex)
+        ts = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(len(self.lanes))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if failed:
+            raise failed[0]
+        return done
+
+    def run(self, nsteps):
+        """`nsteps` steps (a pass over a batch of `fuse` fused parts counts as `fuse` steps; nsteps is rounded up to
+        whole passes); returns the batches solved"""
+        order = self._take((nsteps + self.fuse - 1) // self.fuse)
+        return self._run_threads(order) if self.threads else self._run_async(order)
+
+    def close(self):
+        pass
+
+    def status_histogram(self):
+        """PIPAMD_ST_* -> tableaux, over one solve of every batch"""
+        return dict(self.hist)
+
+    def totals(self, solved):
+        """pivots, cuts, rows rewritten, tableaux, finished tableaux of the batches in `solved`"""
         tot = [0, 0, 0, 0, 0]
-        for (e, b, _), n in zip(self.lanes, share):
-            if not n:
-                continue
-            c = b.counters()
-            tot[0] += n * c["pivots"]
-            tot[1] += n * c["cuts"]
-            tot[2] += n * c["rows_rewritten"]
-            tot[3] += n * b.desc.batch
-            tot[4] += n * c["finished"]
+        for k in solved:
+            for j in range(5):
+                tot[j] += self.per_batch[k][j]
         return tot
 
 
@@ -384,35 +367,13 @@ def host_cpus():
     return n
 
 
-def lane_count(pipeline, steps):
-    depth = max(1, min(pipeline, steps))
-    # every lane should time the same number of steps: prefer a lane count that divides --steps
-    for d in range(depth, max(1, depth // 2) - 1, -1):
-        if steps % d == 0:
-            return d
-    return depth
-
-
-def timed(lanes, steps, warmup, barrier, stagger_arg):
+def timed(lanes, steps, warmup, barrier, stagger_arg=0):
     lanes.run(max(warmup, lanes.depth))
     barrier()
-    if lanes.depth > 1 and stagger_arg != 0:
-        if stagger_arg > 0:
-            lanes.stagger = stagger_arg * 1e-3
-        else:  # one lane's own step latency with every lane busy, spread evenly over the lanes
-            best = 1e9  # the quickest of three tries: one slow try (a late thread) would hold the last lane back for long
-            for _ in range(3):
-                lanes.stagger = 0.0
-                tw = time.perf_counter()
-                lanes.run(lanes.depth)
-                lanes.torch.cuda.synchronize(lanes.dev)
-                best = min(best, (time.perf_counter() - tw) / lanes.depth)
-            lanes.stagger = best
-        barrier()
     t0 = time.perf_counter()
-    share = lanes.run(steps)
+    solved = lanes.run(steps)
     barrier()
-    return time.perf_counter() - t0, share
+    return time.perf_counter() - t0, solved
 
 
 def timed_regions(lanes, steps, warmup, barrier, stagger_arg, n=3):
@@ -448,11 +409,60 @@ def roofline_of(b, e, k_ms, cfg, extra=None):
     return r
 
 
-def kernel_ms_of(b, reps=2):
+def launch_split(b, e, cfg, parts):
+    """Roofline per launch of one un-pipelined solve: the one-wave bulk launch and the four-wave tail launch(es) do
+    very different work per pivot (a late pivot of a long tableau rewrites 15-25 rows, an early one 1-3).  Durations:
+    HIP events around each launch; pivots and rows of the bulk launch: the batch solved once more with the solve
+    stopped after its first launch (pipamd_debug_single_launch), the tail's = the whole solve's minus those."""
+    e.set_timing(True)
+    b.load_parts(parts)
+    b.solve()
+    n = e.last_solve_launches()
+    ms = [e.last_launch_ms(i) for i in range(n)]
+    whole = b.counters()
+    if n < 2:
+        return None
+    e.debug_single_launch(True)
+    try:
+        b.load_parts(parts)
+        b.solve()
+        first = b.counters()
+    finally:
+        e.debug_single_launch(False)
+    b.load_parts(parts)   # leave the batch solved
+    b.solve()
+    eb = 16.0 if cfg["ebits"] == 128 else 8.0
+    ncol = cfg["nvar"] + 1
+    out = []
+    for kind, t, piv, rows in (("bulk (one wave per tableau)", ms[0], first["pivots"], first["rows_rewritten"]),
+                               ("tail (four waves per tableau, %d launch%s)" % (n - 1, "" if n == 2 else "es"), sum(ms[1:]),
+                                whole["pivots"] - first["pivots"], whole["rows_rewritten"] - first["rows_rewritten"])):
+        by = eb * ncol * (2.0 * rows + 2.0 * piv)
+        out.append({"launch": kind, "ms": t, "pivots": piv, "rows_rewritten_per_pivot": rows / max(1, piv),
+                    "algorithmic_bytes": by, "achieved": by / (t * 1e-3) / 1e9, "frac": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    return out
+
+
+def profile_json(*names):
+    """the first of profiles/<name> that exists, parsed; (None, None) otherwise"""
+    for nm in names:
+        path = os.path.join(ROOT, "profiles", nm)
+        if os.path.exists(path):
+            try:
+                return json.load(open(path)), "profiles/" + nm
+            except Exception:
+                pass
+    return None, None
+
+
+def kernel_ms_of(b, parts=None, reps=2):
     b.e.set_timing(True)
     ms = []
     for _ in range(reps):
-        b.load()
+        if parts is None:
+            b.load()
+        else:
+            b.load_parts(parts)
         b.solve()
         ms.append(b.last_solve_ms())
     return sum(ms) / len(ms)
@@ -482,8 +492,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=0,
                     help="strong scaling: shards of this many batches share a workspace and a launch sequence (0 = enough "
                          "for about 5,000 tableaux per launch sequence)")
-    ap.add_argument("--stagger", type=float, default=0.0,
-                    help="ms between the lanes' starts (0 = none, <0 = step latency / lanes, measured in warm-up)")
+    ap.add_argument("--stagger", type=float, default=0.0, help="(ignored; kept for old command lines)")
     ap.add_argument("--blocking-wait", type=int, default=-1,
                     help="1: host threads sleep while the device works, 0: they poll; -1: sleep when there are more lanes than CPUs")
     ap.add_argument("--copy-rows", action="store_true", help="load copies the input rows into the job blocks (no PIPAMD_T_ROWS_STAY)")
@@ -540,7 +549,7 @@ def main():
             # (round 2: 262 M pivots/s per GPU at 1,250, 304 M at 2,500, 350 M at 5,000, 362 M at 10,000).
             shard = max(1, (args.batch + world - 1) // world)
             fuse = args.fuse if args.fuse > 0 else max(1, min(16, 5000 // shard))
-            depth = lane_count(args.pipeline, (args.steps + fuse - 1) // fuse)
+            depth = max(1, min(args.pipeline, (args.steps + fuse - 1) // fuse))
             lo, hi = pdist.shard_range(args.batch, rank, world)
             cfg["batch"] = hi - lo
             seeds = [1000 + 7919 * i for i in range(depth)]
@@ -548,8 +557,10 @@ def main():
             def gen(seed):
                 return synth.lexmin_batch(seed, args.batch, cfg["nvar"], cfg["ni"])[lo:hi]
         else:
-            depth = lane_count(args.pipeline, args.steps)
-            # lane i of rank r draws its own batch: seed 1000 + r + 7919 * i
+            # small batches (--batch below 2,500 per GPU) are fused the same way: a lane's workspace holds `fuse` of them
+            fuse = args.fuse if args.fuse > 0 else max(1, min(16, 5000 // max(1, args.batch)))
+            depth = max(1, min(args.pipeline, (args.steps + fuse - 1) // fuse))
+            # batch i of rank r: seed 1000 + r + 7919 * i
             seeds = [pdist.shard_seed(1000, rank) + 7919 * i for i in range(depth)]
             gen = None
         return cfg, Lanes(cfg, depth, dev, local, seeds, args, gen, threads=threads, fuse=fuse), depth, seeds, gen
@@ -564,20 +575,20 @@ def main():
     # three timed regions of --steps steps each; the median is the line's value, all three are printed
     regions = timed_regions(lanes, args.steps, args.warmup, barrier, args.stagger)
     dt, share = regions[1]
-    steps_done = sum(share) * fuse   # == --steps unless shards are fused (whole passes of `fuse` steps)
+    steps_done = len(share) * fuse   # == --steps unless shards are fused (whole passes of `fuse` steps)
     progress(f"regions {[round(r[0] * 1e3, 2) for r in regions]} ms")
     tot = lanes.totals(share)
     hist = lanes.status_histogram()
 
     # the advance kernel's own launch durations (HIP events on its stream), un-overlapped
-    k_ms = kernel_ms_of(b)
+    parts0 = lanes.batches[0]
+    k_ms = kernel_ms_of(b, parts0)
     torch.cuda.synchronize(dev)
     gt, dt_max = pdist.gather_totals(tot, dt, dev)
 
     other = None
     if world > 1:  # the other scaling mode, same steps (every rank takes part)
         mode2 = "weak" if args.scaling == "strong" else "strong"
-        rows_keep = b.rows
         lanes.close()
         del lanes
         torch.cuda.empty_cache()
@@ -585,7 +596,7 @@ def main():
         dt2, share2 = timed(lanes2, args.steps, args.warmup, barrier, args.stagger)
         gt2, dt2_max = pdist.gather_totals(lanes2.totals(share2), dt2, dev)
         other = {"scaling": mode2, "value": gt2[0] / dt2_max, "unit": "pivots/s",
-                 "ms_per_step": dt2_max / (sum(share2) * lanes2.fuse) * 1e3,
+                 "ms_per_step": dt2_max / (len(share2) * lanes2.fuse) * 1e3,
                  "batch_per_gpu": cfg2["batch"], "pipeline_depth": depth2, "fused_batches_per_launch_sequence": lanes2.fuse,
                  "problems_per_sec": gt2[3] / dt2_max}
         lanes2.close()
@@ -620,7 +631,11 @@ def main():
                    "host_threads": depth if args.threads else 1,
                    "driver": "one host thread per lane, pipamd_batch_solve" if args.threads else
                              "one host thread, pipamd_batch_solve_async / pipamd_batch_wait",
-                   "fused_batches_per_launch_sequence": fuse},
+                   "fused_batches_per_launch_sequence": fuse,
+                   "screened_out": {"what": "tableaux on which Gomory's cuts have not converged within 448 cut rows (the "
+                                            "reference does not finish them within minutes either), replaced by their "
+                                            "neighbours before anything is timed; seed -> indices",
+                                    "rank0": {str(k): v for k, v in sorted(lanes.screened.items())}}},
         "steps_timed": steps_done,
         "regions_ms": [round(r[0] * 1e3, 3) for r in regions],
         "problems_per_sec": gt[3] / dt_max,
@@ -638,20 +653,25 @@ def main():
         raise SystemExit(3)
     if other:
         out["other_scaling"] = other
-    traffic = None
-    for tp in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
-        tp = os.path.join(ROOT, "profiles", tp)
-        if os.path.exists(tp):
-            try:
-                t = json.load(open(tp))
-                if t.get("batch_per_gpu") == my_batch:
-                    traffic = t["hbm_bytes_per_step"]
-                    break
-            except Exception:
-                pass
+    traffic, traffic_src = None, None
+    t, src = profile_json("r03_pmc_hbm.json", "r02_pmc_hbm.json")
+    if t and t.get("batch_per_gpu") == my_batch:
+        traffic, traffic_src = t["hbm_bytes_per_step"], src
     c0 = b.counters()
+    issue, issue_src = profile_json("r03_pmc_issue.json")
+    split = None
+    if fuse == 1:
+        try:
+            split = launch_split(b, e, cfg, parts0)
+        except Exception as ex:
+            split = {"error": repr(ex)}
     out["roofline"] = roofline_of(b, e, k_ms, cfg, {
         "traffic": traffic,
+        "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command with --pipeline 1; "
+                           "read from the file, not measured in this run)") if traffic_src else None,
+        "launches": split,
+        "issue": dict(issue, source=issue_src + " (rocprofv3 --pmc SQ_INSTS_* / SQ_ACTIVE_INST_* passes; read from the file, "
+                                                "not measured in this run)") if issue else None,
         "measured": "HIP events around each launch, 2 un-pipelined steps after the timed region "
                     "(= `bench.py --pipeline 1`, the command of profiles/r02_kernel_stats.csv)",
         "timed_region_GBps_per_gpu": 8.0 * (cfg["nvar"] + 1) * (2.0 * gt[2] + 2.0 * gt[0]) / world / dt_max / 1e9,
@@ -667,7 +687,7 @@ def main():
         try:  # an extra leg never costs the headline line
             ed = eng.Engine(local)
             ed.set_waves_per_job(4)  # streaming regime: four waves share a tableau's rows
-            bd = eng.Batch(ed, b.rows, cfg["nvar"], 0, tflags=eng.T_INT | eng.T_NOSKIP)
+            bd = eng.Batch(ed, parts0[0], cfg["nvar"], 0, tflags=eng.T_INT | eng.T_NOSKIP)
             bd.load()
             bd.solve()
             dk = kernel_ms_of(bd)
@@ -706,28 +726,30 @@ def main():
             others = []
             for oc in OTHERS:
                 progress(oc["key"])
-                # a 1k batch of small tableaux is a tenth of a millisecond of GPU work: twice the lanes keep the GPU fed
-                od = args.pipeline * (2 if oc["batch"] < 4096 and oc["nvar"] < 128 else 1)
-                ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args)
-                osteps = 16 * od
-                # 16 steps per lane: long enough for the lanes to start a fraction of a step apart (their tails
-                # then fall into other lanes' bulk phases; it costs the short headline runs more than it gives)
+                od = args.pipeline
+                # batches of a thousand small tableaux are a tenth of a millisecond of GPU work each: five of them share a
+                # workspace and a launch sequence (pipamd_batch_load_part), as the shards of a strong-scaling run do
+                ofuse = max(1, min(16, 5000 // oc["batch"])) if oc["ebits"] == 64 else 1
+                ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args, fuse=ofuse)
+                osteps = 16 * od * ofuse
                 # The median of three timed regions: a region here is 35 ms to 1.4 s long, and the first region of a
                 # fresh set of lanes came out 2-3x slower than every later one on configs[1] (cause not found).
-                regions = sorted((timed(ol, osteps, od, barrier, args.stagger if args.stagger != 0 else -1.0) for _ in range(3)),
-                                 key=lambda r: r[0])
+                regions = sorted((timed(ol, osteps, od, barrier) for _ in range(3)), key=lambda r: r[0])
                 odt, osh = regions[1]
+                osteps = len(osh) * ofuse
                 ot = ol.totals(osh)
                 oe, ob, _ = ol.lanes[0]
-                okm = kernel_ms_of(ob)
+                okm = kernel_ms_of(ob, ol.batches[0])
                 o1 = Lanes(oc, 1, dev, local, [2000], args)
                 odt1, osh1 = timed(o1, 16, 2, barrier, 0)
                 ot1 = o1.totals(osh1)
                 others.append({
                     "config": oc["key"], "workload": oc["workload"], "dtype": "int128" if oc["ebits"] == 128 else "int64",
                     "value": ot[0] / odt, "unit": "pivots/s", "ms_per_step": odt / osteps * 1e3, "steps": osteps,
-                    "pipeline_depth": od, "regions_ms": [round(r[0] * 1e3, 3) for r in regions], "problems_per_sec": ot[3] / odt, "pivots_per_step": ot[0] / osteps,
+                    "pipeline_depth": od, "fused_batches_per_launch_sequence": ofuse, "host_threads": 1,
+                    "regions_ms": [round(r[0] * 1e3, 3) for r in regions], "problems_per_sec": ot[3] / odt, "pivots_per_step": ot[0] / osteps,
                     "finished_fraction": ot[4] / max(1, ot[3]),
+                    "status_histogram": {STATUS_NAMES.get(k, str(k)): v for k, v in sorted(ol.status_histogram().items())},
                     "pipeline1_value": ot1[0] / odt1, "pipeline1_ms_per_step": odt1 / 16 * 1e3,
                     "roofline": roofline_of(ob, oe, okm, oc)})
                 ol.close()

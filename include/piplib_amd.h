@@ -154,13 +154,14 @@ int pipamd_batch_solve(pipamd_engine *e, void *d_workspace, const pipamd_batch_d
 
 /* The same in two halves, so that ONE host thread keeps many batches in flight: pipamd_batch_solve_async enqueues
  * the launch sequence (bulk launch, tail launch, a copy of the tail's control words) on `stream` and returns without
- * waiting; pipamd_batch_wait waits for it, issues whatever else the batch needs (further tail launches for tableaux
- * beyond the per-launch pivot limit, re-housing of full tableaux) and returns when every tableau has a final status.
- * pipamd_batch_poll: 1 when pipamd_batch_wait would not block on the launches enqueued so far (or nothing is in
- * flight), 0 while they run.  One solve in flight per engine -- an engine is a small host object: a caller keeps K
- * of them, each with its own stream and workspace, and goes round (load, solve_async on lane i; wait on lane i+1, ...):
+ * waiting.  pipamd_batch_poll never blocks: 0 while the launches enqueued so far run; once they have ended it looks at
+ * what they left -- if tableaux remain (beyond the per-launch pivot limit, or out of spare rows: those are re-housed)
+ * it enqueues the next launches and returns 0 again; 1 when every tableau has its final status (or nothing is in
+ * flight); < 0 on error.  pipamd_batch_wait does the same blocking and returns PIPAMD_OK when the batch is done.
+ * One solve in flight per engine -- an engine is a small host object: a caller keeps K of them, each with its own
+ * stream and workspace, starts a batch on each and polls them in turn, starting the next batch on whichever is done:
  * a lone batch leaves most of the GPU idle in its latency-bound tail, K batches in different phases fill it
- * (bench.py: one thread, K = 12).  Results may be fetched after pipamd_batch_wait. */
+ * (bench.py: one host thread, K = 12).  Results may be fetched once poll has returned 1 / wait has returned. */
 int pipamd_batch_solve_async(pipamd_engine *e, void *d_workspace, const pipamd_batch_desc *d, void *stream);
 /* Row budget of the growth above: a tableau is re-housed only while its row capacity stays within `rows` (at least
  * ni + cap_cuts; 0 = the default, only the engine's own limit) and ends PIPAMD_ST_CAPACITY beyond it.  The reference

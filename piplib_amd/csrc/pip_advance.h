@@ -65,7 +65,7 @@ typedef unsigned short u16;
 typedef unsigned char u8;
 
 #ifndef PIP_MINWAVES
-#define PIP_MINWAVES 1
+#define PIP_MINWAVES 6
 #endif
 // Diagnostic builds only (tools/pmc_dup.sh): -DPIP_DUP=n executes one idempotent piece of the
 // pivot loop twice, so that the difference of the SQ_INSTS_* counters against the normal build
@@ -633,6 +633,19 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
   return true;
 }
 
+// a mod g for a, g < 2^20, g >= 1, rg = v_rcp_f32(g): the float quotient estimate is off by at most one either way
+// (a / g < 2^20, relative error of the reciprocal and of the product below 2^-22), so the remainder estimate is
+// r - g, r or r + g; the two unsigned minima pick r.
+__device__ __forceinline__ unsigned umod_tiny(unsigned a, unsigned g, float rg) {
+  const unsigned q = (unsigned)((float)a * rg);
+  unsigned r = a - __umul24(q, g);
+  const unsigned up = r + g;
+  r = up < r ? up : r;   // q one too large: a - q g wrapped around
+  const unsigned dn = r - g;
+  r = dn < r ? dn : r;   // q one too small
+  return r;
+}
+
 // The same row update when every operand is small: the row's and the pivot row's entries below
 // 2^15 (magnitude class 0) and |lpiv|, |foo|, |dpiv| < 2^15.  Then every product is below 2^30 and
 // every z below 2^31: 24-bit multiplies (full rate, unlike the 64-bit product's three quarter-rate
@@ -660,16 +673,30 @@ __device__ __forceinline__ bool update_row_small(RowRegs<i64, NCH> &r, const i64
     u64 g64 = (u64)uni64((i64)uabs64(g0));
     if ((g64 >> 32) == 0) {
       unsigned g = (unsigned)g64;
+      // every |z| and g below 2^20 (the rule on this path): remainders through a float reciprocal of the wave-uniform
+      // g -- five full-rate instructions and two corrections per entry instead of the 32-bit division sequence
+      const bool tiny = g != 0 && g < (1u << 20) && __ballot((mx >> 20) != 0) == 0;
       for (;;) {
         unsigned rr = 0;
+        if (tiny) {
+          const float rg = __builtin_amdgcn_rcpf((float)g);
 #pragma unroll
-        for (int c = 0; c < NCH; c++)
+          for (int c = 0; c < NCH; c++)
 #pragma unroll
-          for (int h = 0; h < 2; h++) {
-            const unsigned a = (unsigned)(z[c][h] < 0 ? -z[c][h] : z[c][h]);
-            const unsigned m = g == 0 ? a : a % g;
-            rr = rr ? rr : m;
-          }
+            for (int h = 0; h < 2; h++) {
+              const unsigned a = (unsigned)(z[c][h] < 0 ? -z[c][h] : z[c][h]);
+              rr = rr ? rr : umod_tiny(a, g, rg);
+            }
+        } else {
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const unsigned a = (unsigned)(z[c][h] < 0 ? -z[c][h] : z[c][h]);
+              const unsigned m = g == 0 ? a : a % g;
+              rr = rr ? rr : m;
+            }
+        }
         const u64 nz = __ballot(rr != 0);
         if (!nz) break;
         const unsigned r0 = __builtin_amdgcn_readlane(rr, __ffsll((long long)nz) - 1);

@@ -187,7 +187,7 @@ struct BatchRun {
   long long *arena;
   hipStream_t st;
   int *pool, *over, *list[2];
-  bool over_zeroed, have_list, active;
+  bool over_zeroed, have_list, active, finishing;
   int stage;       // launches issued
   int curS;        // row capacity of the largest block in play (grows when tableaux are re-housed)
   int grow_round;
@@ -327,6 +327,7 @@ struct BatchRun {
     e->last_rehoused = 0;
     stage = 0;
     have_list = false;
+    finishing = false;
     curS = lay.S;
     grow_round = 0;
     const bool integer = (lay.tflags & PIPAMD_T_INT) != 0;
@@ -362,27 +363,45 @@ struct BatchRun {
     return PIPAMD_OK;
   }
 
-  int finish() {
-    active = false;
-    for (;;) {
-      int rc = wait_stream();
-      if (rc) return rc;
-      if (e->h_run[0] <= 0 || e->single_launch) break;
+  // What the launches enqueued so far left behind (the stream must be idle): 1 = every tableau has its final status,
+  // 0 = more work was enqueued (a further tail launch, after re-housing the tableaux that are out of rows), < 0 error.
+  int advance() {
+    if (finishing) {  // the solutions of re-housed tableaux are back in the caller's workspace
+      finishing = false;
+      active = false;
+      e->timed = !e->no_timing;
+      return 1;
+    }
+    if (e->h_run[0] > 0 && !e->single_launch) {
       upper = e->h_run[0];
       if (e->h_run[1] & PIPAMD_Q_CAPFLAG) {  // some of them have spent their spare rows
-        rc = rehouse(upper);
+        int rc = rehouse(upper);
         if (rc) return rc;
       }
-      rc = tail();
-      if (rc) return rc;
+      int rc = tail();
+      return rc ? rc : 0;
     }
-    if (grow_round > 0) {
+    if (grow_round > 0) {  // the side arenas serve the engine's next solve: the solve ends when the copy-back has
       HIPCHK(pipk_launch_rehouse_finish(jobs, arena, lay.batch, lay.sol_words, st));
-      int rc = wait_stream();  // the side arenas serve the engine's next solve
-      if (rc) return rc;
+      finishing = true;
+      return 0;
     }
+    active = false;
     e->timed = !e->no_timing;
-    return PIPAMD_OK;
+    return 1;
+  }
+
+  int finish() {
+    for (;;) {
+      int rc = wait_stream();
+      if (rc) {
+        active = false;
+        return rc;
+      }
+      rc = advance();
+      if (rc < 0) active = false;
+      if (rc != 0) return rc < 0 ? rc : PIPAMD_OK;
+    }
   }
 };
 
@@ -425,13 +444,18 @@ extern "C" int pipamd_batch_wait(pipamd_engine *e) {
 extern "C" int pipamd_batch_poll(pipamd_engine *e) {
   if (!e) return PIPAMD_E_INVALID;
   if (!e->run || !e->run->active) return 1;
+  if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
   hipError_t q = hipStreamQuery(e->run->st);
   if (q == hipErrorNotReady) return 0;
   if (q != hipSuccess) {
     pipamd_set_error("hipStreamQuery failed: %s", hipGetErrorString(q));
+    e->run->active = false;
     return PIPAMD_E_HIP;
   }
-  return 1;  // the launches enqueued so far have ended: pipamd_batch_wait will not block unless tableaux are left
+  // the launches enqueued so far have ended: done, or the next ones go out now (never blocks)
+  int rc = e->run->advance();
+  if (rc < 0) e->run->active = false;
+  return rc;
 }
 
 // Row budget of pipamd_batch_solve: a tableau is re-housed (expanser) while its row capacity stays within `rows`

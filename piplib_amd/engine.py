@@ -123,6 +123,18 @@ class Engine:
     def set_round_rows(self, n):
         _check(lib().pipamd_engine_set_round_rows(self._h, int(n)))
 
+    def last_launch_ms(self, i):
+        """duration of launch i of the last solve (HIP events on its stream; timing must be on)"""
+        ms = C.c_float()
+        lib().pipamd_last_launch_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        _check(lib().pipamd_last_launch_ms(self._h, int(i), C.byref(ms)))
+        return float(ms.value)
+
+    def debug_single_launch(self, on):
+        """measurement aid: the next solves stop after their first launch (the bulk launch of a large batch)"""
+        lib().pipamd_debug_single_launch.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().pipamd_debug_single_launch(self._h, int(bool(on))))
+
     def last_solve_launches(self):
         return int(lib().pipamd_last_solve_launches(self._h))
 
@@ -148,11 +160,13 @@ class Batch:
     """A uniform batch of tableaux resident in HBM (layer 1 of the C ABI)."""
 
     def __init__(self, engine, rows, nvar, nparm, bigparm=-1, tflags=T_INT, cap_cuts=None, cap_newparm=0,
-                 entier_bits=64):
+                 entier_bits=64, shape=None):
+        """rows: (batch, ni, ncol) int64, host or device; or None with shape=(batch, ni, ncol) for a workspace whose
+        tableaux come from load_parts()"""
         import torch
         self.torch = torch
         self.e = engine
-        B, ni, ncol = rows.shape
+        B, ni, ncol = rows.shape if rows is not None else shape
         assert ncol == nvar + nparm + 1
         if cap_cuts is None:
             cap_cuts = max(0, min(ni + 64, 2048 - ni)) if (tflags & T_INT) else 0
@@ -160,8 +174,11 @@ class Batch:
         self.entier_bits = entier_bits
         ew = 2 if entier_bits == 128 else 1
         self.dev = torch.device("cuda", engine.device)
-        self.rows = rows if (torch.is_tensor(rows) and rows.is_cuda) else torch.as_tensor(rows, dtype=torch.int64).to(self.dev)
-        self.rows = self.rows.contiguous()
+        if rows is None:
+            self.rows = None
+        else:
+            self.rows = rows if (torch.is_tensor(rows) and rows.is_cuda) else torch.as_tensor(rows, dtype=torch.int64).to(self.dev)
+            self.rows = self.rows.contiguous()
         nbytes = lib().pipamd_batch_workspace_bytes(C.byref(self.desc))
         if nbytes == 0:
             raise RuntimeError(lib().pipamd_last_error().decode())
@@ -180,14 +197,24 @@ class Batch:
         _check(lib().pipamd_batch_load(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc),
                                        C.c_void_p(self.rows.data_ptr()), self._stream()))
 
-    def load_part(self, rows, first):
-        """tableaux first .. first + len(rows) - 1 of the batch from another resident row array (pipamd_batch_load_part)"""
-        assert rows.is_cuda and rows.is_contiguous() and rows.shape[1:] == self.rows.shape[1:]
+    def load_part(self, rows, first, stream=None):
+        """tableaux first .. first + len(rows) - 1 of the batch from a resident row array (pipamd_batch_load_part)"""
+        assert rows.is_cuda and rows.is_contiguous()
+        st = C.c_void_p(stream) if stream is not None else self._stream()
         _check(lib().pipamd_batch_load_part(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc),
-                                            C.c_void_p(rows.data_ptr()), int(first), int(rows.shape[0]), self._stream()))
+                                            C.c_void_p(rows.data_ptr()), int(first), int(rows.shape[0]), st))
 
-    def solve(self):
-        _check(lib().pipamd_batch_solve(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc), self._stream()))
+    def load_parts(self, parts, stream=None):
+        """the whole batch from a list of resident row arrays (one pipamd_batch_load_part each)"""
+        off = 0
+        for part in parts:
+            self.load_part(part, off, stream)
+            off += part.shape[0]
+        assert off == self.desc.batch
+
+    def solve(self, stream=None):
+        st = C.c_void_p(stream) if stream is not None else self._stream()
+        _check(lib().pipamd_batch_solve(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc), st))
 
     def solve_async(self, stream=None):
         """pipamd_batch_solve_async on `stream` (a raw hipStream_t handle; default: torch's current stream); one solve
@@ -199,7 +226,11 @@ class Batch:
         _check(lib().pipamd_batch_wait(self.e._h))
 
     def poll(self):
-        return int(lib().pipamd_batch_poll(self.e._h))
+        """pipamd_batch_poll: 1 = the batch is done, 0 = still running (never blocks)"""
+        rc = int(lib().pipamd_batch_poll(self.e._h))
+        if rc < 0:
+            _check(rc)
+        return rc
 
     def fetch(self):
         _check(lib().pipamd_batch_results(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc),
@@ -222,6 +253,29 @@ class Batch:
 
     def pivot_bytes(self):
         return int(lib().pipamd_dense_pivot_bytes(C.byref(self.desc)))
+
+
+def slow_converging(engine, rows, nvar, cut_rows=448, entier_bits=64):
+    """Indices of the tableaux of an integer batch (nparm = 0) on which Gomory's cuts have not converged within
+    `cut_rows` cut rows: the batch is solved once with that row budget (pipamd_engine_set_max_rows) and the tableaux left
+    at PIPAMD_ST_CAPACITY are returned.  A property of the tableau and of the reference's algorithm (the number of
+    cuts integrer() adds is the same on any correct implementation), not of this engine: on the synthetic families of
+    piplib_amd/synth.py about 3 tableaux in 100,000 are of this kind, and on them the reference's own loop
+    (traiter.c:665-789, unbounded expanser) does not end within minutes on a CPU either.  bench.py replaces them by
+    their neighbours before it times anything (a benchmark workload must be one the reference finishes)."""
+    import torch
+    e2 = Engine(engine.device)
+    ni = int(rows.shape[1])
+    e2.set_max_rows(ni + cut_rows)
+    b = Batch(e2, rows, nvar, 0, tflags=T_INT, entier_bits=entier_bits)
+    b.load()
+    b.solve()
+    b.fetch()
+    torch.cuda.synchronize(b.dev)
+    idx = torch.nonzero(b.status == ST_CAPACITY).flatten().cpu().tolist()
+    del b
+    e2.close()
+    return idx
 
 
 class SolCell(C.Structure):
