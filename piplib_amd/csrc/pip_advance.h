@@ -39,6 +39,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "pip_job.h"
 
@@ -442,6 +443,7 @@ struct Shared {
 struct Scalars {
   int pivi, pivi2, pivj, tmp, tmp2, aux;
   int flagor, nwork, bad, ovf;
+  int mc;  // the largest magnitude class any row of the job has had in this launch (never lowered: conservative)
   u64 smaxbits;
 };
 
@@ -503,9 +505,10 @@ __device__ __forceinline__ T row_entry(const RowRegs<T, NCH> &r, int pc, int ph,
 
 // Sign summary, non-zero bitmap and magnitude class of a row held in registers
 // (wave-collective).  Lane 0 publishes them for slot s.
+// Returns the row's magnitude class (wave-uniform).
 template <class T, int NCH>
-__device__ __forceinline__ void row_publish(const RowRegs<T, NCH> &r, const Shared<T> &S, int s, int nvar, int ncol,
-                                            int bigparm, int pivj, int extra_sig, bool has_parm, int lane) {
+__device__ __forceinline__ int row_publish(const RowRegs<T, NCH> &r, const Shared<T> &S, int s, int nvar, int ncol,
+                                           int bigparm, int pivj, int extra_sig, bool has_parm, int lane) {
   int bs = 0;
   bool ppos = false, pneg = false;
   typename ET<T>::U mx = 0;
@@ -546,6 +549,67 @@ __device__ __forceinline__ void row_publish(const RowRegs<T, NCH> &r, const Shar
 #pragma unroll
     for (int e = 0; e < NCH * ET<T>::CPL; e++) S.nzm[(size_t)s * (NCH * ET<T>::CPL) + e] = nz[e];
   }
+  return cls;
+}
+
+// ---- rows whose entries all fit an int (64-bit tableaux): the same three steps on 32-bit registers ----
+template <int NCH>
+struct RowRegs32 {
+  int v[NCH][2];
+};
+template <int NCH>
+__device__ __forceinline__ void row_store32(const RowRegs32<NCH> &z, i64 *row, int ncolp, int lane) {
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int j0 = colof<i64>(c, lane, 0);
+    if (j0 < ncolp) {
+      longlong2 t;
+      t.x = (i64)z.v[c][0];
+      t.y = (i64)z.v[c][1];
+      *reinterpret_cast<longlong2 *>(row + j0) = t;
+    }
+  }
+}
+template <int NCH>
+__device__ __forceinline__ int row_entry32(const RowRegs32<NCH> &z, int pc, int ph, int pl) {
+  int mine = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (c == pc && h == ph) mine = z.v[c][h];
+  return __builtin_amdgcn_readlane(mine, pl);
+}
+// row_publish for a row without parameter columns (nparm == 0) held as ints; returns its class (0: every entry
+// below 2^15, 1: below 2^31)
+template <int NCH>
+__device__ __forceinline__ int row_publish32(const RowRegs32<NCH> &z, const Shared<i64> &S, int s, int nvar, int pivj,
+                                             int extra_sig, int lane) {
+  const int cz = row_entry32<NCH>(z, nvar / 128, nvar % 2, (nvar % 128) / 2);
+  int sig = extra_sig | (cz > 0 ? 1 : (cz < 0 ? 2 : 0));
+  if (pivj >= 0) {
+    const int pz = row_entry32<NCH>(z, pivj / 128, pivj % 2, (pivj % 128) / 2);
+    sig |= (pz > 0 ? 1 : (pz < 0 ? 2 : 0)) << 6;
+  }
+  unsigned mx = 0;
+  u64 nz[NCH * 2];
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int v = z.v[c][h];
+      mx |= (unsigned)(v < 0 ? -v : v);
+      nz[2 * c + h] = __ballot(v != 0);
+    }
+  const int cls = __ballot((mx >> 15) != 0) ? 1 : 0;
+  if (lane == 0) {
+    S.sig[s] = (u16)sig;
+    S.rcls[s] = (u8)cls;
+    S.cst[s] = (i64)cz;
+#pragma unroll
+    for (int e = 0; e < NCH * 2; e++) S.nzm[(size_t)s * (NCH * 2) + e] = nz[e];
+  }
+  return cls;
 }
 
 // pivoter()'s inner loop for one row (traiter.c:470-501), one wave per row.
@@ -652,8 +716,8 @@ __device__ __forceinline__ unsigned umod_tiny(unsigned a, unsigned g, float rg) 
 // multiplies) and 32-bit registers all the way through the gcd refinement and the division give
 // the same bits as the 64-bit code above.  64-bit entries only.
 template <int NCH>
-__device__ __forceinline__ bool update_row_small(RowRegs<i64, NCH> &r, const i64 *prow, int pivj, int lp, int foo, int dpiv,
-                                                 i64 g0, int lane, i64 &newden) {
+__device__ __forceinline__ bool update_row_small(const RowRegs<i64, NCH> &r, RowRegs32<NCH> &out, const i64 *prow, int pivj,
+                                                 int lp, int foo, int dpiv, i64 g0, int lane, i64 &newden) {
   int z[NCH][2];
   unsigned mx = 0;
 #pragma unroll
@@ -777,7 +841,7 @@ __device__ __forceinline__ bool update_row_small(RowRegs<i64, NCH> &r, const i64
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
-    for (int h = 0; h < 2; h++) r.v[c][h] = (i64)z[c][h];
+    for (int h = 0; h < 2; h++) out.v[c][h] = z[c][h];
   return ok;
 }
 
@@ -867,12 +931,15 @@ __device__ int exam_rows(const Shared<T> &S, Scalars *sc, int ni) {
 // and stop when one column is left.  Executed by wave 0 only; `prow` holds the
 // pivot row in the wave's lane geometry.
 // Exact while (max a_j) * (max |entry|) < 2^62, which the caller guarantees.
-template <class T, int NCH>
+// SMALL: every entry of every row (the pivot row included) is below 2^15 -- the caller knows from the magnitude
+// classes -- so the candidates and the cross products are held and formed on 32-bit registers with 24-bit multiplies.
+template <class T, int NCH, bool SMALL>
 __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, const T *vals, int W, int nvar, int nligne,
                              int pivi, int ncolp, Scalars *sc) {
   constexpr int NM = NCH * ET<T>::CPL;
   const int lane = threadIdx.x & 63;
-  T a[NCH][ET<T>::CPL];
+  typedef typename std::conditional<SMALL, int, T>::type A;  // arithmetic type of the ratio test
+  A a[NCH][ET<T>::CPL];
   int u[NCH][ET<T>::CPL];
   bool cand[NCH][ET<T>::CPL];
   u64 cm[NM];
@@ -882,7 +949,7 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
 #pragma unroll
     for (int h = 0; h < ET<T>::CPL; h++) {
       int j = colof<T>(c, lane, h);
-      a[c][h] = j < nvar ? prow.v[c][h] : 0;
+      a[c][h] = j < nvar ? (A)prow.v[c][h] : (A)0;
       cand[c][h] = a[c][h] > 0;
       u[c][h] = cand[c][h] ? (int)S.urow[j] : -1;
       cm[ET<T>::CPL * c + h] = __ballot(cand[c][h]);
@@ -941,7 +1008,7 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
       for (;;) {
         CNT(15, 1);
         // reference column b = first remaining candidate
-        T ab = 0, nb = 0;
+        A ab = 0, nb = 0;
         bool got = false;
 #pragma unroll
         for (int c = 0; c < NCH; c++)
@@ -950,8 +1017,13 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
             u64 m = cm[ET<T>::CPL * c + h];
             if (!got && m) {
               int src = __ffsll((long long)m) - 1;
-              ab = readlane64(a[c][h], src);
-              nb = readlane64(n.v[c][h], src);
+              if constexpr (SMALL) {
+                ab = __builtin_amdgcn_readlane(a[c][h], src);
+                nb = __builtin_amdgcn_readlane((int)n.v[c][h], src);
+              } else {
+                ab = readlane64(a[c][h], src);
+                nb = readlane64(n.v[c][h], src);
+              }
               got = true;
             }
           }
@@ -961,7 +1033,11 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
         for (int c = 0; c < NCH; c++)
 #pragma unroll
           for (int h = 0; h < ET<T>::CPL; h++) {
-            T x = wsub(wmul(ab, n.v[c][h]), wmul(nb, a[c][h]));
+            A x;
+            if constexpr (SMALL)
+              x = __mul24(ab, (int)n.v[c][h]) - __mul24(nb, a[c][h]);
+            else
+              x = wsub(wmul(ab, n.v[c][h]), wmul(nb, a[c][h]));
             neg[c][h] = cand[c][h] && x < 0;
             bool zero = cand[c][h] && x == 0;
             nneg += __popcll(__ballot(neg[c][h]));
@@ -1244,6 +1320,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   T *g_log = (T *)(arena + J->log_off);
   constexpr int LOGCAP = PIPAMD_DETLOG;  // pairs the log area holds
   int nlog = J->nlog;
+  // magnitude classes of the rows this wave has published (row_publish returns them) and what of it sc.mc has seen
+  int mcw = 0, mcf = 0;
+#define PIP_FLUSH_MC()                                  \
+  do {                                                  \
+    if (mcw > mcf && lane == 0) atomicMax(&sc.mc, mcw); \
+    mcf = mcw;                                          \
+  } while (0)
   if (ni > Smax || nligne > Lmax) {  // this launch's LDS image is too small: stay RUN for a larger one
     if (tid == 0 && q.out_count) {
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
@@ -1316,6 +1399,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     sc.pivi2 = BIG_I;
     sc.flagor = 0;
     sc.bad = 0;
+    sc.mc = 0;
   }
   bsync<NW>();
   for (int i = tid; i < nligne; i += NT) {
@@ -1338,7 +1422,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     // resumed job: the summaries were saved when it paused
     for (int s = tid; s < ni; s += NT) {
       S.sig[s] = g_sig[s];
-      S.rcls[s] = g_rcls[s];
+      const int rc_ = g_rcls[s];
+      S.rcls[s] = (u8)rc_;
+      if (rc_ > 0) atomicMax(&sc.mc, rc_);
     }
     for (int e = tid; e < ni * NM; e += NT) S.nzm[e] = g_nzm[e];
     for (int s = tid; s < ni; s += NT) S.cst[s] = vals[(size_t)s * W + nvar];
@@ -1369,13 +1455,41 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         RowRegs<T, NCH> &r = rr[q];
         // rows with a denominator other than 1 are conservatively treated as not yet reduced
         const bool den1 = S.den[s] == 1;
-        row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, -1, den1 ? SIG_RED : 0, has_parm, lane);
+        bool row32 = false;  // a row of ints under denominator 1 without parameter columns (every input row of the
+                             // batch layer): summarised on 32-bit registers
+        int sz = 0;
+        if constexpr (sizeof(T) == 8) {
+          if (den1 && !has_parm) {
+            bool fits = true;
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+              for (int h = 0; h < 2; h++) fits &= r.v[c][h] == (T)(int)r.v[c][h];
+            if (__ballot(!fits) == 0) {
+              RowRegs32<NCH> z32;
+#pragma unroll
+              for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                  z32.v[c][h] = (int)r.v[c][h];
+                  const int q2 = z32.v[c][h];
+                  const int aq = q2 < 0 ? (int)(0u - (unsigned)q2) : q2;
+                  if (colof<T>(c, lane, h) < nvar) sz = sz > aq ? sz : aq;
+                }
+              mcw = max(mcw, row_publish32<NCH>(z32, S, s, nvar, -1, SIG_RED, lane));
+              row32 = true;
+            }
+          }
+        }
+        if (!row32)
+          mcw = max(mcw, row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, -1, den1 ? SIG_RED : 0, has_parm, lane));
         if (tflags & PIPAMD_T_SORT) {
           // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns.  The per-entry
           // terms are ints (x86 cvttsd2si: INT_MIN when out of range, and abs(INT_MIN) stays
           // negative, so it never wins the max): the row maximum is in [0, 2^31).
-          int sz = 0;
-          if (den1) {
+          if (row32) {
+            // computed above
+          } else if (den1) {
             // x / 1.0 == x exactly, and (int)x is x itself when it fits an int
 #pragma unroll
             for (int c = 0; c < NCH; c++)
@@ -1414,6 +1528,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     }
   }
   if constexpr (FUSE) tflags &= ~PIPAMD_T_FRESHROWS;
+  PIP_FLUSH_MC();
   bsync<NW>();
   PROF(14);
   if (tflags & PIPAMD_T_SORT) {
@@ -1482,9 +1597,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         }
         if (tid == 0) sc.tmp = BIG_I;
         bsync<NW>();
-        for (int rep19 = 0; rep19 < PIP_DUP_REPS(19); rep19++)
         for (int i = tid; i < nvar; i += NT) {
-          if (PIP_DUP == 19) PIP_OPAQUE_MEM();
           const int rf = S.ref[i];
           if (rf & UNITBIT) continue;
           const T D = S.den[rf];
@@ -1509,8 +1622,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
           const T D = uni64(S.den[cslot]);
           RowRegs<T, NCH> r;
           bool okv = false, okp = false;
-          for (int rep20 = 0; rep20 < PIP_DUP_REPS(20); rep20++) {
-          if (PIP_DUP == 20) PIP_OPAQUE_MEM();
           row_load<T, NCH>(r, vals + (size_t)cslot * W, ncolp, lane);
 #pragma unroll
           for (int c = 0; c < NCH; c++)
@@ -1529,7 +1640,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
               }
               r.v[c][h] = x;
             }
-          }
           const bool any_v = __ballot(okv) != 0, any_p = __ballot(okp) != 0;
           int verdict;
           if (any_p)
@@ -1568,11 +1678,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
                 }
             }
             // append the cut as logical row nligne in slot ni (integrer.c:440-446)
-            for (int rep21 = 0; rep21 < PIP_DUP_REPS(21); rep21++) {
-              if (PIP_DUP == 21) PIP_OPAQUE_MEM();
-              row_store<T, NCH>(r, vals + (size_t)ni * W, ncolp, lane);
-              row_publish<T, NCH>(r, S, ni, nvar, ncol, bigparm, -1, 0, has_parm, lane);
-            }
+            row_store<T, NCH>(r, vals + (size_t)ni * W, ncolp, lane);
+            mcw = max(mcw, row_publish<T, NCH>(r, S, ni, nvar, ncol, bigparm, -1, 0, has_parm, lane));
             if (lane == 0) {
               S.fl[ni] = PIPAMD_F_MINUS;
               S.nf[ni] = 0;
@@ -1585,6 +1692,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             sc.tmp2 = verdict;
             sc.aux = ci;
           }
+          PIP_FLUSH_MC();
         }
         bsync<NW>();
         if (sc.tmp2 != PIPAMD_ST_RUN) {
@@ -1603,17 +1711,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     const int pslot = S.ref[pivi];
     if (wave == 0) {
       RowRegs<T, NCH> pr;
-      int mc = 0;
-      typename ET<T>::U amax = 0;
-      for (int rep14 = 0; rep14 < PIP_DUP_REPS(14); rep14++) {
-      if (PIP_DUP == 14) PIP_OPAQUE_MEM();
       row_load<T, NCH>(pr, vals + (size_t)pslot * W, ncolp, lane);
-      // (while the pivot row is on its way) largest magnitude class of any row, for the guard below
-      mc = 0;
-      for (int s = lane; s < ni; s += 64)
-        if (S.rcls[s] > mc) mc = S.rcls[s];
-      mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
-      amax = 0;
+      // the largest magnitude class any row has had (sc.mc: kept up by whoever publishes a row), for the guard below
+      const int mc = sc.mc;
+      typename ET<T>::U amax = 0;
 #pragma unroll
       for (int c = 0; c < NCH; c++)
 #pragma unroll
@@ -1623,19 +1724,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
           S.prow[j] = pr.v[c][h];
           if (j < nvar && pr.v[c][h] > 0) amax |= (typename ET<T>::U)pr.v[c][h];
         }
-      }
       // exactness guard of the tournament: (max candidate a_j) * (max |entry|) < 2^62
       const int abits = cls_bits<T>(cls_of<T>(amax));
       const bool safe = abits + cls_bits<T>(mc) <= ET<T>::BITS - 2;
       PROF(3);
-      int pj = safe ? choose_column<T, NCH>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc)
-                    : choose_column_slow(S, vals, W, nvar, nligne);
-      if (PIP_DUP == 15) {
-        PIP_OPAQUE_MEM();
-        asm volatile("" : "+v"(pr.v[0][0]));
-        pj = safe ? choose_column<T, NCH>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc)
+      int pj;
+      if (sizeof(T) == 8 && mc == 0)  // every row in class 0, the pivot row among them
+        pj = choose_column<T, NCH, sizeof(T) == 8>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc);
+      else
+        pj = safe ? choose_column<T, NCH, false>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc)
                   : choose_column_slow(S, vals, W, nvar, nligne);
-      }
+
       PROF(4);
       if (pj >= 0) {
         // slots the elimination has to rewrite: the recycled pivot slot plus every real row
@@ -1643,9 +1742,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         constexpr int CW = 64 * ET<T>::CPL;
         const int pe = (pj / CW) * ET<T>::CPL + (pj % ET<T>::CPL), pl = (pj % CW) / ET<T>::CPL;
         int base = 0;
-        for (int rep13 = 0; rep13 < PIP_DUP_REPS(13); rep13++) {
-        if (PIP_DUP == 13) PIP_OPAQUE_MEM();
-        base = 0;
         for (int s0 = 0; s0 < ni; s0 += 64) {
           const int s = s0 + lane;
           bool need = false;
@@ -1664,7 +1760,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
           if (need) S.work[base + __popcll(m & ((1ull << lane) - 1))] = (u16)s;
           base += __popcll(m);
         }
-        }
         if (lane == 0) sc.nwork = base;
       }
       if (lane == 0) sc.pivj = pj;
@@ -1681,6 +1776,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     const T dpiv_v = S.den[pslot];
     const int psig_v = S.sig[pslot];
     const int prow_cls = S.rcls[pslot];  // magnitude class of the pivot row (as last published)
+
     if (pivj == -1) {  // traiter.c:782-785
       status = PIPAMD_ST_NIL;
       break;
@@ -1700,13 +1796,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
 #pragma unroll
     for (int q = 0; q < PF; q++) {
       const int w = wave + q * NW;
-      const int sw = q == 0 ? wq0 : (q == 1 ? wq1 : (int)S.work[w < nwork ? w : 0]);
+      // (work-list entries are wave-uniform: as scalars, the row addresses below are scalar arithmetic)
+      const int sw = __builtin_amdgcn_readfirstlane(q == 0 ? wq0 : (q == 1 ? wq1 : (int)S.work[w < nwork ? w : 0]));
       if (w < nwork && sw != pslot) row_load<T, NCH>(rr[q], vals + (size_t)sw * W, ncolp, lane);
     }
     // pivot scalars, traiter.c:394-396 (uniform, every thread); the determinant bookkeeping of
     // traiter.c:412-446 only needs them logged
     const T pivot = uni64(S.prow[pivj]);
     const T dpiv = uni64(dpiv_v);
+    // the pivot row's entries and its denominator below 2^15: rows of class 0 are rewritten on 32-bit registers
+    const bool prow_small = sizeof(T) == 8 && prow_cls == 0 && dpiv < ((T)1 << 15) && dpiv > -((T)1 << 15);
+    (void)prow_small;
     if (tid == 0) {
       g_log[2 * nlog] = pivot;
       g_log[2 * nlog + 1] = dpiv;
@@ -1724,7 +1824,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
 #pragma unroll
           for (int q = 0; q < PF; q++) {
             const int w = w0 + q * NW;
-            if (w < nwork && S.work[w] != pslot) row_load<T, NCH>(rr[q], vals + (size_t)S.work[w] * W, ncolp, lane);
+            const int sw = __builtin_amdgcn_readfirstlane((int)S.work[w < nwork ? w : 0]);
+            if (w < nwork && sw != pslot) row_load<T, NCH>(rr[q], vals + (size_t)sw * W, ncolp, lane);
           }
         }
 #pragma unroll
@@ -1732,21 +1833,27 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
           const int w = w0 + q * NW;
           if (w >= nwork) break;
           RowRegs<T, NCH> &r = rr[q];
-          const int s = S.work[w];
+          const int s = __builtin_amdgcn_readfirstlane((int)S.work[w]);
           T *row = vals + (size_t)s * W;
           if (s == pslot) {
             // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
+            bool recycled32 = false;
+            if constexpr (sizeof(T) == 8) {
+              if (prow_small && !has_parm) {  // the negated pivot row and its denominator fit ints
+                RowRegs32<NCH> z32;
 #pragma unroll
-            for (int c = 0; c < NCH; c++)
+                for (int c = 0; c < NCH; c++)
 #pragma unroll
-              for (int h = 0; h < ET<T>::CPL; h++) {
-                int j = colof<T>(c, lane, h);
-                r.v[c][h] = (j == pivj) ? dpiv : wneg(S.prow[j]);
+                  for (int h = 0; h < 2; h++) {
+                    const int j = colof<T>(c, lane, h);
+                    z32.v[c][h] = (j == pivj) ? (int)dpiv : -(int)S.prow[j];
+                  }
+                row_store32<NCH>(z32, row, ncolp, lane);
+                mcw = max(mcw, row_publish32<NCH>(z32, S, s, nvar, pivj, pred, lane));
+                recycled32 = true;
               }
-            row_store<T, NCH>(r, row, ncolp, lane);
-            row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
-            if (PIP_DUP == 9) {  // the recycled row once more
-              PIP_OPAQUE_MEM();
+            }
+            if (!recycled32) {
 #pragma unroll
               for (int c = 0; c < NCH; c++)
 #pragma unroll
@@ -1755,21 +1862,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
                   r.v[c][h] = (j == pivj) ? dpiv : wneg(S.prow[j]);
                 }
               row_store<T, NCH>(r, row, ncolp, lane);
-              row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
+              mcw = max(mcw, row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane));
             }
           } else {
             T nd;
-            if (PIP_DUP == 12) {  // the row's load and pivot-column read once more
-              PIP_OPAQUE_MEM();
-              row_load<T, NCH>(r, vals + (size_t)S.work[w] * W, ncolp, lane);
-            }
             // multipliers from the row's own pivot-column entry (traiter.c:470-476)
             T foo = row_entry<T, NCH>(r, pc, ph, pl);
-            if (PIP_DUP == 12) {
-              asm volatile("" : "+v"(r.v[0][0]));
-              foo ^= row_entry<T, NCH>(r, pc, ph, pl);
-              foo = row_entry<T, NCH>(r, pc, ph, pl);
-            }
             PROF(9);
             if (foo == 0 && (S.sig[s] & SIG_RED)) {
               // only reached with PIPAMD_T_NOSKIP: multipliers (1, 0) and gcd 1, the reference
@@ -1780,52 +1878,45 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             }
             // pivot > 0 (choisir_piv only takes positive entries): with pivot == 1, or
             // gcd(pivot, foo) == 1, the divisions of traiter.c:472-474 are by 1
-            T den_s = uni64(S.den[s]);
+            const T den_s = uni64(S.den[s]);
             T d = 1, lp = pivot, g0 = den_s;
-            const T foo_in = foo;
-            for (int rep16 = 0; rep16 < PIP_DUP_REPS(16); rep16++) {
-              if (PIP_DUP == 16) {
-                PIP_OPAQUE_MEM();
-                den_s = uni64(S.den[s]);
-                foo = foo_in;
-                if constexpr (sizeof(T) == 8) asm volatile("" : "+s"(foo));
-                d = 1, lp = pivot, g0 = den_s;
+            if (pivot != 1) {
+              d = gcd_i64(pivot, foo);
+              if (d != 1) {
+                lp = exact_quo(pivot, d);
+                foo = exact_quo(foo, d);
               }
-              if (pivot != 1) {
-                d = gcd_i64(pivot, foo);
-                if (d != 1) {
-                  lp = exact_quo(pivot, d);
-                  foo = exact_quo(foo, d);
-                }
-                g0 = wmul(lp, den_s);
-              }
+              g0 = wmul(lp, den_s);
             }
             PROF(10);
             bool done_small = false;
-            if constexpr (PIP_DUP == 17 && sizeof(T) == 8) {  // the row update once more, on a copy
-              RowRegs<T, NCH> r2 = r;
-              T nd2;
-              asm volatile("" : "+v"(r2.v[0][0]));
-              bool okk;
-              const T lim = (T)1 << 15;
-              if (S.rcls[s] == 0 && prow_cls == 0 && lp < lim && foo < lim && foo > -lim && dpiv < lim && dpiv > -lim)
-                okk = update_row_small<NCH>(r2, S.prow, pivj, (int)lp, (int)foo, (int)dpiv, g0, lane, nd2);
-              else
-                okk = update_row<T, NCH>(r2, S.prow, pivj, lp, foo, dpiv, g0, lane, nd2);
-              asm volatile("" ::"v"(r2.v[0][0]), "v"(r2.v[0][1]), "s"(nd2), "s"((int)okk));
-              PIP_OPAQUE_MEM();
-            }
             if constexpr (sizeof(T) == 8) {
               // both rows in magnitude class 0 (entries below 2^15) and small multipliers: 32-bit path
               const T lim = (T)1 << 15;
-              if (S.rcls[s] == 0 && prow_cls == 0 && lp < lim && foo < lim && foo > -lim && dpiv < lim && dpiv > -lim) {
-                if (!update_row_small<NCH>(r, S.prow, pivj, (int)lp, (int)foo, (int)dpiv, g0, lane, nd)) {
+              if (S.rcls[s] == 0 && prow_small && lp < lim && foo < lim && foo > -lim) {
+                RowRegs32<NCH> z32;
+                if (!update_row_small<NCH>(r, z32, S.prow, pivj, (int)lp, (int)foo, (int)dpiv, g0, lane, nd)) {
                   if (lane == 0) sc.bad = 1;
                 }
+                PROF(11);
+                // the results fit ints: stored and summarised from the 32-bit registers
+                row_store32<NCH>(z32, row, ncolp, lane);
+                if (!has_parm) {
+                  mcw = max(mcw, row_publish32<NCH>(z32, S, s, nvar, pivj, SIG_RED, lane));
+                } else {
+#pragma unroll
+                  for (int c = 0; c < NCH; c++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) r.v[c][h] = (T)z32.v[c][h];
+                  mcw = max(mcw, row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane));
+                }
+                if (lane == 0) S.den[s] = nd;
+                PROF(12);
                 done_small = true;
               }
             }
-            if (!done_small && !update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
+            if (done_small) continue;
+            if (!update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
               if (lane == 0) sc.bad = 1;
             }
             PROF(11);
@@ -1836,17 +1927,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             PROF_CNT(prof, 4, nd != g0);
             PROF_CNT(prof, 5, uni64(S.den[s]) != 1);
             PROF_CNT(prof, 6, (u64)uabs64(pivot) >> 16 != 0);
-            for (int rep18 = 0; rep18 < PIP_DUP_REPS(18); rep18++) {
-              if (PIP_DUP == 18) PIP_OPAQUE_MEM();
-              row_store<T, NCH>(r, row, ncolp, lane);
-              row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane);
-            }
+            row_store<T, NCH>(r, row, ncolp, lane);
+            mcw = max(mcw, row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane));
             if (lane == 0) S.den[s] = nd;
             PROF(12);
           }
         }
       }
     }
+    PIP_FLUSH_MC();
     bsync<NW>();
     PROF(6);
     if (sc.bad) {
