@@ -378,8 +378,10 @@ def timed(lanes, steps, warmup, barrier, stagger_arg=0):
 
 def timed_regions(lanes, steps, warmup, barrier, stagger_arg, n=3):
     """`n` timed regions of `steps` steps each behind one warm-up; sorted by duration: [(seconds, share)]"""
-    out = [timed(lanes, steps, warmup, barrier, stagger_arg)]
-    for _ in range(n - 1):
+    lanes.run(max(warmup, lanes.depth))
+    out = []
+    for _ in range(n):
+        lanes.next_step = 0   # every region times the same steps: batch 0, 1, ... in turn
         barrier()
         t0 = time.perf_counter()
         share = lanes.run(steps)

@@ -65,6 +65,12 @@ struct ET<i128> {
 typedef unsigned short u16;
 typedef unsigned char u8;
 
+#ifndef PIP_OPT_CSMALL
+#define PIP_OPT_CSMALL 1   // (A/B switch) choisir_piv with 24-bit cross products while every row is in class 0
+#endif
+#ifndef PIP_MINWAVES128
+#define PIP_MINWAVES128 4  // waves per SIMD the 128-bit kernels of <= 256 columns are bounded to (128 VGPRs; 1 = no bound)
+#endif
 #ifndef PIP_MINWAVES
 #define PIP_MINWAVES 6
 #endif
@@ -443,7 +449,6 @@ struct Shared {
 struct Scalars {
   int pivi, pivi2, pivj, tmp, tmp2, aux;
   int flagor, nwork, bad, ovf;
-  int mc;  // the largest magnitude class any row of the job has had in this launch (never lowered: conservative)
   u64 smaxbits;
 };
 
@@ -505,10 +510,9 @@ __device__ __forceinline__ T row_entry(const RowRegs<T, NCH> &r, int pc, int ph,
 
 // Sign summary, non-zero bitmap and magnitude class of a row held in registers
 // (wave-collective).  Lane 0 publishes them for slot s.
-// Returns the row's magnitude class (wave-uniform).
 template <class T, int NCH>
-__device__ __forceinline__ int row_publish(const RowRegs<T, NCH> &r, const Shared<T> &S, int s, int nvar, int ncol,
-                                           int bigparm, int pivj, int extra_sig, bool has_parm, int lane) {
+__device__ __forceinline__ void row_publish(const RowRegs<T, NCH> &r, const Shared<T> &S, int s, int nvar, int ncol,
+                                            int bigparm, int pivj, int extra_sig, bool has_parm, int lane) {
   int bs = 0;
   bool ppos = false, pneg = false;
   typename ET<T>::U mx = 0;
@@ -549,7 +553,6 @@ __device__ __forceinline__ int row_publish(const RowRegs<T, NCH> &r, const Share
 #pragma unroll
     for (int e = 0; e < NCH * ET<T>::CPL; e++) S.nzm[(size_t)s * (NCH * ET<T>::CPL) + e] = nz[e];
   }
-  return cls;
 }
 
 // ---- rows whose entries all fit an int (64-bit tableaux): the same three steps on 32-bit registers ----
@@ -1266,7 +1269,8 @@ struct PipQueue {
 // column counts and the row stride are compile-time constants, so the per-column range checks, the
 // parameter-sign bookkeeping of the row summaries and the stride multiplications disappear.
 template <class T, int NCH, int NW, bool GM, int SC, bool FULL>
-__global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? PIP_MINWAVES : 1) void pip_advance_kernel(
+__global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? PIP_MINWAVES
+                                      : ((sizeof(T) == 16 && NCH <= 4) ? PIP_MINWAVES128 : 1)) void pip_advance_kernel(
     PipJob *jobs, i64 *arena, int njobs, int Lmax_, int Smax_, int Wmax, int iter_limit, PipQueue q, unsigned char *gimg,
     size_t gimg_bytes, int gslots, u64 *prof) {
   const int Smax = SC > 0 ? SC : Smax_;
@@ -1320,13 +1324,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   T *g_log = (T *)(arena + J->log_off);
   constexpr int LOGCAP = PIPAMD_DETLOG;  // pairs the log area holds
   int nlog = J->nlog;
-  // magnitude classes of the rows this wave has published (row_publish returns them) and what of it sc.mc has seen
-  int mcw = 0, mcf = 0;
-#define PIP_FLUSH_MC()                                  \
-  do {                                                  \
-    if (mcw > mcf && lane == 0) atomicMax(&sc.mc, mcw); \
-    mcf = mcw;                                          \
-  } while (0)
   if (ni > Smax || nligne > Lmax) {  // this launch's LDS image is too small: stay RUN for a larger one
     if (tid == 0 && q.out_count) {
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
@@ -1399,7 +1396,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     sc.pivi2 = BIG_I;
     sc.flagor = 0;
     sc.bad = 0;
-    sc.mc = 0;
   }
   bsync<NW>();
   for (int i = tid; i < nligne; i += NT) {
@@ -1422,16 +1418,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     // resumed job: the summaries were saved when it paused
     for (int s = tid; s < ni; s += NT) {
       S.sig[s] = g_sig[s];
-      const int rc_ = g_rcls[s];
-      S.rcls[s] = (u8)rc_;
-      if (rc_ > 0) atomicMax(&sc.mc, rc_);
+      S.rcls[s] = g_rcls[s];
     }
     for (int e = tid; e < ni * NM; e += NT) S.nzm[e] = g_nzm[e];
     for (int s = tid; s < ni; s += NT) S.cst[s] = vals[(size_t)s * W + nvar];
   } else {
     // one pass over the tableau: sign summaries, bitmaps, magnitudes, sort keys (PF rows of a
     // wave in flight at a time)
-    constexpr int PF0 = NCH <= 2 ? 4 : (NCH == 4 ? 2 : 1);
+    constexpr int PF0 = (NCH * ET<T>::EW) <= 2 ? 4 : ((NCH * ET<T>::EW) <= 4 ? 2 : 1);  // by the registers a row takes
     const T *fresh = nullptr;
     if constexpr (FUSE)
       if (tflags & PIPAMD_T_FRESHROWS) fresh = (const T *)(uintptr_t)J->src_rows;
@@ -1455,41 +1449,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         RowRegs<T, NCH> &r = rr[q];
         // rows with a denominator other than 1 are conservatively treated as not yet reduced
         const bool den1 = S.den[s] == 1;
-        bool row32 = false;  // a row of ints under denominator 1 without parameter columns (every input row of the
-                             // batch layer): summarised on 32-bit registers
-        int sz = 0;
-        if constexpr (sizeof(T) == 8) {
-          if (den1 && !has_parm) {
-            bool fits = true;
-#pragma unroll
-            for (int c = 0; c < NCH; c++)
-#pragma unroll
-              for (int h = 0; h < 2; h++) fits &= r.v[c][h] == (T)(int)r.v[c][h];
-            if (__ballot(!fits) == 0) {
-              RowRegs32<NCH> z32;
-#pragma unroll
-              for (int c = 0; c < NCH; c++)
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                  z32.v[c][h] = (int)r.v[c][h];
-                  const int q2 = z32.v[c][h];
-                  const int aq = q2 < 0 ? (int)(0u - (unsigned)q2) : q2;
-                  if (colof<T>(c, lane, h) < nvar) sz = sz > aq ? sz : aq;
-                }
-              mcw = max(mcw, row_publish32<NCH>(z32, S, s, nvar, -1, SIG_RED, lane));
-              row32 = true;
-            }
-          }
-        }
-        if (!row32)
-          mcw = max(mcw, row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, -1, den1 ? SIG_RED : 0, has_parm, lane));
+        row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, -1, den1 ? SIG_RED : 0, has_parm, lane);
         if (tflags & PIPAMD_T_SORT) {
           // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns.  The per-entry
           // terms are ints (x86 cvttsd2si: INT_MIN when out of range, and abs(INT_MIN) stays
           // negative, so it never wins the max): the row maximum is in [0, 2^31).
-          if (row32) {
-            // computed above
-          } else if (den1) {
+          int sz = 0;
+          if (den1) {
             // x / 1.0 == x exactly, and (int)x is x itself when it fits an int
 #pragma unroll
             for (int c = 0; c < NCH; c++)
@@ -1528,7 +1494,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     }
   }
   if constexpr (FUSE) tflags &= ~PIPAMD_T_FRESHROWS;
-  PIP_FLUSH_MC();
   bsync<NW>();
   PROF(14);
   if (tflags & PIPAMD_T_SORT) {
@@ -1597,7 +1562,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         }
         if (tid == 0) sc.tmp = BIG_I;
         bsync<NW>();
+        for (int rep19 = 0; rep19 < PIP_DUP_REPS(19); rep19++)
         for (int i = tid; i < nvar; i += NT) {
+          if (PIP_DUP == 19) PIP_OPAQUE_MEM();
           const int rf = S.ref[i];
           if (rf & UNITBIT) continue;
           const T D = S.den[rf];
@@ -1622,6 +1589,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
           const T D = uni64(S.den[cslot]);
           RowRegs<T, NCH> r;
           bool okv = false, okp = false;
+          for (int rep20 = 0; rep20 < PIP_DUP_REPS(20); rep20++) {
+          if (PIP_DUP == 20) PIP_OPAQUE_MEM();
           row_load<T, NCH>(r, vals + (size_t)cslot * W, ncolp, lane);
 #pragma unroll
           for (int c = 0; c < NCH; c++)
@@ -1640,6 +1609,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
               }
               r.v[c][h] = x;
             }
+          }
           const bool any_v = __ballot(okv) != 0, any_p = __ballot(okp) != 0;
           int verdict;
           if (any_p)
@@ -1678,8 +1648,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
                 }
             }
             // append the cut as logical row nligne in slot ni (integrer.c:440-446)
-            row_store<T, NCH>(r, vals + (size_t)ni * W, ncolp, lane);
-            mcw = max(mcw, row_publish<T, NCH>(r, S, ni, nvar, ncol, bigparm, -1, 0, has_parm, lane));
+            for (int rep21 = 0; rep21 < PIP_DUP_REPS(21); rep21++) {
+              if (PIP_DUP == 21) PIP_OPAQUE_MEM();
+              row_store<T, NCH>(r, vals + (size_t)ni * W, ncolp, lane);
+              row_publish<T, NCH>(r, S, ni, nvar, ncol, bigparm, -1, 0, has_parm, lane);
+            }
             if (lane == 0) {
               S.fl[ni] = PIPAMD_F_MINUS;
               S.nf[ni] = 0;
@@ -1692,7 +1665,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             sc.tmp2 = verdict;
             sc.aux = ci;
           }
-          PIP_FLUSH_MC();
         }
         bsync<NW>();
         if (sc.tmp2 != PIPAMD_ST_RUN) {
@@ -1711,10 +1683,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     const int pslot = S.ref[pivi];
     if (wave == 0) {
       RowRegs<T, NCH> pr;
-      row_load<T, NCH>(pr, vals + (size_t)pslot * W, ncolp, lane);
-      // the largest magnitude class any row has had (sc.mc: kept up by whoever publishes a row), for the guard below
-      const int mc = sc.mc;
+      int mc = 0;
       typename ET<T>::U amax = 0;
+      for (int rep14 = 0; rep14 < PIP_DUP_REPS(14); rep14++) {
+      if (PIP_DUP == 14) PIP_OPAQUE_MEM();
+      row_load<T, NCH>(pr, vals + (size_t)pslot * W, ncolp, lane);
+      // (while the pivot row is on its way) largest magnitude class of any row, for the guard below
+      mc = 0;
+      for (int s = lane; s < ni; s += 64)
+        if (S.rcls[s] > mc) mc = S.rcls[s];
+      mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
+      amax = 0;
 #pragma unroll
       for (int c = 0; c < NCH; c++)
 #pragma unroll
@@ -1724,17 +1703,23 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
           S.prow[j] = pr.v[c][h];
           if (j < nvar && pr.v[c][h] > 0) amax |= (typename ET<T>::U)pr.v[c][h];
         }
+      }
       // exactness guard of the tournament: (max candidate a_j) * (max |entry|) < 2^62
       const int abits = cls_bits<T>(cls_of<T>(amax));
       const bool safe = abits + cls_bits<T>(mc) <= ET<T>::BITS - 2;
       PROF(3);
       int pj;
-      if (sizeof(T) == 8 && mc == 0)  // every row in class 0, the pivot row among them
+      if (PIP_OPT_CSMALL && sizeof(T) == 8 && mc == 0)  // every row in class 0, the pivot row among them
         pj = choose_column<T, NCH, sizeof(T) == 8>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc);
       else
         pj = safe ? choose_column<T, NCH, false>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc)
                   : choose_column_slow(S, vals, W, nvar, nligne);
-
+      if (PIP_DUP == 15) {
+        PIP_OPAQUE_MEM();
+        asm volatile("" : "+v"(pr.v[0][0]));
+        pj = safe ? choose_column<T, NCH, false>(S, pr, vals, W, nvar, nligne, pivi, ncolp, &sc)
+                  : choose_column_slow(S, vals, W, nvar, nligne);
+      }
       PROF(4);
       if (pj >= 0) {
         // slots the elimination has to rewrite: the recycled pivot slot plus every real row
@@ -1742,6 +1727,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
         constexpr int CW = 64 * ET<T>::CPL;
         const int pe = (pj / CW) * ET<T>::CPL + (pj % ET<T>::CPL), pl = (pj % CW) / ET<T>::CPL;
         int base = 0;
+        for (int rep13 = 0; rep13 < PIP_DUP_REPS(13); rep13++) {
+        if (PIP_DUP == 13) PIP_OPAQUE_MEM();
+        base = 0;
         for (int s0 = 0; s0 < ni; s0 += 64) {
           const int s = s0 + lane;
           bool need = false;
@@ -1760,6 +1748,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
           if (need) S.work[base + __popcll(m & ((1ull << lane) - 1))] = (u16)s;
           base += __popcll(m);
         }
+        }
         if (lane == 0) sc.nwork = base;
       }
       if (lane == 0) sc.pivj = pj;
@@ -1776,7 +1765,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     const T dpiv_v = S.den[pslot];
     const int psig_v = S.sig[pslot];
     const int prow_cls = S.rcls[pslot];  // magnitude class of the pivot row (as last published)
-
     if (pivj == -1) {  // traiter.c:782-785
       status = PIPAMD_ST_NIL;
       break;
@@ -1791,22 +1779,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
 #ifndef PIP_PF
 #define PIP_PF 2
 #endif
-    constexpr int PF = NCH <= 2 ? PIP_PF : (NCH == 4 ? 2 : 1);
+    constexpr int PF = (NCH * ET<T>::EW) <= 2 ? PIP_PF : ((NCH * ET<T>::EW) <= 4 ? 2 : 1);  // by the registers a row takes
     RowRegs<T, NCH> rr[PF];
 #pragma unroll
     for (int q = 0; q < PF; q++) {
       const int w = wave + q * NW;
-      // (work-list entries are wave-uniform: as scalars, the row addresses below are scalar arithmetic)
-      const int sw = __builtin_amdgcn_readfirstlane(q == 0 ? wq0 : (q == 1 ? wq1 : (int)S.work[w < nwork ? w : 0]));
+      const int sw = q == 0 ? wq0 : (q == 1 ? wq1 : (int)S.work[w < nwork ? w : 0]);
       if (w < nwork && sw != pslot) row_load<T, NCH>(rr[q], vals + (size_t)sw * W, ncolp, lane);
     }
     // pivot scalars, traiter.c:394-396 (uniform, every thread); the determinant bookkeeping of
     // traiter.c:412-446 only needs them logged
     const T pivot = uni64(S.prow[pivj]);
     const T dpiv = uni64(dpiv_v);
-    // the pivot row's entries and its denominator below 2^15: rows of class 0 are rewritten on 32-bit registers
-    const bool prow_small = sizeof(T) == 8 && prow_cls == 0 && dpiv < ((T)1 << 15) && dpiv > -((T)1 << 15);
-    (void)prow_small;
     if (tid == 0) {
       g_log[2 * nlog] = pivot;
       g_log[2 * nlog + 1] = dpiv;
@@ -1824,8 +1808,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
 #pragma unroll
           for (int q = 0; q < PF; q++) {
             const int w = w0 + q * NW;
-            const int sw = __builtin_amdgcn_readfirstlane((int)S.work[w < nwork ? w : 0]);
-            if (w < nwork && sw != pslot) row_load<T, NCH>(rr[q], vals + (size_t)sw * W, ncolp, lane);
+            if (w < nwork && S.work[w] != pslot) row_load<T, NCH>(rr[q], vals + (size_t)S.work[w] * W, ncolp, lane);
           }
         }
 #pragma unroll
@@ -1833,13 +1816,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
           const int w = w0 + q * NW;
           if (w >= nwork) break;
           RowRegs<T, NCH> &r = rr[q];
-          const int s = __builtin_amdgcn_readfirstlane((int)S.work[w]);
+          const int s = S.work[w];
           T *row = vals + (size_t)s * W;
           if (s == pslot) {
             // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
             bool recycled32 = false;
             if constexpr (sizeof(T) == 8) {
-              if (prow_small && !has_parm) {  // the negated pivot row and its denominator fit ints
+              const T lim_ = (T)1 << 15;
+              if (prow_cls == 0 && dpiv < lim_ && dpiv > -lim_ && !has_parm) {
                 RowRegs32<NCH> z32;
 #pragma unroll
                 for (int c = 0; c < NCH; c++)
@@ -1849,11 +1833,23 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
                     z32.v[c][h] = (j == pivj) ? (int)dpiv : -(int)S.prow[j];
                   }
                 row_store32<NCH>(z32, row, ncolp, lane);
-                mcw = max(mcw, row_publish32<NCH>(z32, S, s, nvar, pivj, pred, lane));
+                row_publish32<NCH>(z32, S, s, nvar, pivj, pred, lane);
                 recycled32 = true;
               }
             }
             if (!recycled32) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+              for (int h = 0; h < ET<T>::CPL; h++) {
+                int j = colof<T>(c, lane, h);
+                r.v[c][h] = (j == pivj) ? dpiv : wneg(S.prow[j]);
+              }
+            row_store<T, NCH>(r, row, ncolp, lane);
+            row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
+            }
+            if (PIP_DUP == 9) {  // the recycled row once more
+              PIP_OPAQUE_MEM();
 #pragma unroll
               for (int c = 0; c < NCH; c++)
 #pragma unroll
@@ -1862,12 +1858,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
                   r.v[c][h] = (j == pivj) ? dpiv : wneg(S.prow[j]);
                 }
               row_store<T, NCH>(r, row, ncolp, lane);
-              mcw = max(mcw, row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane));
+              row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
             }
           } else {
             T nd;
+            if (PIP_DUP == 12) {  // the row's load and pivot-column read once more
+              PIP_OPAQUE_MEM();
+              row_load<T, NCH>(r, vals + (size_t)S.work[w] * W, ncolp, lane);
+            }
             // multipliers from the row's own pivot-column entry (traiter.c:470-476)
             T foo = row_entry<T, NCH>(r, pc, ph, pl);
+            if (PIP_DUP == 12) {
+              asm volatile("" : "+v"(r.v[0][0]));
+              foo ^= row_entry<T, NCH>(r, pc, ph, pl);
+              foo = row_entry<T, NCH>(r, pc, ph, pl);
+            }
             PROF(9);
             if (foo == 0 && (S.sig[s] & SIG_RED)) {
               // only reached with PIPAMD_T_NOSKIP: multipliers (1, 0) and gcd 1, the reference
@@ -1878,45 +1883,63 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             }
             // pivot > 0 (choisir_piv only takes positive entries): with pivot == 1, or
             // gcd(pivot, foo) == 1, the divisions of traiter.c:472-474 are by 1
-            const T den_s = uni64(S.den[s]);
+            T den_s = uni64(S.den[s]);
             T d = 1, lp = pivot, g0 = den_s;
-            if (pivot != 1) {
-              d = gcd_i64(pivot, foo);
-              if (d != 1) {
-                lp = exact_quo(pivot, d);
-                foo = exact_quo(foo, d);
+            const T foo_in = foo;
+            for (int rep16 = 0; rep16 < PIP_DUP_REPS(16); rep16++) {
+              if (PIP_DUP == 16) {
+                PIP_OPAQUE_MEM();
+                den_s = uni64(S.den[s]);
+                foo = foo_in;
+                if constexpr (sizeof(T) == 8) asm volatile("" : "+s"(foo));
+                d = 1, lp = pivot, g0 = den_s;
               }
-              g0 = wmul(lp, den_s);
+              if (pivot != 1) {
+                d = gcd_i64(pivot, foo);
+                if (d != 1) {
+                  lp = exact_quo(pivot, d);
+                  foo = exact_quo(foo, d);
+                }
+                g0 = wmul(lp, den_s);
+              }
             }
             PROF(10);
             bool done_small = false;
+            if constexpr (PIP_DUP == 17 && sizeof(T) == 8) {  // the row update once more, on a copy
+              RowRegs<T, NCH> r2 = r;
+              T nd2;
+              asm volatile("" : "+v"(r2.v[0][0]));
+              bool okk;
+              const T lim = (T)1 << 15;
+              if (S.rcls[s] == 0 && prow_cls == 0 && lp < lim && foo < lim && foo > -lim && dpiv < lim && dpiv > -lim)
+                { RowRegs32<NCH> zz; okk = update_row_small<NCH>(r2, zz, S.prow, pivj, (int)lp, (int)foo, (int)dpiv, g0, lane, nd2); }
+              else
+                okk = update_row<T, NCH>(r2, S.prow, pivj, lp, foo, dpiv, g0, lane, nd2);
+              asm volatile("" ::"v"(r2.v[0][0]), "v"(r2.v[0][1]), "s"(nd2), "s"((int)okk));
+              PIP_OPAQUE_MEM();
+            }
             if constexpr (sizeof(T) == 8) {
               // both rows in magnitude class 0 (entries below 2^15) and small multipliers: 32-bit path
               const T lim = (T)1 << 15;
-              if (S.rcls[s] == 0 && prow_small && lp < lim && foo < lim && foo > -lim) {
+              if (S.rcls[s] == 0 && prow_cls == 0 && lp < lim && foo < lim && foo > -lim && dpiv < lim && dpiv > -lim) {
                 RowRegs32<NCH> z32;
                 if (!update_row_small<NCH>(r, z32, S.prow, pivj, (int)lp, (int)foo, (int)dpiv, g0, lane, nd)) {
                   if (lane == 0) sc.bad = 1;
                 }
-                PROF(11);
-                // the results fit ints: stored and summarised from the 32-bit registers
-                row_store32<NCH>(z32, row, ncolp, lane);
                 if (!has_parm) {
-                  mcw = max(mcw, row_publish32<NCH>(z32, S, s, nvar, pivj, SIG_RED, lane));
-                } else {
-#pragma unroll
-                  for (int c = 0; c < NCH; c++)
-#pragma unroll
-                    for (int h = 0; h < 2; h++) r.v[c][h] = (T)z32.v[c][h];
-                  mcw = max(mcw, row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane));
+                  row_store32<NCH>(z32, row, ncolp, lane);
+                  row_publish32<NCH>(z32, S, s, nvar, pivj, SIG_RED, lane);
+                  if (lane == 0) S.den[s] = nd;
+                  continue;
                 }
-                if (lane == 0) S.den[s] = nd;
-                PROF(12);
+#pragma unroll
+                for (int c = 0; c < NCH; c++)
+#pragma unroll
+                  for (int h = 0; h < 2; h++) r.v[c][h] = (T)z32.v[c][h];
                 done_small = true;
               }
             }
-            if (done_small) continue;
-            if (!update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
+            if (!done_small && !update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
               if (lane == 0) sc.bad = 1;
             }
             PROF(11);
@@ -1927,15 +1950,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
             PROF_CNT(prof, 4, nd != g0);
             PROF_CNT(prof, 5, uni64(S.den[s]) != 1);
             PROF_CNT(prof, 6, (u64)uabs64(pivot) >> 16 != 0);
-            row_store<T, NCH>(r, row, ncolp, lane);
-            mcw = max(mcw, row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane));
+            for (int rep18 = 0; rep18 < PIP_DUP_REPS(18); rep18++) {
+              if (PIP_DUP == 18) PIP_OPAQUE_MEM();
+              row_store<T, NCH>(r, row, ncolp, lane);
+              row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane);
+            }
             if (lane == 0) S.den[s] = nd;
             PROF(12);
           }
         }
       }
     }
-    PIP_FLUSH_MC();
     bsync<NW>();
     PROF(6);
     if (sc.bad) {

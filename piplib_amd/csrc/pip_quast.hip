@@ -578,7 +578,8 @@ __device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i64 c, i6
 // traiter() of a tableau without parameters, integer solve (the sub-problems of compa_test and the
 // context test): true when the first cell of its tape would not be Nil
 // Result word: bit 0 = a solution exists, bits 1..15 = reason bits (per lane), bits 16.. = pivots.
-__device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int deepest, long long deadline) {
+// `budget`: pivots the problem may still spend (Q_PIVOT_BUDGET less what it has used): beyond it the problem is handed back.
+__device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int deepest, int budget) {
   const int ncol = nvar + 1;
   int bad = sort_rows(t, nvar, nvar + ni, lane), pivots = 0, found = 0;
   for (int guard = 0; guard < 30000 && !__any(bad); guard++) {  // (the pivot count has 15 bits of the result word)
@@ -617,7 +618,7 @@ __device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int d
     const int pr = pivot_step(t, pivi, nvar, ncol, nvar + ni, lane);
     if (__any(pr < 0)) break;  // no positive entry in the pivot row: Nil
     bad |= pr;
-    if (guard == 29999 || wall_clock64() > deadline) bad |= Q_WHY_OTHER;  // (the deadline: see the kernel)
+    if (guard == 29999 || pivots > budget) bad |= Q_WHY_OTHER;  // (the pivot budget: see the kernel)
   }
   return found | (bad << 1) | (pivots << 16);
 }
@@ -705,10 +706,12 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   if (pi >= nprob) return;
   const QProb P = probs[pi];
   const long long t_start = wall_clock64();
-  // No problem keeps its wave for more than two seconds (wall_clock64 ticks at 100 MHz): whatever is still
-  // running then is handed back to the host schedulers.  Every loop below is bounded on its own; this bounds
-  // their product.
-  const long long deadline = t_start + 200000000ll;
+  // No problem keeps its wave for more than Q_PIVOT_BUDGET pivots (its own and those of its compa_test sub-problems;
+  // about two seconds of one wave): whatever is still running then is handed back to the host schedulers.  Every loop
+  // below is bounded on its own; this bounds their product -- by a count, so that which side serves a problem does not
+  // depend on the load of the GPU.  The clock (wall_clock64 ticks at 100 MHz) stays as a last resort at 60 seconds.
+  constexpr int Q_PIVOT_BUDGET = 250000;
+  const long long deadline = t_start + 6000000000ll;
   Wv w;
   w.lane = threadIdx.x;
   w.bad = 0;
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
     if (sni < 0)
       w.bad |= Q_WHY_ROWS | 1024;
     else {
-      const int r = solve_plain(S, nparm, sni, lane, w.deepest, deadline);
+      const int r = solve_plain(S, nparm, sni, lane, w.deepest, Q_PIVOT_BUDGET - w.pivots);
       w.bad |= (r >> 1) & 0x7fff;
       w.pivots += r >> 16;
       if (!(r & 1) && !BAD(w)) result = Q_VOID;
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
     int pivi = 0, next = DECIDE;
     bool enter = true, finished = false;
     for (int guard = 0; guard < 2000000 && !finished; guard++) {
-      if (wall_clock64() > deadline) w.bad |= Q_WHY_OTHER;
+      if (w.pivots > Q_PIVOT_BUDGET || wall_clock64() > deadline) w.bad |= Q_WHY_OTHER;
       if (BAD(w)) break;
       if (next == DECIDE) {
         if (enter) {
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
                 ex = lane < nparm ? cneg(vp, w.bad) : (lane == nparm ? csub(cneg(vc, w.bad), 1, w.bad) : 0);
                 sni = build_sub(S, ctx, CW, nparm, nc, true, ex, lane);
               }
-              const int r = solve_plain(S, nparm, sni, lane, w.deepest, deadline);
+              const int r = solve_plain(S, nparm, sni, lane, w.deepest, Q_PIVOT_BUDGET - w.pivots);
               w.bad |= (r >> 1) & 0x7fff;
               w.pivots += r >> 16;
               can[sg] = r & 1;
