@@ -581,6 +581,7 @@ def main():
     progress(f"regions {[round(r[0] * 1e3, 2) for r in regions]} ms")
     tot = lanes.totals(share)
     hist = lanes.status_histogram()
+    screened0 = dict(lanes.screened)
 
     # the advance kernel's own launch durations (HIP events on its stream), un-overlapped
     parts0 = lanes.batches[0]
@@ -637,7 +638,7 @@ def main():
                    "screened_out": {"what": "tableaux on which Gomory's cuts have not converged within 448 cut rows (the "
                                             "reference does not finish them within minutes either), replaced by their "
                                             "neighbours before anything is timed; seed -> indices",
-                                    "rank0": {str(k): v for k, v in sorted(lanes.screened.items())}}},
+                                    "rank0": {str(k): v for k, v in sorted(screened0.items())}}},
         "steps_timed": steps_done,
         "regions_ms": [round(r[0] * 1e3, 3) for r in regions],
         "problems_per_sec": gt[3] / dt_max,

@@ -20,16 +20,49 @@
  * reference sources where they lie (oracle/_ref/libpiplib_gpu_dp.so, oracle/_ref/refpip_gpu) and
  * the -m gpu tests run the reference's test (.dat) and example (.pip) suites through it.
  *
- * Only the int64 ("dp") flavour: the engine's host tree works on 64-bit entries.
+ * Flavour-generic, like PipLib itself (PIPLIB_NAME, include/piplib/piplib.h:40-88, source/funcall.h:37-47): compiled
+ * with -DPIPLIB_INT_DP it defines pipamd_traiter_hook_dp over the 64-bit engine (pipamd_traiter); compiled with
+ * -DPIPLIB_INT_GMP it defines pipamd_traiter_hook_gmp over the 128-bit engine (pipamd_traiter128): the overflow-safe
+ * device flavour serves the arbitrary-precision build as long as the input coefficients fit 64 bits (they come from a
+ * PipMatrix / a .dat file) -- answers whose numbers fit 128 bits come back exact, a problem that would leave 128 bits
+ * ends with the engine's "Integer overflow" like the fixed-width flavours (oracle/_ref/libpiplib_gpu_gmp.so,
+ * oracle/_ref/refpip_gpu_gmp; tests/test_gpu_golden.py runs the reference's .dat suite through it).
  */
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "pip.h" /* PipLib's internal header (source/pip.h): Tableau_dp, Index/Denom/Flag, sol_*_dp */
+#include "pip.h" /* PipLib's internal header (source/pip.h): Tableau_xx, Index/Denom/Flag, sol_*_xx */
 #include "piplib_amd.h"
 
 long long pipamd_hook_pivots; /* pivots of the calls so far (drivers print it) */
-extern int deepest_cut_dp;     /* source/piplib.c:53 (set from PipOptions.Deepest_cut, piplib.c:746) */
+extern int deepest_cut_xx;     /* source/piplib.c:53 (set from PipOptions.Deepest_cut, piplib.c:746) */
+
+#define pipamd_traiter_hook_xx PIPLIB_NAME(pipamd_traiter_hook)
+#ifdef PIPLIB_INT_GMP
+typedef pipamd_sol_cell128 hook_cell;
+/* an Entier of the caller as int64 (input coefficients) */
+static long long entier_in(piplib_int_t_xx v) {
+  if (!mpz_fits_slong_p(v)) {
+    fprintf(stderr, "piplib (GPU traiter): an input coefficient does not fit 64 bits\n");
+    exit(1);
+  }
+  return mpz_get_si(v);
+}
+/* a 128-bit (low, high) value of the engine as an mpz */
+static void entier_out(mpz_t r, int64_t lo, int64_t hi) {
+  unsigned long long w[2];
+  const int neg = hi < 0;
+  unsigned __int128 m = ((unsigned __int128)(unsigned long long)hi << 64) | (unsigned long long)lo;
+  if (neg) m = (unsigned __int128)0 - m;
+  w[0] = (unsigned long long)m;
+  w[1] = (unsigned long long)(m >> 64);
+  mpz_import(r, 2, -1, sizeof w[0], 0, 0, w);
+  if (neg) mpz_neg(r, r);
+}
+#else
+typedef pipamd_sol_cell hook_cell;
+#define entier_in(v) ((long long)(v))
+#endif
 
 static pipamd_engine *hook_engine(void) {
   static pipamd_engine *eng;
@@ -43,12 +76,12 @@ static pipamd_engine *hook_engine(void) {
   return eng;
 }
 
-void pipamd_traiter_hook_dp(Tableau_dp *tp, Tableau_dp *ctxt, int nvar, int nparm, int ni, int nc, int bigparm,
+void pipamd_traiter_hook_xx(Tableau_xx *tp, Tableau_xx *ctxt, int nvar, int nparm, int ni, int nc, int bigparm,
                             int flags) {
   const int ncol = nvar + nparm + 1;
   long long *rows = malloc(sizeof(long long) * ((size_t)ni * ncol + 1));
   long long *crow = malloc(sizeof(long long) * ((size_t)nc * (nparm + 1) + 1));
-  pipamd_sol_cell *cells = NULL;
+  hook_cell *cells = NULL;
   size_t n = 0, k;
   int i, j, status = 0, rc;
   int64_t piv = 0;
@@ -59,16 +92,21 @@ void pipamd_traiter_hook_dp(Tableau_dp *tp, Tableau_dp *ctxt, int nvar, int npar
   /* the callers build tp with tab_Matrix2Tableau / tab_get / expanser: nvar unit rows, then ni
    * Unknown rows with denominator 1 (tab.c:222-248, 292-393) */
   for (i = 0; i < ni; i++) {
-    if (Flag(tp, nvar + i) != Unknown || Denom(tp, nvar + i) != 1) {
+    if (Flag(tp, nvar + i) != Unknown || !piplib_int_one(Denom(tp, nvar + i))) {
       fprintf(stderr, "piplib (GPU traiter): row %d is not a fresh Unknown row\n", i);
       exit(1);
     }
-    for (j = 0; j < ncol; j++) rows[(size_t)i * ncol + j] = Index(tp, nvar + i, j);
+    for (j = 0; j < ncol; j++) rows[(size_t)i * ncol + j] = entier_in(Index(tp, nvar + i, j));
   }
   for (i = 0; i < nc; i++)
-    for (j = 0; j <= nparm; j++) crow[(size_t)i * (nparm + 1) + j] = Index(ctxt, i, j);
-  rc = pipamd_traiter(hook_engine(), nvar, nparm, ni, nc, bigparm, flags & (TRAITER_INT | TRAITER_DUAL), deepest_cut_dp,
+    for (j = 0; j <= nparm; j++) crow[(size_t)i * (nparm + 1) + j] = entier_in(Index(ctxt, i, j));
+#ifdef PIPLIB_INT_GMP
+  rc = pipamd_traiter128(hook_engine(), nvar, nparm, ni, nc, bigparm, flags & (TRAITER_INT | TRAITER_DUAL), deepest_cut_xx,
+                         (const int64_t *)rows, (const int64_t *)crow, &cells, &n, &status, &piv);
+#else
+  rc = pipamd_traiter(hook_engine(), nvar, nparm, ni, nc, bigparm, flags & (TRAITER_INT | TRAITER_DUAL), deepest_cut_xx,
                       (const int64_t *)rows, (const int64_t *)crow, &cells, &n, &status, &piv);
+#endif
   pipamd_hook_pivots += piv;
   free(rows);
   free(crow);
@@ -80,15 +118,39 @@ void pipamd_traiter_hook_dp(Tableau_dp *tp, Tableau_dp *ctxt, int nvar, int npar
     fprintf(stderr, "piplib (GPU traiter): %s (status %d)\n", pipamd_last_error(), status);
     exit(1);
   }
+#ifdef PIPLIB_INT_GMP
+  {
+    mpz_t a, b;
+    mpz_init(a);
+    mpz_init(b);
+    for (k = 0; k < n; k++) switch (cells[k].kind) {
+        case PIPAMD_SOL_NIL: sol_nil_xx(); break;
+        case PIPAMD_SOL_IF: sol_if_xx(); break;
+        case PIPAMD_SOL_LIST: sol_list_xx((int)cells[k].param1_lo); break;
+        case PIPAMD_SOL_FORM: sol_forme_xx((int)cells[k].param1_lo); break;
+        case PIPAMD_SOL_NEW: sol_new_xx((int)cells[k].param1_lo); break;
+        case PIPAMD_SOL_DIV: sol_div_xx(); break;
+        case PIPAMD_SOL_VAL:
+          entier_out(a, cells[k].param1_lo, cells[k].param1_hi);
+          entier_out(b, cells[k].param2_lo, cells[k].param2_hi);
+          sol_val_xx(a, b);
+          break;
+        default: fprintf(stderr, "piplib (GPU traiter): unknown tape cell %d\n", cells[k].kind); exit(1);
+      }
+    mpz_clear(a);
+    mpz_clear(b);
+  }
+#else
   for (k = 0; k < n; k++) switch (cells[k].kind) {
-      case PIPAMD_SOL_NIL: sol_nil_dp(); break;
-      case PIPAMD_SOL_IF: sol_if_dp(); break;
-      case PIPAMD_SOL_LIST: sol_list_dp((int)cells[k].param1); break;
-      case PIPAMD_SOL_FORM: sol_forme_dp((int)cells[k].param1); break;
-      case PIPAMD_SOL_NEW: sol_new_dp((int)cells[k].param1); break;
-      case PIPAMD_SOL_DIV: sol_div_dp(); break;
-      case PIPAMD_SOL_VAL: sol_val_dp(cells[k].param1, cells[k].param2); break;
+      case PIPAMD_SOL_NIL: sol_nil_xx(); break;
+      case PIPAMD_SOL_IF: sol_if_xx(); break;
+      case PIPAMD_SOL_LIST: sol_list_xx((int)cells[k].param1); break;
+      case PIPAMD_SOL_FORM: sol_forme_xx((int)cells[k].param1); break;
+      case PIPAMD_SOL_NEW: sol_new_xx((int)cells[k].param1); break;
+      case PIPAMD_SOL_DIV: sol_div_xx(); break;
+      case PIPAMD_SOL_VAL: sol_val_xx(cells[k].param1, cells[k].param2); break;
       default: fprintf(stderr, "piplib (GPU traiter): unknown tape cell %d\n", cells[k].kind); exit(1);
     }
+#endif
   pipamd_free(cells);
 }

@@ -38,7 +38,8 @@ extern "C" {
  * tape cells (`cells, n_cells`) instead of text; the transliterated pip_solve front end (pipamd_pip_solve,
  * pipamd_quast_*) is gone: pip_solve stays the reference's piplib.c over bindings/piplib_traiter_hook.c.
  * 300: round 3 -- pipamd_batch_solve_async / _wait / _poll, pipamd_batch_load_part, unbounded row growth in the
- * batch layer (no PIPAMD_ST_CAPACITY short of the engine's 16,000-row limit), the 128-bit lock-step entry. */
+ * batch layer (no PIPAMD_ST_CAPACITY short of the engine's 16,000-row limit), pipamd_solve_tableaux128,
+ * pipamd_engine_set_max_rows. */
 #define PIPAMD_VERSION 300
 
 /* ---- error codes (return values) ---- */
@@ -284,6 +285,12 @@ typedef struct pipamd_problem {
 int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
                           int deepest_cut, int nthreads, pipamd_sol_cell **cells, size_t *n_cells, int *rcs,
                           int *statuses, int64_t *pivots);
+
+/* The same on 128-bit entries (one TreeT<__int128> per host thread; cells as pipamd_traiter128 hands them out).  The
+ * lock-step scheduler and the device-resident traiter() below stay 64-bit. */
+int pipamd_solve_tableaux128(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
+                             int deepest_cut, int nthreads, pipamd_sol_cell128 **cells, size_t *n_cells, int *rcs,
+                             int *statuses, int64_t *pivots);
 
 /* The same results from a lock-step scheduler: one explicit traiter() state machine per problem
  * and, per step, ONE clone / patch / pivot-kernel / gather sequence for the whole batch, so the

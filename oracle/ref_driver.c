@@ -79,7 +79,7 @@ int pivoter_xx(Tableau_xx *tp, int pivi, int nvar, int nparm, int ni) {
 }
 #endif
 
-#ifdef PIPLIB_INT_GMP
+#if defined(PIPLIB_INT_GMP) && !defined(REF_GPU_HOOK) && !defined(REF_NO_COUNT)
 /* ---- width tracker: the reference's arithmetic goes through libgmp's PLT entries; the main
  * executable's definitions win, record the width of the result and call the real function ---- */
 static void track(mpz_srcptr r) {
@@ -274,7 +274,7 @@ static int mode_batch(const char *in_path, const char *out_path) {
     hq = tab_hwm_xx();
     xq = p = sol_hwm_xx();
     g_pivots = 0;
-#ifdef PIPLIB_INT_GMP
+#if defined(PIPLIB_INT_GMP) && !defined(REF_GPU_HOOK) && !defined(REF_NO_COUNT)
     g_entry_bits = g_det_bits = 0;
     g_det = NULL;
 #endif
@@ -320,7 +320,7 @@ static int mode_batch(const char *in_path, const char *out_path) {
     rh.pivots = g_pivots;
     total_pivots += g_pivots;
     rh.text_len = (unsigned)txtlen;
-#ifdef PIPLIB_INT_GMP
+#if defined(PIPLIB_INT_GMP) && !defined(REF_GPU_HOOK) && !defined(REF_NO_COUNT)
     rh.reserved = (g_entry_bits > 0xffff ? 0xffffu : g_entry_bits) | ((g_det_bits > 0xffff ? 0xffffu : g_det_bits) << 16);
 #endif
     fwrite(&rh, sizeof rh, 1, out);

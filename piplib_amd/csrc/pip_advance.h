@@ -1927,9 +1927,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
                   if (lane == 0) sc.bad = 1;
                 }
                 if (!has_parm) {
+                  PROF(11);
                   row_store32<NCH>(z32, row, ncolp, lane);
                   row_publish32<NCH>(z32, S, s, nvar, pivj, SIG_RED, lane);
                   if (lane == 0) S.den[s] = nd;
+                  PROF(12);
                   continue;
                 }
 #pragma unroll

@@ -1069,28 +1069,16 @@ extern "C" int pipamd_solve_tableau128(pipamd_engine *e, int nvar, int nparm, in
 // Many independent problems: `nthreads` host threads, each with its own tree (device arena and
 // HIP stream), pull problems from a shared counter; their launches overlap on the GPU.
 // rc[i] receives what pipamd_solve_tableau would have returned for problem i.
-extern "C" int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
-                                     int nthreads, pipamd_sol_cell **cells, size_t *n_cells, int *rcs, int *statuses,
-                                     int64_t *pivots) {
-  if (!e || n < 0 || (n && (!probs || !cells || !n_cells || !rcs))) return PIPAMD_E_INVALID;
-  if (nthreads < 1) nthreads = 1;
-  if (nthreads > n) nthreads = n > 0 ? n : 1;
-  for (int i = 0; i < n; i++) {  // a worker that cannot even start leaves its problems marked as failed
-    rcs[i] = PIPAMD_E_HIP;
-    cells[i] = nullptr;
-    n_cells[i] = 0;
-    if (statuses) statuses[i] = 0;
-    if (pivots) pivots[i] = 0;
-  }
-  std::vector<char> served(n > 0 ? n : 1, 0);
-  if (hipSetDevice(e->device) == hipSuccess)  // small problems: wholly on the device, in one launch
-    device_tree_many(e, n, probs, simplify, deepest_cut, served, cells, n_cells, rcs, statuses, pivots);
+// TREE = Tree (64-bit entries; small problems go to the device-resident traiter() first) or TreeT<i128>.
+template <class TREE, class CELL>
+static int solve_many(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut, int nthreads,
+                      CELL **cells, size_t *n_cells, int *rcs, int *statuses, int64_t *pivots, std::vector<char> &served) {
   std::atomic<int> next(0);
   const int device = e->device;
   auto worker = [&]() {
     if (hipSetDevice(device) != hipSuccess) return;
     try {
-      Tree t(e, deepest_cut);
+      TREE t(e, deepest_cut);
       for (;;) {
         const int i = next.fetch_add(1);
         if (i >= n) break;
@@ -1110,6 +1098,43 @@ extern "C" int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_probl
   for (int k = 0; k < nthreads; k++) th.emplace_back(worker);
   for (auto &x : th) x.join();
   return PIPAMD_OK;
+}
+
+template <class CELL>
+static bool many_args(pipamd_engine *e, int n, const pipamd_problem *probs, int &nthreads, CELL **cells, size_t *n_cells,
+                      int *rcs, int *statuses, int64_t *pivots) {
+  if (!e || n < 0 || (n && (!probs || !cells || !n_cells || !rcs))) return false;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > n) nthreads = n > 0 ? n : 1;
+  for (int i = 0; i < n; i++) {  // a worker that cannot even start leaves its problems marked as failed
+    rcs[i] = PIPAMD_E_HIP;
+    cells[i] = nullptr;
+    n_cells[i] = 0;
+    if (statuses) statuses[i] = 0;
+    if (pivots) pivots[i] = 0;
+  }
+  return true;
+}
+
+extern "C" int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
+                                     int nthreads, pipamd_sol_cell **cells, size_t *n_cells, int *rcs, int *statuses,
+                                     int64_t *pivots) {
+  if (!many_args(e, n, probs, nthreads, cells, n_cells, rcs, statuses, pivots)) return PIPAMD_E_INVALID;
+  std::vector<char> served(n > 0 ? n : 1, 0);
+  if (hipSetDevice(e->device) == hipSuccess)  // small problems: wholly on the device, in one launch
+    device_tree_many(e, n, probs, simplify, deepest_cut, served, cells, n_cells, rcs, statuses, pivots);
+  return solve_many<Tree, pipamd_sol_cell>(e, n, probs, simplify, deepest_cut, nthreads, cells, n_cells, rcs, statuses, pivots,
+                                           served);
+}
+
+// The same on 128-bit entries (the overflow-safe flavour): one TreeT<__int128> per host thread.
+extern "C" int pipamd_solve_tableaux128(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
+                                        int nthreads, pipamd_sol_cell128 **cells, size_t *n_cells, int *rcs, int *statuses,
+                                        int64_t *pivots) {
+  if (!many_args(e, n, probs, nthreads, cells, n_cells, rcs, statuses, pivots)) return PIPAMD_E_INVALID;
+  std::vector<char> served(n > 0 ? n : 1, 0);
+  return solve_many<TreeT<i128>, pipamd_sol_cell128>(e, n, probs, simplify, deepest_cut, nthreads, cells, n_cells, rcs, statuses,
+                                                     pivots, served);
 }
 
 // =========================================================================== Forest

@@ -228,3 +228,39 @@ def test_parametric_128bit_tree_vs_reference_gmp_build(seed):
         assert pb.squash(text) == pb.squash(want) and piv == r["pivots"], (seed, i, piv, r["pivots"])
         checked += 1
     assert checked >= 12
+
+
+def test_many_problems_on_the_128bit_tree():
+    """pipamd_solve_tableaux128 (host threads, a TreeT<__int128> each) gives problem by problem what the one-problem
+    entry gives -- which the test above holds against the reference's GMP build."""
+    from gmpfix import gmp_fixture
+    from piplib_amd import engine as eng
+    probs, flags, recs, sha = gmp_fixture("param81")
+    keep = [p for p, r in zip(probs, recs) if "status" in r and r["pivots"] <= 20000]
+    e = eng.Engine(0)
+    many = eng.solve_tableaux128(e, keep, nthreads=6)
+    assert len(many) == len(keep) >= 20
+    for p, (text, rc, st, piv) in zip(keep, many):
+        try:
+            t1, p1 = eng.solve_tableau(e, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx, bits=128)
+        except eng.SolverError as ex:
+            assert rc == -5 and st == ex.status
+            continue
+        assert rc == 0 and text == t1 and piv == p1
+
+
+REFPIP_GPU_GMP = os.path.join(os.path.dirname(pb.REFPIP_GPU), "refpip_gpu_gmp")
+
+
+@pytest.mark.skipif(not os.access(REFPIP_GPU_GMP, os.X_OK), reason="oracle/_ref/refpip_gpu_gmp not built (no /root/reference or no gmp.h)")
+@pytest.mark.parametrize("name", PIPTEST_DAT)
+def test_dat_golden_through_the_gmp_flavour_front_end(name):
+    """The reference's GMP flavour (tab_get, tape, sol_edit on mpz_t) with its traiter calls bound to the 128-bit engine
+    by bindings/piplib_traiter_hook.c compiled with -DPIPLIB_INT_GMP (pipamd_traiter_hook_gmp over pipamd_traiter128):
+    test/*.dat vs test/*.ll -- nothing overflows on these inputs, so the arbitrary-precision front end over the
+    overflow-safe device flavour must print the int64 goldens."""
+    import subprocess
+    p = subprocess.run([REFPIP_GPU_GMP, "dat", os.path.join(G, "test", name + ".dat")], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
+    want = open(os.path.join(G, "test", name + ".ll"), encoding="latin-1").read()
+    assert pb.squash(p.stdout.decode("latin-1")) == pb.squash(want)
