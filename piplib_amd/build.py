@@ -25,10 +25,12 @@ def needs_build():
 def build(force=False, verbose=True, profile=False):
     """profile=True builds the diagnostic variant libpipamd_prof.so (-DPIP_PROFILE: per-phase
     cycle stamps in the kernel; never used for timing or shipped results)."""
+    # (the cycle stamps take 32 more VGPRs: without -DPIP_MINWAVES=1 the one-wave kernels' 80-register bound would push
+    # them into scratch and the stamps would measure the spills)
     if profile == "events":
-        return _compile(os.path.join(HERE, "libpipamd_prof_events.so"), ["-DPIP_PROFILE", "-DPIP_PROFILE_EVENTS"], verbose)
+        return _compile(os.path.join(HERE, "libpipamd_prof_events.so"), ["-DPIP_PROFILE", "-DPIP_PROFILE_EVENTS", "-DPIP_MINWAVES=1"], verbose)
     if profile:
-        return _compile(os.path.join(HERE, "libpipamd_prof.so"), ["-DPIP_PROFILE"], verbose)
+        return _compile(os.path.join(HERE, "libpipamd_prof.so"), ["-DPIP_PROFILE", "-DPIP_MINWAVES=1"], verbose)
     if os.environ.get("PIP_MINWAVES"):  # tuning experiments only
         return _compile(os.path.join(HERE, "libpipamd_mw%s.so" % os.environ["PIP_MINWAVES"]),
                         ["-DPIP_MINWAVES=" + os.environ["PIP_MINWAVES"]], verbose)

@@ -1808,10 +1808,12 @@ class Forest {
 // Small problems: the whole traiter() call tree on the device (pip_quast.hip), one wave per problem.
 // Fills res[i] for the problems it finishes; the others keep rc == PIPAMD_E_TOOLARGE ("next path").
 namespace {
-// device buffer `slot` of the engine, at least `bytes` large (kept between calls; grown with headroom)
+// device buffer `slot` of the engine, at least `bytes` large (kept between calls; grown with headroom, given back
+// when a call needs less than a quarter of it and more than 256 MB would stay pinned for nothing)
 template <class T>
 T *dt_buffer(pipamd_engine *e, int slot, size_t bytes) {
-  if (bytes > e->dt_cap[slot]) {
+  const bool oversized = e->dt_cap[slot] > 4 * bytes + ((size_t)256 << 20);
+  if (bytes > e->dt_cap[slot] || oversized) {
     if (e->dt_buf[slot]) hipFree(e->dt_buf[slot]);
     e->dt_buf[slot] = nullptr;
     e->dt_cap[slot] = 0;
@@ -1963,8 +1965,8 @@ void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simpl
     explicit Hold(pthread_mutex_t *mm) : m(mm) { pthread_mutex_lock(m); }
     ~Hold() { pthread_mutex_unlock(m); }
   } hold(&e->dt_lock);
-  // chunks of problems whose stack + tape regions fit the budget (PIPAMD_FOREST_ARENA_MB, default 8192)
-  size_t budget = (size_t)8192 << 20;
+  // chunks of problems whose stack + tape regions fit the budget (PIPAMD_FOREST_ARENA_MB, default 4096)
+  size_t budget = (size_t)4096 << 20;
   if (const char *mb = getenv("PIPAMD_FOREST_ARENA_MB")) budget = (size_t)strtoull(mb, nullptr, 10) << 20;
   std::vector<int> idx;
   QCaps cap;
@@ -2075,8 +2077,8 @@ extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pip
     for (size_t k = 0; k < rest.size(); k++) rp[k] = probs[rest[k]];
     const int nr = (int)rest.size();
     // The forest reserves a worst-case region per problem; batches whose regions add up to more
-    // than the arena budget go through it in chunks (PIPAMD_FOREST_ARENA_MB, default 8192).
-    size_t budget = (size_t)8192 << 20;
+    // than the arena budget go through it in chunks (PIPAMD_FOREST_ARENA_MB, default 4096).
+    size_t budget = (size_t)4096 << 20;
     if (const char *mb = getenv("PIPAMD_FOREST_ARENA_MB")) budget = (size_t)strtoull(mb, nullptr, 10) << 20;
     try {
       Forest f(e->device);

@@ -1,4 +1,4 @@
-"""Pipelined and lone rates of one of bench.py's other configurations (GPU box): python3 tools/cfg_rate.py 1|4 [lanes]"""
+"""Pipelined and lone rates of one of bench.py's other configurations (GPU box): python3 tools/cfg_rate.py 1|4 [lanes [waves per tableau]]"""
 import os, sys, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -7,7 +7,7 @@ import torch
 import bench
 oc = [c for c in bench.OTHERS if c["key"] == "configs[%s]" % sys.argv[1]][0]
 od = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-args = types.SimpleNamespace(waves=0, round=0, round_rows=0, tail_waves=0, blocking_wait=-1, bulk_min=-1, copy_rows=False)
+args = types.SimpleNamespace(waves=int(sys.argv[3]) if len(sys.argv) > 3 else 0, round=0, round_rows=0, tail_waves=0, blocking_wait=-1, bulk_min=-1, copy_rows=False)
 dev = torch.device("cuda", 0)
 def barrier(): torch.cuda.synchronize(dev)
 fuse = max(1, min(16, 5000 // oc["batch"])) if oc["ebits"] == 64 else 1

@@ -34,7 +34,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p3_cfg4 -- $C
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/p3_cfg4_fetch -- $C 1 > gpurun_out/p3_cfg4_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/p3_cfg4_write -- $C 1 > gpurun_out/p3_cfg4_write.log 2>&1
 echo "cfg4 done"
-# 6. phase profile (diagnostic builds must exist: python -m piplib_amd.build --profile; --profile-events)
-python3 tools/dbg_prof.py 10000 2>/dev/null | tail -17 > gpurun_out/p3_phase_bulk.txt
-EVENTS=1 python3 tools/dbg_prof.py 10000 2>/dev/null | tail -37 | head -20 > gpurun_out/p3_phase_events.txt
 echo "all done"

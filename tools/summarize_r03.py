@@ -115,9 +115,5 @@ issue["note"] = ("SQ_* cycle counters are quad-cycles (MI355X_MICROARCH.md); uti
                  "kernels, so pipeline12 shows the same lone launches as pipeline1 (12 batches, each launch on its own).")
 json.dump(issue, open(os.path.join(P, "r03_pmc_issue.json"), "w"), indent=1)
 
-hdr = ["# tools/dbg_prof.py 10000 (python -m piplib_amd.build --profile build): wave cycles per pivot and phase, one un-pipelined headline batch"]
-body = open(os.path.join(G, "p3_phase_bulk.txt")).read().rstrip("\n").splitlines()
-ev = open(os.path.join(G, "p3_phase_events.txt")).read().rstrip("\n").splitlines()
-open(os.path.join(P, "r03_phase_profile.txt"), "w").write("\n".join(hdr + body + ["# event counts per pivot (--profile-events build)"] + ev[1:]) + "\n")
 print(json.dumps({k: v for k, v in out.items() if "bytes" in k or k in ("dense_mode", "cfg4")}, indent=1))
 print(json.dumps(issue, indent=1)[:1500])
