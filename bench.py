@@ -9,7 +9,7 @@ Headline workload (BASELINE.json configs[2], the one the metric is quoted on): p
 column; no parameters), integer solve with Gomory cuts, one workgroup per tableau.
 A "step" = tab_get-style load of the batch into the HBM row store + the whole traiter()
 pivot loop for every tableau (inputs are resident in HBM before the timed region).
-Steps are pipelined: up to --pipeline (default 12) batches are in flight on separate HIP streams,
+Steps are pipelined: up to --pipeline (default 14) batches are in flight on separate HIP streams,
 each lane with its own batch (own seed), engine and workspace (each step is a complete load +
 solve of its batch), all driven by ONE host thread through the asynchronous C ABI
 (pipamd_batch_solve_async / pipamd_batch_wait; `--threads` = round 2's one-host-thread-per-lane
@@ -487,7 +487,7 @@ def main():
                     help="strong (default for --gpus > 1, BASELINE configs[3]): every --batch-tableau batch is sharded "
                          "over the ranks; weak (default for one GPU): --batch tableaux per GPU and batch.  The other "
                          "mode is measured too and reported as `other_scaling`.")
-    ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (streams)")
+    ap.add_argument("--pipeline", type=int, default=14, help="batches in flight (streams)")
     ap.add_argument("--threads", action="store_true",
                     help="one host thread per lane calling the synchronous pipamd_batch_solve (round 2's driver) instead of "
                          "one thread over pipamd_batch_solve_async / pipamd_batch_wait")
@@ -506,12 +506,10 @@ def main():
     # Batches in flight run on separate HIP streams; the runtime multiplexes streams onto
     # GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels that share a queue serialise, so
     # give every lane a queue of its own (a HIP runtime setting, read when the runtime starts).
-    # 16 queues suit 12 lanes of 10k-tableau batches best (24 or 32 queues: -3..4 %); the 24 lanes of the small
-    # shards of an 8-way strong-scaling run gain 9 % from 32 (two lanes on a queue wait for each other's tails).
+    # 16 queues suit 14 lanes best (round 3, one MI355X, 20 / 96 steps: 14 lanes on 16 queues 383 / 394 M pivots/s,
+    # 16 lanes 378 / 394, 12 lanes 364 / 384; 24 queues 355 / 373, 32 queues 311 / 373).
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    strong = args.scaling == "strong" or (args.scaling is None and world_env > 1)
-    small_shards = strong and (args.batch + world_env - 1) // world_env < 2000
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32" if small_shards else "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import numpy as np
     import torch
     from piplib_amd import engine as eng

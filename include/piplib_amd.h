@@ -162,7 +162,7 @@ int pipamd_batch_solve(pipamd_engine *e, void *d_workspace, const pipamd_batch_d
  * One solve in flight per engine -- an engine is a small host object: a caller keeps K of them, each with its own
  * stream and workspace, starts a batch on each and polls them in turn, starting the next batch on whichever is done:
  * a lone batch leaves most of the GPU idle in its latency-bound tail, K batches in different phases fill it
- * (bench.py: one host thread, K = 12).  Results may be fetched once poll has returned 1 / wait has returned. */
+ * (bench.py: one host thread, K = 14).  Results may be fetched once poll has returned 1 / wait has returned. */
 int pipamd_batch_solve_async(pipamd_engine *e, void *d_workspace, const pipamd_batch_desc *d, void *stream);
 /* Row budget of the growth above: a tableau is re-housed only while its row capacity stays within `rows` (at least
  * ni + cap_cuts; 0 = the default, only the engine's own limit) and ends PIPAMD_ST_CAPACITY beyond it.  The reference
