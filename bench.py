@@ -8,12 +8,12 @@ Headline workload (BASELINE.json configs[2], the one the metric is quoted on): p
 10,000 synthetic 64x128 int64 tableaux (nvar = 127 unknowns, 64 inequality rows, constant
 column; no parameters), integer solve with Gomory cuts, one workgroup per tableau.
 A "step" = tab_get-style load of the batch into the HBM row store + the whole traiter()
-pivot loop for every tableau (inputs are resident in HBM before the timed region).
+pivot loop for every tableau + solution() (pipamd_batch_load, pipamd_batch_solve, pipamd_batch_results: status,
+pivot and cut counts and the solutions into the caller's arrays); inputs are resident in HBM before the timed region.
 Steps are pipelined: up to --pipeline (default 14) batches are in flight on separate HIP streams,
-each lane with its own batch (own seed), engine and workspace (each step is a complete load +
-solve of its batch), all driven by ONE host thread through the asynchronous C ABI
-(pipamd_batch_solve_async / pipamd_batch_wait; `--threads` = round 2's one-host-thread-per-lane
-driver, measured beside it as `threaded_value`).  The timed region is run three times; ms_per_step is
+each lane with its own engine and workspace (each step is a complete load + solve + results of its
+batch), all driven by ONE host thread through the asynchronous C ABI (pipamd_batch_solve_async /
+pipamd_batch_poll; `--threads` = round 2's one-host-thread-per-lane driver).  The timed region is run three times; ms_per_step is
 the median region / steps and all three are printed (`regions_ms`).  `pipeline1_value` is the same
 workload with one batch at a time.  `other_configs` carries BASELINE configs[1] and configs[4]
 measured the same way (shorter runs).
@@ -184,8 +184,8 @@ def lane_stream(torch, dev, i):
 
 class Lanes:
     """`depth` batches in flight: `depth` resident batches (own seed each) and as many lanes, a lane being an engine,
-    a workspace and a HIP stream.  Step k solves batch k mod depth on whichever lane is free (load + solve, a complete
-    pipamd_batch_load + pipamd_batch_solve of that batch): while one batch's last stragglers finish (a latency-bound
+    a workspace and a HIP stream.  Step k solves batch k mod depth on whichever lane is free (a complete
+    pipamd_batch_load + pipamd_batch_solve + pipamd_batch_results of that batch): while one batch's last stragglers finish (a latency-bound
     tail that leaves most CUs idle) the other batches' bulk launches run.  ONE host thread drives all lanes through
     pipamd_batch_solve_async / pipamd_batch_poll -- it starts a batch on every lane and goes round polling; a lane
     that is done gets the next batch (threads=True: a host thread per lane calling the synchronous
@@ -295,6 +295,8 @@ class Lanes:
             while active:
                 for i in list(active):
                     if self.lanes[i][1].poll():
+                        # solution(): status, pivot and cut counts and the solutions into the caller's arrays
+                        self.lanes[i][1].fetch(self.lanes[i][2].cuda_stream)
                         done.append(active.pop(i))
                         start(i)
         return done
@@ -314,6 +316,7 @@ class Lanes:
                             break
                         bi.load_parts(self.batches[k], st.cuda_stream)
                         bi.solve(st.cuda_stream)
+                        bi.fetch(st.cuda_stream)
                         with lock:
                             done.append(k)
             except BaseException as ex:  # surfaced below

@@ -232,11 +232,12 @@ class Batch:
             _check(rc)
         return rc
 
-    def fetch(self):
+    def fetch(self, stream=None):
+        st = C.c_void_p(stream) if stream is not None else self._stream()
         _check(lib().pipamd_batch_results(self.e._h, C.c_void_p(self.ws.data_ptr()), C.byref(self.desc),
                                           C.c_void_p(self.status.data_ptr()), C.c_void_p(self.pivots.data_ptr()),
                                           C.c_void_p(self.cuts.data_ptr()), C.c_void_p(self.sol_num.data_ptr()),
-                                          C.c_void_p(self.sol_den.data_ptr()), self._stream()))
+                                          C.c_void_p(self.sol_den.data_ptr()), st))
 
     def counters(self):
         """dict of batch totals (pivots, cuts, rows_rewritten, finished) -- synchronises."""

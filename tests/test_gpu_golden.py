@@ -264,3 +264,35 @@ def test_dat_golden_through_the_gmp_flavour_front_end(name):
     assert p.returncode == 0, p.stderr.decode()[-300:]
     want = open(os.path.join(G, "test", name + ".ll"), encoding="latin-1").read()
     assert pb.squash(p.stdout.decode("latin-1")) == pb.squash(want)
+
+
+def test_plain_c_stream_of_batches(tmp_path):
+    """examples/batch_stream.c (built by __graft_entry__.build()): a stream of batches from plain C and one host thread
+    through pipamd_batch_solve_async / pipamd_batch_poll -- every tableau finished, and the pivots it counts are those
+    the Python binding counts for the same batches."""
+    import subprocess
+    import numpy as np
+    import torch
+    from piplib_amd import engine as eng, synth
+    exe = os.path.join(pb.ROOT, "examples", "batch_stream")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("examples/batch_stream not built")
+    nb, B, nvar, ni, lanes, steps = 3, 1500, 127, 64, 4, 10
+    batches = [synth.lexmin_batch(1000 + 7919 * b, B, nvar, ni) for b in range(nb)]
+    path = str(tmp_path / "rows.bin")
+    with open(path, "wb") as f:
+        for r in batches:
+            f.write(np.ascontiguousarray(r, dtype="<i8").tobytes())
+    p = subprocess.run([exe, path, str(nb), str(B), str(nvar), str(ni), str(lanes), str(steps)], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-400:]
+    line = p.stdout.decode().strip().splitlines()[-1]
+    e = eng.Engine(0)
+    piv = []
+    for r in batches:
+        b = eng.Batch(e, r, nvar, 0, tflags=eng.T_INT)
+        b.load()
+        b.solve()
+        piv.append(b.counters()["pivots"])
+    want = sum(piv[k % nb] for k in range(steps))
+    assert f": {want} pivots in" in line, (line, want)
+    assert f"solution {lanes * B} nil 0 other 0" in line, line
