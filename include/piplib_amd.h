@@ -307,7 +307,8 @@ int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem
  * no host round trip.  A problem in which a 64-bit operation would overflow, or that outgrows its
  * reserved rows, is handed back and served by the lock-step scheduler / the per-problem tree, which
  * reproduce the reference's wrap-around and "Integer overflow" behaviour.  pipamd_traiter,
- * pipamd_solve_tableau and pipamd_solve_tableaux try it first too (64-bit entries, no dual).  On by default (the environment
+ * pipamd_solve_tableau and pipamd_solve_tableaux try it first too (64-bit entries; since interface version 300 also with
+ * PIPAMD_T_DUAL).  On by default (the environment
  * variable PIPAMD_NO_DEVICE_TREE switches it off for a process);
  * pipamd_last_device_tree reports how many problems of the last lock-step call each side served. */
 int pipamd_engine_set_device_tree(pipamd_engine *e, int on);

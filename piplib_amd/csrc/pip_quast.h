@@ -10,7 +10,8 @@ struct QProb {
   int nvar, nparm, ni, nc, bigparm, nq;
   int flags, pad;  // Q_NO_CONTEXT_TEST: traiter() proper (the front ends test the context in a call of its own)
 };
-enum { Q_NO_CONTEXT_TEST = 1 };
+enum { Q_NO_CONTEXT_TEST = 1,
+       Q_DUAL = 2 };  // Compute_dual (traiter.c:273-294): the list of dual values behind every (rational) solution
 // capacities of one launch (every problem of the launch gets the same LDS image and HBM regions)
 struct QCaps {
   int R, S, W;    // main tableau: logical rows, real-row slots, columns (W <= 64, S <= 64)

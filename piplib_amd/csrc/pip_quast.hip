@@ -57,8 +57,11 @@ struct Wv {
 
 // scalars of the main tableau that travel with a stack frame
 struct QState {
-  int nvar, nparm, ni, nc, pivi, ldet, pad0, pad1;
+  int nvar, nparm, ni, nc, pivi, ldet, ni0, pad1;
   i64 det[MAXDET];
+  // Compute_dual: tab_sort_rows' `pos` of the traiter() call in progress (traiter.c:567-620): logical row of each of
+  // the call's ni0 inequalities after its sort.  Part of the image, so a fork's frame keeps the caller's.
+  unsigned short pos[64];
 };
 
 #define BAD(w) (__any((w).bad) != 0)
@@ -232,7 +235,10 @@ __device__ __forceinline__ int trunc_x86(double t) {
   return (!(t > -2147483649.0 && t < 2147483648.0)) ? (int)0x80000000 : (int)t;
 }
 __device__ __forceinline__ int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
-__device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane) {
+// pos != null (Compute_dual): pos[i] = the logical row inequality i (row nvar + i before the sort) ends up in; unit
+// rows among nvar.. count as inequality 0, later rows overwriting earlier ones -- the reference never sets their
+// `ineq` (traiter.c:577-578 vs 617-618), zero-filled as the oracle and the reference's own fixtures have it.
+__device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane, LDS unsigned short *pos) {
   const int n = nligne - nvar;  // rows to sort: at most 64 + the unit rows among them
   if (n > 64) return Q_WHY_ROWS | 256;
   // lane l holds logical row nvar + l (flag, slot, denominator, key); the selection sort swaps lanes
@@ -264,6 +270,7 @@ __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane) {
       }
     }
   }
+  int oi = real ? lane : 0;  // the inequality this lane's row is (Compute_dual)
   const u64 realm = __ballot(real);
   int smx = 0;
   for (u64 c = realm; c; c &= c - 1) {
@@ -273,8 +280,8 @@ __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane) {
   const double smax = (double)smx;
   int kb = __float_as_int((float)(double)s);  // non-negative floats order like their bit patterns
   u64 below = __ballot(real && (double)(float)(double)s < smax);
-  if (!below) return 0;  // no key below the maximum: no row moves
   bool moved = false;
+  if (below)  // (else no key is below the maximum: no row moves)
   for (int i = 0; i < n; i++) {
     if (!((realm >> i) & 1)) continue;
     u64 c = below & ~((1ull << i) - 1);
@@ -291,17 +298,19 @@ __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane) {
     {  // rows i and p trade places (traiter.c:604-612)
       const int dl = (int)(u64)dn, dh = (int)((u64)dn >> 32);
       const int f_i = rdlane(fl, i), f_p = rdlane(fl, p), r_i = rdlane(rf, i), r_p = rdlane(rf, p);
-      const int k_i = rdlane(kb, i), k_p = rdlane(kb, p);
+      const int k_i = rdlane(kb, i), k_p = rdlane(kb, p), o_i = rdlane(oi, i), o_p = rdlane(oi, p);
       const int dl_i = rdlane(dl, i), dl_p = rdlane(dl, p), dh_i = rdlane(dh, i), dh_p = rdlane(dh, p);
       if (lane == i) {
         fl = f_p;
         rf = r_p;
         kb = k_p;
+        oi = o_p;
         dn = (i64)(((u64)(unsigned)dh_p << 32) | (unsigned)dl_p);
       } else if (lane == p) {
         fl = f_i;
         rf = r_i;
         kb = k_i;
+        oi = o_i;
         dn = (i64)(((u64)(unsigned)dh_i << 32) | (unsigned)dl_i);
       }
       const u64 bi = (below >> i) & 1;
@@ -315,6 +324,14 @@ __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane) {
       t.ref[k] = rf;
       t.den[k] = dn;
     }
+    wsync();
+  }
+  if (pos) {
+    if (lane < 64) pos[lane] = 0;
+    wsync();
+    const u64 zero = __ballot(lane < n && oi == 0);  // the row that was inequality 0, and every unit row
+    if (lane < n && oi > 0) pos[oi] = (unsigned short)k;
+    if (zero && lane == 63 - __builtin_clzll(zero)) pos[0] = (unsigned short)k;  // the last of them wins
     wsync();
   }
   return 0;
@@ -581,7 +598,7 @@ __device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i64 c, i6
 // `budget`: pivots the problem may still spend (Q_PIVOT_BUDGET less what it has used): beyond it the problem is handed back.
 __device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int deepest, int budget) {
   const int ncol = nvar + 1;
-  int bad = sort_rows(t, nvar, nvar + ni, lane), pivots = 0, found = 0;
+  int bad = sort_rows(t, nvar, nvar + ni, lane, nullptr), pivots = 0, found = 0;
   for (int guard = 0; guard < 30000 && !__any(bad); guard++) {  // (the pivot count has 15 bits of the result word)
     const int nligne = nvar + ni;
     int pivi = first_flagged(t, F_MINUS, nligne, lane);
@@ -768,6 +785,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   int nvar = P.nvar, nparm = P.nparm, ni = P.ni, nc = P.nc;
   const int bigparm = P.bigparm, CW = cap.CW, W = cap.W;
   const bool integer = P.nq != 0;
+  const bool dual = (P.flags & Q_DUAL) != 0 && !integer;  // the dual goes with rational solves only (piplib.c:854-857)
   int result = Q_DONE;
 
   // ---- load: zero the main image, rows Unknown with denominator 1 under nvar unit rows (tab.c:158-248)
@@ -846,7 +864,9 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
       if (BAD(w)) break;
       if (next == DECIDE) {
         if (enter) {
-          w.bad |= sort_rows(M, nvar, nvar + ni, lane);
+          w.bad |= sort_rows(M, nvar, nvar + ni, lane, dual ? st->pos : nullptr);
+          if (dual && lane == 0) st->ni0 = ni;
+          wsync();
           enter = false;
           if (BAD(w)) break;
         }
@@ -1071,6 +1091,27 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
               if (lane == nvar) tape_put(tape, at + nparm + 1, C_VAL, v, d);
             }
             tape.n += need;
+            if (dual) {
+              // solution_dual, traiter.c:273-294: one value per inequality of this call
+              const int ni0 = st->ni0;
+              if (tape.n + 1 + 2 * ni0 >= tape.cap) {
+                w.bad |= Q_WHY_TAPE;
+                break;
+              }
+              if (lane == 0) tape_put(tape, tape.n, C_LIST, ni0, 0);
+              if (lane < ni0) {
+                const int k = st->pos[lane];
+                i64 v = 0, d = 1;
+                if (M.flag[k] & F_UNIT) {  // valeur(tp, 0, unit column of row k) over Denom(tp, 0)
+                  const int u = M.ref[k];
+                  d = M.den[0];
+                  v = (M.flag[0] & F_UNIT) ? (M.ref[0] == u ? d : 0) : M.val[M.ref[0] * W + u];
+                }
+                tape_put(tape, tape.n + 1 + 2 * lane, C_FORM, 1, 0);
+                tape_put(tape, tape.n + 2 + 2 * lane, C_VAL, v, d);
+              }
+              tape.n += 1 + 2 * ni0;
+            }
             next = LEAVE;
           }
         }

@@ -1011,16 +1011,14 @@ static int traiter_any(pipamd_engine *e, int nvar, int nparm, int ni, int nc, in
   if (pivots) *pivots = 0;
   int rc = PIPAMD_OK;
   try {
-    if constexpr (sizeof(E) == sizeof(i64)) {  // a small problem without the dual: wholly on the device
-      if (!(flags & PIPAMD_T_DUAL)) {
-        const pipamd_problem p{nvar, nparm, ni, nc, bigparm, (flags & PIPAMD_T_INT) ? 1 : 0, tableau, context};
-        std::vector<Cell> tape;
-        bool is_void = false;
-        int64_t pv = 0;
-        if (device_tree_one(e, p, 0, deepest_cut, Q_NO_CONTEXT_TEST, tape, &is_void, &pv)) {
-          if (pivots) *pivots = pv;
-          return export_tape(tape, cells, n_cells);
-        }
+    if constexpr (sizeof(E) == sizeof(i64)) {  // a small problem (with or without the dual): wholly on the device
+      const pipamd_problem p{nvar, nparm, ni, nc, bigparm, (flags & PIPAMD_T_INT) ? 1 : 0, tableau, context};
+      std::vector<Cell> tape;
+      bool is_void = false;
+      int64_t pv = 0;
+      if (device_tree_one(e, p, 0, deepest_cut, Q_NO_CONTEXT_TEST | ((flags & PIPAMD_T_DUAL) ? Q_DUAL : 0), tape, &is_void, &pv)) {
+        if (pivots) *pivots = pv;
+        return export_tape(tape, cells, n_cells);
       }
     }
     TreeT<E> t(e, deepest_cut);
@@ -2032,6 +2030,8 @@ static bool device_tree_one(pipamd_engine *e, const pipamd_problem &p, int simpl
   res[0].rc = PIPAMD_E_TOOLARGE;
   int served = 0, back = 0;
   device_tree(e, 1, &p, simplify, deepest_cut, res, &served, &back, qflags);
+  e->dt_served = served;  // (pipamd_last_device_tree also answers for the one-problem entries)
+  e->dt_fallback = back;
   if (res[0].rc != PIPAMD_OK) return false;
   tape.swap(res[0].tape);
   *is_void = res[0].is_void;

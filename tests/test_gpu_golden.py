@@ -112,12 +112,14 @@ def test_pip_solve_golden_on_gpu(name):
 
 
 @needs_hook
+@pytest.mark.parametrize("device_tree", [True, False], ids=["device-tree", "host-tree"])
 @pytest.mark.parametrize("name", ["small", "square", "max", "big", "cg1", "sven"])
-def test_compute_dual_on_gpu(name):
-    """pip_solve with Nq = 0 and Compute_dual = 1 (TRAITER_DUAL through the hook) vs reference-generated fixtures."""
+def test_compute_dual_on_gpu(name, device_tree):
+    """pip_solve with Nq = 0 and Compute_dual = 1 (TRAITER_DUAL through the hook) vs reference-generated fixtures; with
+    the device-resident traiter() (which computes the dual since round 3) and with the host tree alone."""
     d = os.path.join(G, "ref_dp")
     with open(os.path.join(d, f"dual__{name}.pip")) as f:
-        p = ref_front_end(["pip"], stdin=f)
+        p = ref_front_end(["pip"], stdin=f, device_tree=device_tree)
     assert p.returncode == 0, p.stderr.decode()[-300:]
     want = open(os.path.join(d, f"dual__{name}.ll"), encoding="latin-1").read()
     assert pb.squash(p.stdout.decode("latin-1")) == pb.squash(want)
@@ -296,3 +298,27 @@ def test_plain_c_stream_of_batches(tmp_path):
     want = sum(piv[k % nb] for k in range(steps))
     assert f": {want} pivots in" in line, (line, want)
     assert f"solution {lanes * B} nil 0 other 0" in line, line
+
+
+@pytest.mark.parametrize("seed,shape", [(91, (5, 0, 7, 0)), (92, (5, 2, 7, 2)), (93, (8, 1, 10, 1)), (94, (4, 3, 9, 3)), (95, (12, 2, 20, 2))])
+def test_dual_on_the_device_tree_vs_host_tree(seed, shape):
+    """Compute_dual (TRAITER_DUAL, rational solves): the device-resident traiter() against the host tree (which the
+    fixtures of the reference pin) on random problems with and without parameters -- same tape cells, same pivot count,
+    and the device really served them."""
+    from piplib_amd import engine as eng, synth
+    probs = synth.random_problems(seed, 40, *shape, 0)
+    e_dev, e_host = eng.Engine(0), eng.Engine(0)
+    e_host.set_device_tree(False)
+    served = compared = 0
+    for p in probs:
+        try:
+            want = eng.traiter(e_host, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, eng.T_DUAL, p.ineq, p.ctx)
+        except eng.SolverError as ex:
+            with pytest.raises(eng.SolverError):
+                eng.traiter(e_dev, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, eng.T_DUAL, p.ineq, p.ctx)
+            continue
+        got = eng.traiter(e_dev, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, eng.T_DUAL, p.ineq, p.ctx)
+        served += e_dev.last_device_tree()[0]
+        assert got == want
+        compared += 1
+    assert compared >= 30 and served >= 0.9 * compared, (compared, served)
