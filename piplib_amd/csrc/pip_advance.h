@@ -718,22 +718,10 @@ __device__ __forceinline__ unsigned umod_tiny(unsigned a, unsigned g, float rg) 
 // every z below 2^31: 24-bit multiplies (full rate, unlike the 64-bit product's three quarter-rate
 // multiplies) and 32-bit registers all the way through the gcd refinement and the division give
 // the same bits as the 64-bit code above.  64-bit entries only.
+// Second half of the small row update: z (ints, |z| < 2^31, `mx` = OR of the lane's |z|) is divided by
+// g = gcd(g0, z_0, ..., z_n) in place; newden = g0 / g.  False where the reference would divide by zero.
 template <int NCH>
-__device__ __forceinline__ bool update_row_small(const RowRegs<i64, NCH> &r, RowRegs32<NCH> &out, const i64 *prow, int pivj,
-                                                 int lp, int foo, int dpiv, i64 g0, int lane, i64 &newden) {
-  int z[NCH][2];
-  unsigned mx = 0;
-#pragma unroll
-  for (int c = 0; c < NCH; c++)
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int j = colof<i64>(c, lane, h);
-      const int p = (int)r.v[c][h], q = (int)prow[j];
-      int v = __mul24(p, lp) - __mul24(q, foo);
-      if (j == pivj) v = __mul24(dpiv, foo);
-      z[c][h] = v;
-      mx |= (unsigned)(v < 0 ? -v : v);
-    }
+__device__ __forceinline__ bool small_reduce(int (&z)[NCH][2], unsigned mx, i64 g0, int lane, i64 &newden) {
   newden = g0;
   bool ok = true;
   if (g0 != 1) {
@@ -841,6 +829,26 @@ __device__ __forceinline__ bool update_row_small(const RowRegs<i64, NCH> &r, Row
       }
     }
   }
+  return ok;
+}
+
+template <int NCH>
+__device__ __forceinline__ bool update_row_small(const RowRegs<i64, NCH> &r, RowRegs32<NCH> &out, const i64 *prow, int pivj,
+                                                 int lp, int foo, int dpiv, i64 g0, int lane, i64 &newden) {
+  int z[NCH][2];
+  unsigned mx = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int j = colof<i64>(c, lane, h);
+      const int p = (int)r.v[c][h], q = (int)prow[j];
+      int v = __mul24(p, lp) - __mul24(q, foo);
+      if (j == pivj) v = __mul24(dpiv, foo);
+      z[c][h] = v;
+      mx |= (unsigned)(v < 0 ? -v : v);
+    }
+  const bool ok = small_reduce<NCH>(z, mx, g0, lane, newden);
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll

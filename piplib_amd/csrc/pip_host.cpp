@@ -43,6 +43,10 @@ extern "C" int pipamd_engine_create(pipamd_engine **out, int device) {
   if (!e) return PIPAMD_E_NOMEM;
   e->device = device;
   e->iter_limit = PIPAMD_DETLOG;
+  {
+    const char *nl = getenv("PIPAMD_NO_LEAN");  // measurement aid, like pipamd_debug_lean(e, 0)
+    e->no_lean = nl && nl[0] == '1';
+  }
   pthread_mutex_init(&e->dt_lock, nullptr);
   *out = e;
   return PIPAMD_OK;
@@ -257,7 +261,7 @@ struct BatchRun {
     return PIPAMD_OK;
   }
 
-  int launch(int waves, int budget, int smax, int grid) {
+  int launch(int waves, int budget, int smax, int grid, bool lean = false) {
     int rcs = next_stage();
     if (rcs) return rcs;
     if (smax > curS) smax = curS;
@@ -277,7 +281,7 @@ struct BatchRun {
     }
     void *big[2] = {&e->d_scratch, &e->scratch_bytes};
     // a uniform batch without parameters whose rows fill a wave's 128 columns exactly: FULL kernels
-    const int hints = (lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 && lay.W == 128) ? 1 : 0;
+    const int hints = ((lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 && lay.W == 128) ? 1 : 0) | (lean ? 2 : 0);
     HIPCHK(pipk_launch_advance_q(jobs, arena, lay.batch, lay.nvar + smax, smax, lay.W, budget, waves, lay.ebits, q5, grid,
                                  big, hints, e->d_prof, st));
     if (!e->no_timing) HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
@@ -337,7 +341,24 @@ struct BatchRun {
     upper = lay.batch;
     if (lay.batch >= (e->bulk_min > 0 ? e->bulk_min : 2048) && e->waves_per_job != 4 && e->waves_per_job != 8) {
       const int budget = e->iter_limit < K1 ? e->iter_limit : K1;
-      rc = launch(1, budget, lay.ni + (KA < budget ? KA : budget), lay.batch);
+      int smax = lay.ni + (KA < budget ? KA : budget);
+      if (smax > curS) smax = curS;
+      // 127 unknowns + constant in 64 bits, rows skipped, plain cuts: the lean kernel (pip_lean.h) goes first -- it
+      // finishes the tableaux whose entries stay below 2^15 and leaves the others to the general kernel's launch
+      const bool lean = !e->no_lean && lay.ebits != 128 && lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 &&
+                        lay.W == 128 && !(lay.tflags & (PIPAMD_T_NOSKIP | PIPAMD_T_DEEPEST)) && pipk_static_class(smax) != 0;
+      if (lean) {
+        rc = launch(1, budget, smax, lay.batch, true);
+        if (rc) return rc;
+        if (e->single_launch == 2) {  // measurement aid: the lean launch on its own
+          HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+          active = true;
+          return PIPAMD_OK;
+        }
+      }
+      // (then the general one-wave kernel over what the lean launch left -- measured with 14 batches in flight: sending
+      // those ~12 % of the tableaux straight to the four-wave tail instead costs 10 % of the throughput)
+      rc = launch(1, budget, smax, lay.batch);
       if (rc) return rc;
       if (e->single_launch) {  // measurement aid: the bulk launch on its own (its tableaux stay PIPAMD_ST_RUN)
         HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -481,7 +502,14 @@ extern "C" int pipamd_debug_grow_step(pipamd_engine *e, int rows) {
 // what that launch alone did.
 extern "C" int pipamd_debug_single_launch(pipamd_engine *e, int on) {
   if (!e) return PIPAMD_E_INVALID;
-  e->single_launch = on ? 1 : 0;
+  e->single_launch = on < 0 ? 0 : (on > 2 ? 1 : on);  // 1: after the bulk launches, 2: after the lean launch alone
+  return PIPAMD_OK;
+}
+
+// Measurement / testing aid: without the lean kernel every tableau of a bulk launch runs in pip_advance_kernel.
+extern "C" int pipamd_debug_lean(pipamd_engine *e, int on) {
+  if (!e) return PIPAMD_E_INVALID;
+  e->no_lean = on ? 0 : 1;
   return PIPAMD_OK;
 }
 

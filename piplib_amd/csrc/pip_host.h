@@ -18,6 +18,7 @@ struct pipamd_engine {
   int round_rows;    /* spare rows (Gomory cuts) in the bulk launch's LDS image (0 = default) */
   int bulk_min;      /* batches of at least this many tableaux start with the one-wave bulk launch (0 = default 2048) */
   int single_launch; /* debug: stop after one launch */
+  int no_lean;       /* 1: bulk launches without the lean kernel (pip_lean.h) */
   int *h_run;        /* pinned: {jobs still running, their largest row count} */
   int *d_q;          /* launch-list control words (a pool, see pipamd_batch_solve) and the two job lists */
   unsigned solve_seq; /* solves since the control pool was last zeroed */
@@ -56,6 +57,7 @@ extern "C" {
 /* bytes of the LDS image a launch over jobs of at most (Lmax, Smax, Wmax) needs; a job only fits
  * the engine if this stays within the 159 KiB a workgroup can get (PIPAMD_LDS_BUDGET) */
 size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax, int ebits);
+int pipk_static_class(int smax);
 hipError_t pipk_launch_advance(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
                                int waves_per_job, int ebits, unsigned long long *prof, hipStream_t stream);
 hipError_t pipk_launch_advance_q(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,

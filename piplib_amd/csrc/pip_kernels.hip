@@ -4,7 +4,7 @@
 // tab_sort_rows of the reference) lives in pip_advance.h and is instantiated by the pip_adv_*.hip files; this file
 // holds the determinant replay, the batch load / results / counters kernels, expanser for the batch layer, the
 // helpers of the lock-step scheduler and every launcher.
-#include "pip_advance.h"
+#include "pip_lean.h"
 
 // the instantiations of the pivot kernel's launcher live in pip_adv_*.hip
 #define PIP_ADV_EXTERN(...) extern template hipError_t launch_advance_t<__VA_ARGS__>(const AdvanceLaunch &);
@@ -13,6 +13,9 @@ PIP_ADV_GROUP_B(PIP_ADV_EXTERN)
 PIP_ADV_GROUP_C(PIP_ADV_EXTERN)
 PIP_ADV_GROUP_D(PIP_ADV_EXTERN)
 #undef PIP_ADV_EXTERN
+#define PIP_LEAN_EXTERN(SC) extern template hipError_t launch_lean<SC>(const AdvanceLaunch &);
+PIP_LEAN_CLASSES(PIP_LEAN_EXTERN)
+#undef PIP_LEAN_EXTERN
 
 // ------------------------------------------------------------- determinant replay
 // traiter.c:394-446 for the pivots a launch logged: d = gcd(pivot, dpiv); the limbs lose the
@@ -548,6 +551,33 @@ static hipError_t launch_static(AdvanceLaunch a, int ebits) {
   a.shm = pipk_advance_lds_bytes(a.Lmax, a.Smax, 128, ebits);
   return a.full ? launch_advance_t<i64, 1, 1, false, SC, true>(a) : launch_advance_t<i64, 1, 1, false, SC, false>(a);
 }
+// Row-capacity class of the one-wave kernels with a compile-time LDS image for a launch of `smax` row slots: the
+// smallest class that holds it if that costs at most an eighth more LDS than its exact size (occupancy is LDS-bound
+// at 24 tableaux per CU); 0 = none.
+extern "C" int pipk_static_class(int smax) {
+  const int s = (smax + 3) & ~3;
+  if (s <= 64) return 64;
+  if (s > 84 && s <= 96) return 96;
+  if (s > 98 && s <= 112) return 112;
+  if (s > 112 && s <= 128) return 128;
+  if (s > 140 && s <= 160) return 160;
+  return 0;
+}
+// the lean bulk kernel (pip_lean.h) over a launch list; the caller has checked pipk_static_class(a.Smax) != 0
+static hipError_t launch_lean_class(AdvanceLaunch a) {
+  const int sc = pipk_static_class(a.Smax);
+  a.Smax = sc;
+  a.Lmax = sc + 128;
+  a.shm = pipk_advance_lds_bytes(a.Lmax, a.Smax, 128, 64);
+  switch (sc) {
+    case 64: return launch_lean<64>(a);
+    case 96: return launch_lean<96>(a);
+    case 112: return launch_lean<112>(a);
+    case 128: return launch_lean<128>(a);
+    case 160: return launch_lean<160>(a);
+  }
+  return hipErrorInvalidValue;
+}
 template <class T, int NCH>
 static hipError_t launch_advance_w(bool one, const AdvanceLaunch &a) {
   if constexpr (sizeof(T) == 8) {
@@ -557,12 +587,13 @@ static hipError_t launch_advance_w(bool one, const AdvanceLaunch &a) {
       // row-capacity classes; a launch goes to the smallest class that holds it if that costs at most
       // an eighth more LDS than its exact size (occupancy is LDS-bound at 24 tableaux per CU)
       if (one && a.Lmax - a.Smax <= 128) {
-        const int s = a.Smax;
-        if (s <= 64) return launch_static<64>(a, 64);
-        if (s > 84 && s <= 96) return launch_static<96>(a, 64);
-        if (s > 98 && s <= 112) return launch_static<112>(a, 64);
-        if (s > 112 && s <= 128) return launch_static<128>(a, 64);
-        if (s > 140 && s <= 160) return launch_static<160>(a, 64);
+        switch (pipk_static_class(a.Smax)) {
+          case 64: return launch_static<64>(a, 64);
+          case 96: return launch_static<96>(a, 64);
+          case 112: return launch_static<112>(a, 64);
+          case 128: return launch_static<128>(a, 64);
+          case 160: return launch_static<160>(a, 64);
+        }
       }
     }
 #endif
@@ -587,7 +618,9 @@ static hipError_t launch_by_shape(const AdvanceLaunch &a, bool one, int wp, int 
 // (re)allocates when the row tables of the launch do not fit LDS (64-bit entries only): the launch
 // then keeps them there, `grid` blocks of the image size.  Without it such a launch is refused.
 // hints: bit 0 = every job of the launch has no parameters, no big parameter and nvar + 1 == W ==
-// the wave's column coverage (the caller knows its batch is uniform): see FULL.
+// the wave's column coverage (the caller knows its batch is uniform): see FULL.  Bit 1 (with bit 0, one wave per job,
+// 64-bit entries and pipk_static_class(Smax) != 0, else refused) = the lean kernel of pip_lean.h: it runs the jobs it
+// can and leaves the others PIPAMD_ST_RUN on the output list for a launch without this bit.
 extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
                                             int iter_limit, int waves_per_job, int ebits, void *const *q5, int grid,
                                             void **big, int hints, unsigned long long *prof, hipStream_t stream) {
@@ -648,7 +681,13 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
   a.stream = stream;
   const bool one = waves_per_job == 1;
   const int wp = wp_of(Wmax, ebits);
-  hipError_t le = launch_by_shape(a, one, wp, ebits);
+  hipError_t le;
+  if (hints & 2) {
+    if (!(hints & 1) || !one || ebits != 64 || wp != 128 || a.gimg || !pipk_static_class(a.Smax)) return hipErrorInvalidValue;
+    le = launch_lean_class(a);
+  } else {
+    le = launch_by_shape(a, one, wp, ebits);
+  }
   if (le != hipSuccess) return le;
   // the determinant bookkeeping of the pivots just logged
   const int nrep = a.grid > 0 && a.grid < njobs ? a.grid : njobs;

@@ -1,0 +1,708 @@
+// piplib_amd/csrc/pip_lean.h -- the lean bulk kernel: pip_advance_kernel's pivot loop specialised for the regime the
+// headline workload lives in.
+//
+// One wave per tableau, 127 unknowns + constant (W == 128), no parameters, no big parameter, 64-bit Entier, compile-time
+// row capacity SC -- and EVERY entry of EVERY row below 2^15 in magnitude (magnitude class 0), the pivot row's
+// denominator too.  Under that invariant every product of a pivot fits 31 bits, so
+//   * rows live in HBM as int32 (512 bytes per row, in the first half of the row's 1 KiB slot): half the traffic of the
+//     reference's long long rows, half the working set;
+//   * a row is two 32-bit registers per lane; the elimination, the row gcd (float-reciprocal remainders), the exact
+//     division, the summaries, choisir_piv's cross products (24-bit multiplies) and the cuts are 32-bit arithmetic;
+//   * none of the general kernel's other paths (64-bit update, wide tournament, parameters, deepest cuts, row tables in
+//     HBM) is compiled in: less code, fewer registers, fewer branches.
+// The invariant is checked between pivots (the running maximum of the magnitude classes and the pivot row's denominator).
+// A tableau that leaves it -- or anything else this kernel does not do -- is written back in the general format (rows
+// widened to int64 in place, the same row tables and saved summaries as a paused job of pip_advance_kernel) and stays
+// PIPAMD_ST_RUN on the launch list: the tail launch of pipamd_batch_solve (pip_advance_kernel, four waves per tableau)
+// takes it from there.  Same algorithm, same statuses, same bits as pip_advance_kernel -- the reference's
+// traiter()/pivoter()/choisir_piv()/exam_coef()/integrer()/tab_sort_rows (traiter.c:101-159, 297-548, 556-623, 628-791;
+// integrer.c:305-486) -- which the parity tests check tableau by tableau.
+#ifndef PIP_LEAN_H
+#define PIP_LEAN_H
+#include "pip_advance.h"
+
+#ifndef PIP_LEAN_WAVES
+#define PIP_LEAN_WAVES 8  // waves per SIMD the kernel is bounded to (64 VGPRs)
+#endif
+
+// a packed row: lane l holds columns 2l, 2l+1 as ints, 8 bytes per lane
+__device__ __forceinline__ void row_load32p(RowRegs32<1> &r, const i64 *slot, int lane) {
+  const int2 t = *reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(slot) + 2 * lane);
+  r.v[0][0] = t.x;
+  r.v[0][1] = t.y;
+}
+__device__ __forceinline__ void row_store32p(const RowRegs32<1> &r, i64 *slot, int lane) {
+  int2 t;
+  t.x = r.v[0][0];
+  t.y = r.v[0][1];
+  *reinterpret_cast<int2 *>(reinterpret_cast<int *>(slot) + 2 * lane) = t;
+}
+
+// rows [0, n) of a block, packed -> the general format, each within its own slot (the loads of a group of rows are back
+// before their slots are overwritten)
+__device__ __forceinline__ void rows_unpack(i64 *vals, int n, int lane) {
+  for (int s0 = 0; s0 < n; s0 += 4) {
+    RowRegs32<1> rr[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++)
+      if (s0 + qq < n) row_load32p(rr[qq], vals + (size_t)(s0 + qq) * 128, lane);
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++)
+      if (s0 + qq < n) {
+        longlong2 t;
+        t.x = (i64)rr[qq].v[0][0];
+        t.y = (i64)rr[qq].v[0][1];
+        *reinterpret_cast<longlong2 *>(vals + (size_t)(s0 + qq) * 128 + 2 * lane) = t;
+      }
+  }
+}
+
+// row_publish32<1> for this kernel's LDS image (constant terms kept as ints): sign summary, non-zero bitmap and
+// magnitude class of a row of 127 unknowns + constant; returns the class (0: every entry below 2^15)
+__device__ __forceinline__ int lean_publish(const RowRegs32<1> &z, const Shared<i64> &S, int *cst, int s, int pivj, int extra_sig,
+                                            int lane) {
+  const int cz = __builtin_amdgcn_readlane(z.v[0][1], 63);  // column 127
+  int sig = extra_sig | (cz > 0 ? 1 : (cz < 0 ? 2 : 0));
+  if (pivj >= 0) {
+    const int pz = row_entry32<1>(z, 0, pivj & 1, pivj >> 1);
+    sig |= (pz > 0 ? 1 : (pz < 0 ? 2 : 0)) << 6;
+  }
+  const int v0 = z.v[0][0], v1 = z.v[0][1];
+  const unsigned mx = (unsigned)(v0 < 0 ? -v0 : v0) | (unsigned)(v1 < 0 ? -v1 : v1);
+  const u64 nz0 = __ballot(v0 != 0), nz1 = __ballot(v1 != 0);
+  const int cls = __ballot((mx >> 15) != 0) ? 1 : 0;
+  if (lane == 0) {
+    S.sig[s] = (u16)sig;
+    S.rcls[s] = (u8)cls;
+    cst[s] = cz;
+    S.nzm[(size_t)s * 2] = nz0;
+    S.nzm[(size_t)s * 2 + 1] = nz1;
+  }
+  return cls;
+}
+
+// bytes of this kernel's LDS image for SC row slots (smaller than pip_advance_kernel's: no pivot row, int constants)
+__host__ __device__ constexpr size_t lean_lds_bytes(int SC) { return ((size_t)39 * SC + 2 * 128 + 2 * 128 + 15) & ~(size_t)15; }
+
+// choisir_piv (traiter.c:297-341) as choose_column<i64, 1, true> does it, on packed rows
+__device__ int choose_column32(const Shared<i64> &S, const RowRegs32<1> &prow, const i64 *vals, int nvar, int nligne,
+                               int pivi, Scalars *sc) {
+  constexpr int NM = 2, W = 128;
+  const int lane = threadIdx.x & 63;
+  int a[2], u[2];
+  bool cand[2];
+  u64 cm[NM];
+  int count = 0;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int j = 2 * lane + h;
+    a[h] = j < nvar ? prow.v[0][h] : 0;
+    cand[h] = a[h] > 0;
+    u[h] = cand[h] ? (int)S.urow[j] : -1;
+    cm[h] = __ballot(cand[h]);
+    count += __popcll(cm[h]);
+  }
+  if (count == 0) return -1;
+  for (int k0 = 0; k0 < nligne && count > 1; k0 += 64) {
+    const int k = k0 + lane;
+    bool rel = false;
+    if (k < nligne && k != pivi) {
+      const int rf = S.ref[k];
+      if (!(rf & UNITBIT)) {
+        const u64 *m = S.nzm + (size_t)rf * NM;
+        rel = ((m[0] & cm[0]) | (m[1] & cm[1])) != 0;
+      }
+    }
+    u64 relmask = __ballot(rel);
+    while (relmask && count > 1) {
+      const int kk = k0 + __ffsll((long long)relmask) - 1;
+      relmask &= relmask - 1;
+      const int sl = S.ref[kk];
+      // unit rows above kk knock out their own column
+      int nel = 0;
+#pragma unroll
+      for (int h = 0; h < 2; h++) nel += __popcll(__ballot(cand[h] && u[h] < kk));
+      if (nel == count) goto last_unit_wins;
+      if (nel) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          if (u[h] < kk) cand[h] = false;
+          cm[h] = __ballot(cand[h]);
+        }
+        count -= nel;
+        if (count == 1) break;
+      }
+      if (!((S.nzm[(size_t)sl * NM] & cm[0]) | (S.nzm[(size_t)sl * NM + 1] & cm[1]))) continue;  // cannot separate them
+      // real row kk: keep the minimal ratios
+      RowRegs32<1> n;
+      row_load32p(n, vals + (size_t)sl * W, lane);
+      for (;;) {
+        // reference column b = first remaining candidate
+        int ab, nb;
+        if (cm[0]) {
+          const int src = __ffsll((long long)cm[0]) - 1;
+          ab = __builtin_amdgcn_readlane(a[0], src);
+          nb = __builtin_amdgcn_readlane(n.v[0][0], src);
+        } else {
+          const int src = __ffsll((long long)cm[1]) - 1;
+          ab = __builtin_amdgcn_readlane(a[1], src);
+          nb = __builtin_amdgcn_readlane(n.v[0][1], src);
+        }
+        bool neg[2];
+        int nneg = 0, nzero = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int x = __mul24(ab, n.v[0][h]) - __mul24(nb, a[h]);
+          neg[h] = cand[h] && x < 0;
+          const bool zero = cand[h] && x == 0;
+          nneg += __popcll(__ballot(neg[h]));
+          nzero += __popcll(__ballot(zero));
+          if (!neg[h] && !zero) cand[h] = false;  // strictly larger: out
+        }
+        if (nneg == 0) {
+          count = nzero;
+        } else {
+          cand[0] = neg[0];
+          cand[1] = neg[1];
+          count = nneg;
+        }
+        cm[0] = __ballot(cand[0]);
+        cm[1] = __ballot(cand[1]);
+        if (nneg == 0 || count == 1) break;
+      }
+    }
+  }
+  if (count == 1) return cm[0] ? 2 * (__ffsll((long long)cm[0]) - 1) : 2 * (__ffsll((long long)cm[1]) - 1) + 1;
+last_unit_wins:
+  // only unit rows left to look at: the column whose unit row comes last survives
+  if (lane == 0) sc->tmp2 = -1;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+    if (cand[h]) atomicMax(&sc->tmp2, (u[h] << 10) | (2 * lane + h));
+  __builtin_amdgcn_wave_barrier();
+  return sc->tmp2 & 1023;
+}
+
+template <int SC>
+__global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jobs, i64 *arena, int njobs, int iter_limit,
+                                                                      PipQueue q) {
+  typedef i64 T;
+  constexpr int Smax = SC, Lmax = SC + 128, WP = 128, NM = 2, W = 128, nvar = 127;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ Scalars sc;
+  const int nq = q.in_count ? *q.in_count : njobs;
+  if ((int)blockIdx.x >= nq) return;
+  const int jb = q.in_list ? q.in_list[blockIdx.x] : (int)blockIdx.x;
+  PipJob *J = &jobs[jb];
+  const int lane = threadIdx.x;
+  if (J->status != PIPAMD_ST_RUN) {
+    if (J->status == PIPAMD_ST_CAPACITY && q.out_count && lane == 0) {
+      q.out_list[atomicAdd(q.out_count, 1)] = jb;
+      atomicMax(q.out_maxni, PIPAMD_Q_CAPFLAG | J->ni);
+    }
+    return;
+  }
+  int tflags = J->tflags;
+  int ni = J->ni;
+  int nligne = nvar + ni;
+  // what this kernel does not do stays with pip_advance_kernel: the job goes on the launch list untouched
+  const bool mine = J->nvar == nvar && J->nparm == 0 && J->bigparm < 0 && J->W == W && J->ebits != 128 &&
+                    !(tflags & (PIPAMD_T_NOSKIP | PIPAMD_T_DEEPEST | PIPAMD_T_STATE)) && ni <= Smax && nligne <= Lmax;
+  if (!mine) {
+    if (lane == 0 && q.out_count) {
+      q.out_list[atomicAdd(q.out_count, 1)] = jb;
+      atomicMax(q.out_maxni, ni);
+    }
+    return;
+  }
+  const int L = J->L, Sl = J->S;
+  T *vals = (T *)(arena + J->vals_off);
+  T *g_den = (T *)(arena + J->rows_off);
+  int *g_flag = (int *)(g_den + L);
+  int *g_ref = g_flag + L;
+  int npiv = J->npiv, ncut = J->ncut, nupd = J->nupd;
+  T *g_log = (T *)(arena + J->log_off);
+  constexpr int LOGCAP = PIPAMD_DETLOG;
+  int nlog = J->nlog;
+  u64 *g_nzm = (u64 *)(arena + J->state_off);
+  u16 *g_sig = (u16 *)(g_nzm + (size_t)Sl * NM);
+  u8 *g_rcls = (u8 *)(g_sig + Sl);
+
+  Shared<T> S;  // the tables of pip_advance_kernel's image this kernel uses
+  int *cst;     // [S] constant terms (ints here); the entry-time sort keys share their storage
+  {
+    unsigned char *p = smem;
+    S.den = (T *)p;      p += sizeof(T) * Smax;
+    S.nzm = (u64 *)p;    p += sizeof(u64) * (size_t)Smax * NM;
+    cst = (int *)p;
+    S.size = (float *)p; p += sizeof(int) * Smax;
+    S.prow = nullptr;
+    S.cst = nullptr;
+    S.sig = (u16 *)p;    p += sizeof(u16) * Smax;
+    S.srow = (u16 *)p;   p += sizeof(u16) * Smax;
+    S.work = (u16 *)p;   p += sizeof(u16) * Smax;
+    S.ref = (u16 *)p;    p += sizeof(u16) * Lmax;
+    S.urow = (u16 *)p;   p += sizeof(u16) * WP;
+    S.fl = (u8 *)p;      p += Smax;
+    S.nf = (u8 *)p;      p += Smax;
+    S.rcls = (u8 *)p;    p += Smax;
+  }
+
+  // ---- the row tables (as pip_advance_kernel stages them)
+  for (int j = lane; j < WP; j += 64) S.urow[j] = NOROW;
+  if (lane == 0) {
+    sc.ovf = 0;
+    sc.aux = 0;
+    sc.smaxbits = 0;
+    sc.pivi = BIG_I;
+    sc.pivi2 = BIG_I;
+    sc.flagor = 0;
+    sc.bad = 0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < nligne; i += 64) {
+    const int f = g_flag[i], rf = g_ref[i];
+    if (f & PIPAMD_F_UNIT) {
+      S.ref[i] = (u16)(UNITBIT | ((f & PIPAMD_F_ZERO) ? UNITZERO : 0) | rf);
+      S.urow[rf] = (u16)i;
+    } else {
+      S.ref[i] = (u16)rf;
+      S.srow[rf] = (u16)i;
+      S.fl[rf] = (u8)f;
+      S.den[rf] = g_den[i];
+      S.nf[rf] = 0;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- one pass over the tableau: the rows become ints (rows of a job loaded with PIPAMD_T_ROWS_STAY come from the
+  // caller's array), summaries, sort keys.  A row with an entry of 2^15 or more ends the lean run before its first pivot.
+  int mcw = 0;  // largest magnitude class published so far: the lean invariant is mcw == 0
+  {
+    constexpr int PF0 = 4;
+    const bool fresh = (tflags & PIPAMD_T_FRESHROWS) != 0;
+    const T *src = fresh ? (const T *)(uintptr_t)J->src_rows : vals;
+    int npacked = 0;
+    bool wide = false;
+    for (int s0 = 0; s0 < ni && !wide; s0 += PF0) {
+      RowRegs<T, 1> rr[PF0];
+#pragma unroll
+      for (int qq = 0; qq < PF0; qq++)
+        if (s0 + qq < ni) row_load<T, 1>(rr[qq], src + (size_t)(s0 + qq) * W, W, lane);
+#pragma unroll
+      for (int qq = 0; qq < PF0; qq++) {
+        const int s = s0 + qq;
+        if (s >= ni || wide) break;
+        const RowRegs<T, 1> &r = rr[qq];
+        const bool fits = r.v[0][0] == (T)(int)r.v[0][0] && r.v[0][1] == (T)(int)r.v[0][1];
+        if (__ballot(!fits)) {
+          wide = true;
+          break;
+        }
+        RowRegs32<1> z;
+        z.v[0][0] = (int)r.v[0][0];
+        z.v[0][1] = (int)r.v[0][1];
+        row_store32p(z, vals + (size_t)s * W, lane);
+        npacked = s + 1;
+        const bool den1 = S.den[s] == 1;
+        mcw = max(mcw, lean_publish(z, S, cst, s, -1, den1 ? SIG_RED : 0, lane));
+        if (tflags & PIPAMD_T_SORT) {
+          // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns (as pip_advance_kernel computes it)
+          int sz = 0;
+          if (den1) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const int q2 = z.v[0][h];
+              const int aq = q2 < 0 ? (int)(0u - (unsigned)q2) : q2;
+              if (2 * lane + h < nvar) sz = sz > aq ? sz : aq;
+            }
+          } else {
+            const double d = to_double(S.den[s]);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const int q2 = trunc_int_x86((double)z.v[0][h] / d);
+              const int aq = q2 < 0 ? (int)(0u - (unsigned)q2) : q2;
+              if (2 * lane + h < nvar) sz = sz > aq ? sz : aq;
+            }
+          }
+          const unsigned szw = wave_minmax_u32<true>((unsigned)sz);
+          if (lane == 0) {
+            S.size[s] = (float)szw;
+            if ((int)S.srow[s] >= nvar) atomicMax(&sc.smaxbits, (u64)szw);
+          }
+        }
+      }
+    }
+    if (wide) {
+      // an entry beyond 32 bits: not a job for this kernel.  Its header is untouched (FRESHROWS and SORT still stand);
+      // rows that came from the block itself and were already rewritten as ints are widened again.
+      if (!fresh) rows_unpack(vals, npacked, lane);
+      if (lane == 0 && q.out_count) {
+        q.out_list[atomicAdd(q.out_count, 1)] = jb;
+        atomicMax(q.out_maxni, ni);
+      }
+      return;
+    }
+  }
+  tflags &= ~PIPAMD_T_FRESHROWS;
+  __builtin_amdgcn_wave_barrier();
+  if (tflags & PIPAMD_T_SORT) {
+    sort_rows(S, nvar, nligne, (double)sc.smaxbits);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < nligne; i += 64)
+      if (!(S.ref[i] & UNITBIT)) S.srow[S.ref[i]] = (u16)i;
+    tflags &= ~PIPAMD_T_SORT;
+    // the sort keys overwrote the constant terms: back from the rows (column 127)
+    __threadfence_block();
+    for (int s = lane; s < ni; s += 64) cst[s] = reinterpret_cast<const int *>(vals + (size_t)s * W)[nvar];
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int s = lane; s < ni; s += 64) {
+    const int ff = S.fl[s];
+    if (ff & PIPAMD_F_MINUS)
+      atomicMin(&sc.pivi, (int)S.srow[s]);
+    else if (ff == PIPAMD_F_UNKNOWN) {
+      const int ec = exam_class(S.sig[s]);
+      S.nf[s] = (u8)ec;
+      if (ec == PIPAMD_F_MINUS) atomicMin(&sc.pivi2, (int)S.srow[s]);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  int status = PIPAMD_ST_RUN;
+  int why = 0;  // why a job left this kernel unfinished (PipJob.pad_, read by tools/lean_split.py): 1 pivot budget,
+                // 2 a row beyond class 0, 3 a cut's denominator, 4 the pivot row's denominator, 5 no room in the LDS image
+  for (int iter = 0;; iter++) {
+    why = 1;
+    if (iter >= iter_limit) break;  // status stays RUN: the next launch resumes the job
+    if (nlog >= LOGCAP) break;
+    why = 2;
+    if (mcw != 0) break;  // a row left magnitude class 0: the general kernel goes on
+    why = 0;
+    int pivi = sc.pivi;
+    if (pivi == BIG_I) {
+      // -------------- exam_coef (its flags were prepared by phase C), then integrer if nothing is negative
+      pivi = sc.pivi2;
+      for (int s = lane; s < ni; s += 64)
+        if (S.fl[s] == PIPAMD_F_UNKNOWN && (int)S.srow[s] <= pivi) S.fl[s] = S.nf[s];
+      __builtin_amdgcn_wave_barrier();
+      if (pivi == BIG_I) {
+        if (!(tflags & PIPAMD_T_INT)) {
+          status = PIPAMD_ST_SOLUTION;
+          break;
+        }
+        // ------------- integrer(): first non-integral row among the unknowns (integrer.c:305-486, constant cuts)
+        if (lane == 0) sc.tmp = BIG_I;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < nvar; i += 64) {
+          const int rf = S.ref[i];
+          if (rf & UNITBIT) continue;
+          const T D = S.den[rf];
+          if (D == 1) continue;
+          if (wneg(fmod64(wneg((T)cst[rf]), D)) != 0) atomicMin(&sc.tmp, i);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int ci = sc.tmp;
+        if (ci == BIG_I) {
+          status = PIPAMD_ST_SOLUTION;
+          break;
+        }
+        const int cslot = S.ref[ci];
+        const T D64 = uni64(S.den[cslot]);
+        why = 3;
+        if (D64 <= 0 || D64 >= ((T)1 << 15)) break;  // the cut's entries would not be of class 0: the general kernel goes on
+        const int D = (int)D64;
+        RowRegs32<1> r;
+        row_load32p(r, vals + (size_t)cslot * W, lane);
+        bool okv = false;
+        const float rD = __builtin_amdgcn_rcpf((float)D);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int j = 2 * lane + h;
+          const int v = r.v[0][h];
+          // piplib_llmod (integrer.c:69-74): the remainder in [0, D); |v| < 2^15 and D < 2^15
+          const unsigned m = umod_tiny((unsigned)(v < 0 ? -v : v), (unsigned)D, rD);
+          const int pos = v < 0 ? (m ? D - (int)m : 0) : (int)m;         // v mod D
+          int x;
+          if (j < nvar) {
+            x = pos;
+            okv |= x > 0;
+          } else {
+            x = pos ? pos - D : 0;  // -((-v) mod D) == (v mod D) - D unless D divides v
+          }
+          r.v[0][h] = x;
+        }
+        const bool any_v = __ballot(okv) != 0;
+        int verdict;
+        if (!any_v)
+          verdict = PIPAMD_ST_NIL;  // integrer.c:482-485 case (b)
+        else if (ni >= Sl || nligne >= L)
+          verdict = PIPAMD_ST_CAPACITY;
+        else if (ni >= Smax || nligne >= Lmax)
+          verdict = -1;  // no room in this launch's LDS image: pause
+        else {
+          verdict = PIPAMD_ST_RUN;
+          row_store32p(r, vals + (size_t)ni * W, lane);
+          mcw = max(mcw, lean_publish(r, S, cst, ni, -1, 0, lane));
+          if (lane == 0) {
+            S.fl[ni] = PIPAMD_F_MINUS;
+            S.nf[ni] = 0;
+            S.den[ni] = D64;
+            S.ref[nligne] = (u16)ni;
+            S.srow[ni] = (u16)nligne;
+          }
+        }
+        if (lane == 0) sc.aux = ci;
+        __builtin_amdgcn_wave_barrier();
+        why = 5;
+        if (verdict != PIPAMD_ST_RUN) {
+          status = verdict < 0 ? PIPAMD_ST_RUN : verdict;
+          break;
+        }
+        pivi = nligne;
+        ni++;
+        nligne++;
+        ncut++;
+        why = 2;
+        if (mcw != 0) break;  // (cannot happen: the cut's entries are below D)
+      }
+    }
+    // ---------------- A: pivot row, choisir_piv, work list
+    const int pslot = S.ref[pivi];
+    const T dpiv = uni64(S.den[pslot]);
+    why = 4;
+    if (dpiv <= -((T)1 << 15) || dpiv >= ((T)1 << 15)) {
+      // the pivot row's denominator is not small: the general kernel does this pivot.  A cut row just appended stays
+      // (it is flagged Minus: the general kernel's chercher finds it).
+      break;
+    }
+    why = 0;
+    npiv++;
+    RowRegs32<1> pr;
+    row_load32p(pr, vals + (size_t)pslot * W, lane);
+    const int psig_v = S.sig[pslot];
+    const int pj = choose_column32(S, pr, vals, nvar, nligne, pivi, &sc);
+    if (pj == -1) {  // traiter.c:782-785
+      status = PIPAMD_ST_NIL;
+      break;
+    }
+    const int pe = pj & 1, pl = pj >> 1;
+    int nwork = 0;
+    for (int s0 = 0; s0 < ni; s0 += 64) {
+      const int s = s0 + lane;
+      bool need = false;
+      if (s < ni) {
+        if (s == pslot)
+          need = true;
+        else {
+          const bool nzb = (S.nzm[(size_t)s * NM + pe] >> pl) & 1;
+          if (nzb || !(S.sig[s] & SIG_RED))
+            need = true;
+          else
+            S.sig[s] &= ~0xC0;  // entry in the pivot column is 0: sign hint "zero"
+        }
+      }
+      const u64 m = __ballot(need);
+      if (need) S.work[nwork + __popcll(m & ((1ull << lane) - 1))] = (u16)s;
+      nwork += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {  // phase C refills them
+      sc.pivi = BIG_I;
+      sc.pivi2 = BIG_I;
+    }
+    const int pivj = pj;
+    const int pivot = __builtin_amdgcn_readlane(pr.v[0][0], pl) * (1 - pe) + __builtin_amdgcn_readlane(pr.v[0][1], pl) * pe;
+    if (lane == 0) {
+      g_log[2 * nlog] = (T)pivot;
+      g_log[2 * nlog + 1] = dpiv;
+    }
+    nlog++;
+    const int ku = S.urow[pivj];  // unit row of the entering column
+    const int pred = psig_v & SIG_RED;
+    // ---------------- B: eliminate the pivot column
+    nupd += nwork - 1;
+    {
+      RowRegs32<1> rr[2];
+      int sw0 = S.work[0], sw1 = S.work[nwork > 1 ? 1 : 0];
+      if (sw0 != pslot) row_load32p(rr[0], vals + (size_t)sw0 * W, lane);
+      if (nwork > 1 && sw1 != pslot) row_load32p(rr[1], vals + (size_t)sw1 * W, lane);
+      for (int w0 = 0; w0 < nwork; w0 += 2) {
+        if (w0) {
+          sw0 = S.work[w0];
+          sw1 = S.work[w0 + 1 < nwork ? w0 + 1 : w0];
+          if (sw0 != pslot) row_load32p(rr[0], vals + (size_t)sw0 * W, lane);
+          if (w0 + 1 < nwork && sw1 != pslot) row_load32p(rr[1], vals + (size_t)sw1 * W, lane);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 2; qq++) {
+          if (w0 + qq >= nwork) break;
+          const int s = qq ? sw1 : sw0;
+          RowRegs32<1> &r = rr[qq];
+          T *row = vals + (size_t)s * W;
+          if (s == pslot) {
+            // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
+#pragma unroll
+            for (int h = 0; h < 2; h++) r.v[0][h] = (2 * lane + h == pivj) ? (int)dpiv : -pr.v[0][h];
+            row_store32p(r, row, lane);
+            mcw = max(mcw, lean_publish(r, S, cst, s, pivj, pred, lane));
+            continue;
+          }
+          // multipliers from the row's own pivot-column entry (traiter.c:470-476); everything below 2^15
+          int foo = __builtin_amdgcn_readlane(r.v[0][0], pl) * (1 - pe) + __builtin_amdgcn_readlane(r.v[0][1], pl) * pe;
+          const T den_s = uni64(S.den[s]);
+          int lp = pivot;
+          T g0 = den_s;
+          if (pivot != 1) {
+            const unsigned d = gcd_u32((unsigned)pivot, (unsigned)(foo < 0 ? -foo : foo));
+            if (d != 1) {  // (d == 0 cannot be: pivot > 0)
+              lp = (int)exact_quo<i64>((i64)pivot, (i64)d);
+              foo = (int)exact_quo<i64>((i64)foo, (i64)d);
+            }
+            g0 = wmul((T)lp, den_s);
+          }
+          int z[1][2];
+          unsigned mx = 0;
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            int v = __mul24(r.v[0][h], lp) - __mul24(pr.v[0][h], foo);
+            if (2 * lane + h == pivj) v = __mul24((int)dpiv, foo);
+            z[0][h] = v;
+            mx |= (unsigned)(v < 0 ? -v : v);
+          }
+          T nd;
+          if (!small_reduce<1>(z, mx, g0, lane, nd)) {
+            if (lane == 0) sc.bad = 1;
+          }
+          r.v[0][0] = z[0][0];
+          r.v[0][1] = z[0][1];
+          row_store32p(r, row, lane);
+          mcw = max(mcw, lean_publish(r, S, cst, s, pivj, SIG_RED, lane));
+          if (lane == 0) S.den[s] = nd;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (sc.bad) {
+      status = PIPAMD_ST_OVERFLOW;
+      break;
+    }
+    // ---------------- C: swap roles, refresh the sign hints, next chercher (traiter.c:503-529)
+    if (lane == 0) {
+      S.ref[pivi] = (u16)(UNITBIT | UNITZERO | pivj);
+      S.urow[pivj] = (u16)pivi;
+    }
+    for (int s = lane; s < ni; s += 64) {
+      int ff, k;
+      if (s == pslot) {
+        k = ku;
+        ff = PIPAMD_F_PLUS;
+        S.den[s] = (T)pivot;
+        S.srow[s] = (u16)ku;
+        S.ref[ku] = (u16)s;
+      } else {
+        k = S.srow[s];
+        ff = S.fl[s];
+      }
+      const int sg = S.sig[s];
+      const int ps = SIG_PIV(sg);
+      const int fff = ps == 1 ? PIPAMD_F_PLUS : (ps == 2 ? PIPAMD_F_MINUS : PIPAMD_F_ZERO);
+      if (fff != PIPAMD_F_ZERO && fff != ff) {
+        if (ff == PIPAMD_F_ZERO)
+          ff = (fff == PIPAMD_F_MINUS) ? PIPAMD_F_UNKNOWN : fff;
+        else
+          ff = PIPAMD_F_UNKNOWN;
+      }
+      S.fl[s] = (u8)ff;
+      if (ff & PIPAMD_F_MINUS)
+        atomicMin(&sc.pivi, k);
+      else if (ff == PIPAMD_F_UNKNOWN) {
+        const int ec = exam_class(sg);
+        S.nf[s] = (u8)ec;
+        if (ec == PIPAMD_F_MINUS) atomicMin(&sc.pivi2, k);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- epilogue: the row tables, the header and (if any) the solution, as pip_advance_kernel writes them
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < nligne; i += 64) {
+    const int rf = S.ref[i];
+    if (rf & UNITBIT) {
+      g_den[i] = 1;
+      g_flag[i] = PIPAMD_F_UNIT | ((rf & UNITZERO) ? PIPAMD_F_ZERO : 0);
+      g_ref[i] = UNITCOL(rf);
+    } else {
+      g_den[i] = S.den[rf];
+      g_flag[i] = S.fl[rf];
+      g_ref[i] = rf;
+    }
+  }
+  tflags &= ~PIPAMD_T_STATE;
+  if (status == PIPAMD_ST_RUN) {
+    for (int s = lane; s < ni; s += 64) {
+      g_sig[s] = S.sig[s];
+      g_rcls[s] = S.rcls[s];
+    }
+    for (int e = lane; e < ni * NM; e += 64) g_nzm[e] = S.nzm[e];
+    tflags |= PIPAMD_T_STATE;
+  }
+  if (status == PIPAMD_ST_SOLUTION) {
+    // solution(), traiter.c:255-271: the constant column of rows 0..nvar-1
+    T *sol_num = (T *)(arena + J->sol_off);
+    T *sol_den = sol_num + nvar;
+    for (int i = lane; i < nvar; i += 64) {
+      const int rf = S.ref[i];
+      T v = 0, d = 1;
+      if (!(rf & UNITBIT)) {
+        v = (T)reinterpret_cast<const int *>(vals + (size_t)rf * W)[nvar];
+        d = S.den[rf];
+      }
+      sol_num[i] = v;
+      sol_den[i] = d;
+    }
+  }
+  if (status == PIPAMD_ST_RUN || status == PIPAMD_ST_CAPACITY) {
+    // the job goes on elsewhere (pip_advance_kernel, pip_rehouse_kernel): its rows in the general format again
+    rows_unpack(vals, ni, lane);
+  }
+  int mc = 0;
+  for (int s = lane; s < ni; s += 64)
+    if (S.rcls[s] > mc) mc = S.rcls[s];
+  mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
+  if (lane == 0) {
+    J->ni = ni;
+    J->npiv = npiv;
+    J->ncut = ncut;
+    J->nupd = nupd;
+    J->nlog = nlog;
+    J->pad_ = why;
+    J->tflags = tflags;
+    J->state_nch = 1;
+    J->maxabs = (u64)mc;
+    J->aux = sc.aux;
+    J->status = status;
+    if (status == PIPAMD_ST_RUN && q.out_count) {
+      q.out_list[atomicAdd(q.out_count, 1)] = jb;
+      atomicMax(q.out_maxni, ni);
+    }
+    if (status == PIPAMD_ST_CAPACITY && q.out_count) {
+      q.out_list[atomicAdd(q.out_count, 1)] = jb;
+      atomicMax(q.out_maxni, PIPAMD_Q_CAPFLAG | ni);
+    }
+  }
+}
+
+template <int SC>
+hipError_t launch_lean(const AdvanceLaunch &a) {
+  const int grid = a.grid > 0 && a.grid < a.njobs ? a.grid : a.njobs;
+  const size_t shm = lean_lds_bytes(SC);
+  hipLaunchKernelGGL((pip_lean_kernel<SC>), dim3(grid), dim3(64), shm, a.stream, a.jobs, a.arena, a.njobs, a.iter_limit, a.q);
+  return hipGetLastError();
+}
+// the row-capacity classes of launch_static (pip_kernels.hip)
+#define PIP_LEAN_CLASSES(X) X(64) X(96) X(112) X(128) X(160)
+#define PIP_LEAN_DEFINE(SC) template hipError_t launch_lean<SC>(const AdvanceLaunch &);
+#endif  // PIP_LEAN_H

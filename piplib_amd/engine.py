@@ -131,9 +131,15 @@ class Engine:
         return float(ms.value)
 
     def debug_single_launch(self, on):
-        """measurement aid: the next solves stop after their first launch (the bulk launch of a large batch)"""
+        """measurement aid: the next solves stop after their bulk launches (True / 1: the one-wave launches of a large
+        batch; 2: after the lean launch alone, when the batch has one) -- unfinished tableaux stay PIPAMD_ST_RUN"""
         lib().pipamd_debug_single_launch.argtypes = [C.c_void_p, C.c_int]
-        _check(lib().pipamd_debug_single_launch(self._h, int(bool(on))))
+        _check(lib().pipamd_debug_single_launch(self._h, int(on)))
+
+    def debug_lean(self, on):
+        """measurement / testing aid: bulk launches with (default) or without the lean kernel (csrc/pip_lean.h)"""
+        lib().pipamd_debug_lean.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().pipamd_debug_lean(self._h, int(bool(on))))
 
     def last_solve_launches(self):
         return int(lib().pipamd_last_solve_launches(self._h))

@@ -623,3 +623,83 @@ def test_rows_fetched_by_the_pivot_kernel(nvar, ni, nq, waves):
         assert r.status != pb.ST_ABORT and pv[k] == r.pivots
         got = "()" if st[k] == eng.ST_NIL else pb.squash(solution_text(num[k], den[k]))
         assert got == pb.squash(r.text), k
+
+
+@pytest.mark.parametrize("name,ni,nq,kw,cap,stay", [
+    ("headline", 64, 1, dict(), None, True),           # most tableaux finish in the lean kernel; some leave it mid-run
+    ("headline-copied-rows", 64, 1, dict(), None, False),  # rows already in the job blocks: packed in place
+    ("rational", 64, 0, dict(), None, True),
+    ("class-1-at-entry", 64, 1, dict(scale=40000), None, True),   # entries of 2^15 and more: left before the first pivot
+    ("beyond-32-bits", 40, 1, dict(scale=1 << 33), None, False),  # rows that cannot be packed (widened again in place)
+    ("beyond-32-bits-fetched", 64, 1, dict(scale=1 << 33), None, True),
+    ("overflow", 64, 1, dict(cmax=40000, x0max=3), None, True),   # "Integer overflow" (traiter.c:424,442) on every tableau
+    ("class-160", 100, 1, dict(), None, True),         # the largest row-capacity class
+    ("no-class", 113, 1, dict(), None, True),          # 161 row slots: no static class, the general kernel does it all
+    ("spare-rows-spent", 64, 1, dict(), 6, True),      # PIPAMD_ST_CAPACITY inside the lean kernel, then expanser
+])
+def test_lean_kernel_paths(name, ni, nq, kw, cap, stay):
+    """The lean bulk kernel (csrc/pip_lean.h: 127 unknowns, int rows, entries below 2^15) and every way a tableau
+    leaves it -- finished, pivot budget, a row or a denominator beyond class 0, no spare row, rows it cannot pack --
+    against the same batch without it (pipamd_debug_lean: statuses, pivot and cut counts, solutions identical) and
+    against the oracle."""
+    import torch
+    from gpu_common import oracle_batch, solution_text
+    import pipbatch as pb
+    from piplib_amd import engine as eng, synth
+    nvar, batch = 127, 160
+    kw = dict(kw)
+    scale = kw.pop("scale", 0)
+    # (seeds on which Gomory's cuts converge: 4121 holds a tableau the reference itself does not finish within minutes)
+    rows = synth.lexmin_batch({"no-class": 4112}.get(name, 4000 + ni + len(name)), batch, nvar, ni, **kw)
+    if scale:  # every other tableau: one inequality multiplied through (same polyhedron, large entries)
+        rows[::2, ni // 2, :] *= scale
+    outs, launches = [], []
+    for lean in (0, 1):
+        e = eng.Engine(0)
+        e.set_bulk_min(64)
+        e.set_max_rows(ni + 1024)
+        e.debug_lean(lean)
+        b = eng.Batch(e, rows, nvar, 0, tflags=(eng.T_INT if nq else 0) | (eng.T_ROWS_STAY if stay else 0), cap_cuts=cap)
+        for _ in range(2):  # the second load + solve reuses the workspace
+            b.load()
+            b.solve()
+        launches.append(e.last_solve_launches())
+        b.fetch()
+        torch.cuda.synchronize()
+        outs.append((b.status.cpu().numpy(), b.pivots.cpu().numpy(), b.cuts.cpu().numpy(), b.sol_num.cpu().numpy(),
+                     b.sol_den.cpu().numpy()))
+    if name != "no-class":
+        assert launches[1] > launches[0] or cap, launches  # the lean launch went out (one more launch than without)
+        # the lean launch on its own: how its tableaux ended (PipJob of csrc/pip_job.h, 200 bytes: status at byte 72,
+        # pivots at 80, the lean kernel's exit reason at 172 -- 1 pivot budget, 2 a row beyond class 0)
+        e.debug_single_launch(2)
+        b.load()
+        b.solve()
+        e.debug_single_launch(0)
+        j = b.ws[:25 * batch].view(torch.int32).view(batch, 50).cpu().numpy()
+        status, npiv, why = j[:, 18], j[:, 20], j[:, 43]
+        running = status == eng.ST_RUN
+        if name == "class-160":   # long tableaux: most spend the launch's pivot budget
+            assert (npiv > 0).all() and (running & (why == 1)).any()
+        if name in ("headline", "headline-copied-rows", "rational"):
+            assert (~running).sum() > batch // 2 and (running & (why == 2) & (npiv > 0)).any(), (running.sum(), why[running])
+        if name == "class-1-at-entry":   # the scaled tableaux leave before their first pivot, the others run
+            assert (running[::2] & (why[::2] == 2) & (npiv[::2] == 0)).all() and (npiv[1::2] > 0).all()
+        if name.startswith("beyond-32-bits"):   # not taken: header untouched
+            assert (running[::2] & (npiv[::2] == 0)).all() and (npiv[1::2] > 0).all()
+        if name == "spare-rows-spent":
+            assert (status == eng.ST_CAPACITY).any()
+    else:
+        assert launches[1] == launches[0], launches
+    for x, y in zip(*outs):
+        assert (x == y).all()
+    st, pv, _, num, den = outs[1]
+    o = oracle_batch(rows, nvar, 0, nq).results
+    for k, r in enumerate(o):
+        if r.status == pb.ST_ABORT:
+            assert st[k] == {2: eng.ST_OVERFLOW, 4: eng.ST_MAXCOL}.get(r.abort_code, eng.ST_OVERFLOW), (k, st[k], r.abort_code)
+            continue
+        assert st[k] in (eng.ST_SOLUTION, eng.ST_NIL), (k, st[k])
+        assert pv[k] == r.pivots, (k, pv[k], r.pivots)
+        got = "()" if st[k] == eng.ST_NIL else pb.squash(solution_text(num[k], den[k]))
+        assert got == pb.squash(r.text), k
