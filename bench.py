@@ -242,6 +242,8 @@ class Lanes:
                                                     and shape[0] >= 2048 else 0)
             if tw:
                 e.set_tail_waves(tw)
+            if depth == 1 and getattr(args, "lone", -1) != 0:
+                e.set_lone_batches(True)
             # safety net: a tableau that escaped the screening ends PIPAMD_ST_CAPACITY (and voids the line) instead of
             # growing for minutes
             e.set_max_rows(cfg.get("max_rows") or cfg["ni"] + 1024)
@@ -393,32 +395,41 @@ def timed_regions(lanes, steps, warmup, barrier, stagger_arg, n=3):
     return sorted(out, key=lambda r: r[0])
 
 
-def roofline_of(b, e, k_ms, cfg, extra=None):
-    """Algorithmic HBM bytes of the pivots of one step of THIS algorithm: read
-    the pivot row, write the row that replaces the entering unit row, read+write every row that
-    actually changes (counted by the kernel) -- rows with a zero multiplier keep their bits --
-    over the kernel's own launch durations (HIP events on its stream, un-pipelined)."""
+def roofline_of(b, e, k_ms, cfg, extra=None, split=None):
+    """Algorithmic HBM bytes of the pivots of THIS algorithm: read the pivot row, write the row
+    that replaces the entering unit row, read+write every row that actually changes (counted by the kernel) -- rows
+    with a zero multiplier keep their bits -- at the reference's 8 bytes per entry, over the launch durations (HIP
+    events on the kernel's stream, un-pipelined).  With `split` (launch_split) the object is about the dominant
+    kernel -- the launch that does most of the step's pivots -- and `step` holds the same figures for all pivot
+    launches of the step together; without it the object is about the whole step."""
     c = b.counters()
     eb = 16.0 if cfg["ebits"] == 128 else 8.0
     ncol = cfg["nvar"] + 1
     algo = eb * ncol * (2.0 * c["rows_rewritten"] + 2.0 * c["pivots"])
     ach = algo / (k_ms * 1e-3) / 1e9
-    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-         "traffic": None, "kernel": "pip_advance_kernel", "kernel_ms": k_ms,
-         "launches_per_step": e.last_solve_launches(),
-         "avg_launch_ms": k_ms / max(1, e.last_solve_launches()),
-         "algorithmic_bytes_per_step": algo,
-         "rows_rewritten_per_pivot": c["rows_rewritten"] / max(1, c["pivots"])}
+    step = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "kernel_ms": k_ms, "launches_per_step": e.last_solve_launches(),
+            "avg_launch_ms": k_ms / max(1, e.last_solve_launches()), "algorithmic_bytes_per_step": algo,
+            "rows_rewritten_per_pivot": c["rows_rewritten"] / max(1, c["pivots"])}
+    dom = max(split, key=lambda l: l["pivots"]) if isinstance(split, list) and split else None
+    if dom:
+        r = {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": None,
+             "kernel": dom["launch"], "kernel_ms": dom["ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
+             "pivots_per_launch": dom["pivots"], "share_of_the_steps_pivots": dom["pivots"] / max(1, c["pivots"]),
+             "rows_rewritten_per_pivot": dom["rows_rewritten_per_pivot"], "step": step}
+    else:
+        r = dict({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel": "pip_advance_kernel"}, **step)
     if extra:
         r.update(extra)
     return r
 
 
 def launch_split(b, e, cfg, parts):
-    """Roofline per launch of one un-pipelined solve: the one-wave bulk launch and the four-wave tail launch(es) do
-    very different work per pivot (a late pivot of a long tableau rewrites 15-25 rows, an early one 1-3).  Durations:
-    HIP events around each launch; pivots and rows of the bulk launch: the batch solved once more with the solve
-    stopped after its first launch (pipamd_debug_single_launch), the tail's = the whole solve's minus those."""
+    """Roofline per launch of one un-pipelined solve.  The launches do very different work per pivot: the lean bulk
+    launch (csrc/pip_lean.h, one wave per tableau, int rows: the headline shape only) takes every tableau as far as
+    its entries stay below 2^15, the general one-wave launch the ones it left, the four-wave tail launches the long
+    tableaux (a late pivot of a long tableau rewrites 15-25 rows, an early one 1-3).  Durations: HIP events around each
+    launch; pivots and rows per launch: the batch solved again with the solve stopped after the lean launch and after
+    the bulk launches (pipamd_debug_single_launch), the tail's = the whole solve's minus those."""
     e.set_timing(True)
     b.load_parts(parts)
     b.solve()
@@ -427,23 +438,35 @@ def launch_split(b, e, cfg, parts):
     whole = b.counters()
     if n < 2:
         return None
-    e.debug_single_launch(True)
-    try:
-        b.load_parts(parts)
-        b.solve()
-        first = b.counters()
-    finally:
-        e.debug_single_launch(False)
+
+    def stopped(level):
+        e.debug_single_launch(level)
+        try:
+            b.load_parts(parts)
+            b.solve()
+            return b.counters(), e.last_solve_launches()
+        finally:
+            e.debug_single_launch(0)
+    bulk, nb = stopped(1)     # after the one-wave launches (lean + general, or the general one alone)
+    lean, nl = stopped(2)     # after the lean launch alone (the same as `bulk` when the batch has no lean launch)
     b.load_parts(parts)   # leave the batch solved
     b.solve()
     eb = 16.0 if cfg["ebits"] == 128 else 8.0
     ncol = cfg["nvar"] + 1
+    legs = []
+    if nb == 2:
+        legs.append(("lean bulk (pip_lean_kernel, one wave per tableau, int rows)", ms[0], lean["pivots"], lean["rows_rewritten"],
+                     lean["finished"]))
+        legs.append(("general bulk (pip_advance_kernel, one wave per tableau) over what the lean launch left", ms[1],
+                     bulk["pivots"] - lean["pivots"], bulk["rows_rewritten"] - lean["rows_rewritten"], bulk["finished"] - lean["finished"]))
+    else:
+        legs.append(("bulk (pip_advance_kernel, one wave per tableau)", ms[0], bulk["pivots"], bulk["rows_rewritten"], bulk["finished"]))
+    legs.append(("tail (pip_advance_kernel, four waves per tableau, %d launch%s)" % (n - nb, "" if n - nb == 1 else "es"), sum(ms[nb:]),
+                 whole["pivots"] - bulk["pivots"], whole["rows_rewritten"] - bulk["rows_rewritten"], whole["finished"] - bulk["finished"]))
     out = []
-    for kind, t, piv, rows in (("bulk (one wave per tableau)", ms[0], first["pivots"], first["rows_rewritten"]),
-                               ("tail (four waves per tableau, %d launch%s)" % (n - 1, "" if n == 2 else "es"), sum(ms[1:]),
-                                whole["pivots"] - first["pivots"], whole["rows_rewritten"] - first["rows_rewritten"])):
+    for kind, t, piv, rows, fin in legs:
         by = eb * ncol * (2.0 * rows + 2.0 * piv)
-        out.append({"launch": kind, "ms": t, "pivots": piv, "rows_rewritten_per_pivot": rows / max(1, piv),
+        out.append({"launch": kind, "ms": t, "pivots": piv, "tableaux_finished": fin, "rows_rewritten_per_pivot": rows / max(1, piv),
                     "algorithmic_bytes": by, "achieved": by / (t * 1e-3) / 1e9, "frac": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS})
     return out
 
@@ -490,7 +513,7 @@ def main():
                     help="strong (default for --gpus > 1, BASELINE configs[3]): every --batch-tableau batch is sharded "
                          "over the ranks; weak (default for one GPU): --batch tableaux per GPU and batch.  The other "
                          "mode is measured too and reported as `other_scaling`.")
-    ap.add_argument("--pipeline", type=int, default=14, help="batches in flight (streams)")
+    ap.add_argument("--pipeline", type=int, default=16, help="batches in flight (streams)")
     ap.add_argument("--threads", action="store_true",
                     help="one host thread per lane calling the synchronous pipamd_batch_solve (round 2's driver) instead of "
                          "one thread over pipamd_batch_solve_async / pipamd_batch_wait")
@@ -500,6 +523,9 @@ def main():
     ap.add_argument("--stagger", type=float, default=0.0, help="(ignored; kept for old command lines)")
     ap.add_argument("--blocking-wait", type=int, default=-1,
                     help="1: host threads sleep while the device works, 0: they poll; -1: sleep when there are more lanes than CPUs")
+    ap.add_argument("--lone", type=int, default=-1,
+                    help="0: a lone batch (--pipeline 1) keeps the launch sequence of the pipelined run (profiles); "
+                         "-1: it runs with pipamd_engine_set_lone_batches")
     ap.add_argument("--copy-rows", action="store_true", help="load copies the input rows into the job blocks (no PIPAMD_T_ROWS_STAY)")
     ap.add_argument("--no-dense", action="store_true", help="skip the row-skipping-off measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -669,7 +695,7 @@ def main():
             split = launch_split(b, e, cfg, parts0)
         except Exception as ex:
             split = {"error": repr(ex)}
-    out["roofline"] = roofline_of(b, e, k_ms, cfg, {
+    out["roofline"] = roofline_of(b, e, k_ms, cfg, split=split, extra={
         "traffic": traffic,
         "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command with --pipeline 1; "
                            "read from the file, not measured in this run)") if traffic_src else None,

@@ -97,6 +97,9 @@ __device__ unsigned long long *pf_buf;
 
 // ---------------------------------------------------------------- integer ops
 // piplib.h:128-169 + integrer.c:43-74 on wrap-around 64-bit integers.
+// the wave's ballot as the compare instruction itself (hip's __ballot first materialises the predicate as 0 / 1 in a
+// vector register and compares that: two more VALU instructions per ballot)
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ u64 uabs64(i64 x) { return x < 0 ? 0ull - (u64)x : (u64)x; }
 __device__ __forceinline__ i64 wmul(i64 a, i64 b) { return (i64)((u64)a * (u64)b); }
 __device__ __forceinline__ i64 wsub(i64 a, i64 b) { return (i64)((u64)a - (u64)b); }
@@ -414,8 +417,8 @@ __device__ __forceinline__ int cls_bits(int c) {
 template <class T>
 __device__ __forceinline__ int cls_of(typename ET<T>::U orall) {  // wave-collective: class of the OR of all lanes
   constexpr int B4 = ET<T>::BITS / 4;
-  return __ballot((orall >> (3 * B4 - 1)) != 0) ? 3
-         : (__ballot((orall >> (2 * B4 - 1)) != 0) ? 2 : (__ballot((orall >> (B4 - 1)) != 0) ? 1 : 0));
+  return ballot64((orall >> (3 * B4 - 1)) != 0) ? 3
+         : (ballot64((orall >> (2 * B4 - 1)) != 0) ? 2 : (ballot64((orall >> (B4 - 1)) != 0) ? 1 : 0));
 }
 
 // LDS image of one job.  L = logical rows, S = row slots (real rows), WP = NCH*128 columns,
@@ -538,12 +541,12 @@ __device__ __forceinline__ void row_publish(const RowRegs<T, NCH> &r, const Shar
           pneg |= z < 0;
         }
       }
-      nz[ET<T>::CPL * c + h] = __ballot(z != 0);
+      nz[ET<T>::CPL * c + h] = ballot64(z != 0);
     }
   int sig = extra_sig | cs | (ps << 6);
   if (has_parm) {
-    sig |= (__ballot(ppos) ? 4 : 0) | (__ballot(pneg) ? 8 : 0);
-    sig |= (__ballot(bs == 1) ? 16 : 0) | (__ballot(bs == 2) ? 32 : 0);
+    sig |= (ballot64(ppos) ? 4 : 0) | (ballot64(pneg) ? 8 : 0);
+    sig |= (ballot64(bs == 1) ? 16 : 0) | (ballot64(bs == 2) ? 32 : 0);
   }
   const int cls = cls_of<T>(mx);
   if (lane == 0) {
@@ -602,9 +605,9 @@ __device__ __forceinline__ int row_publish32(const RowRegs32<NCH> &z, const Shar
     for (int h = 0; h < 2; h++) {
       const int v = z.v[c][h];
       mx |= (unsigned)(v < 0 ? -v : v);
-      nz[2 * c + h] = __ballot(v != 0);
+      nz[2 * c + h] = ballot64(v != 0);
     }
-  const int cls = __ballot((mx >> 15) != 0) ? 1 : 0;
+  const int cls = ballot64((mx >> 15) != 0) ? 1 : 0;
   if (lane == 0) {
     S.sig[s] = (u16)sig;
     S.rcls[s] = (u8)cls;
@@ -645,7 +648,7 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
   U g = (U)uni64((T)uabs64(g0));
   // 32-bit remainders when everything fits (the common case): one v_rcp-based
   // division instead of the 64-bit software routine
-  const bool small = (__ballot((mx >> 32) != 0) == 0) && (g >> 32) == 0;
+  const bool small = (ballot64((mx >> 32) != 0) == 0) && (g >> 32) == 0;
   for (;;) {
     U rr = 0;
 #pragma unroll
@@ -658,7 +661,7 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
       }
     CNT(13, 1);
     CNT(14, small ? 0 : 1);
-    u64 nz = __ballot(rr != 0);
+    u64 nz = ballot64(rr != 0);
     if (!nz) break;
     int src = __ffsll((long long)nz) - 1;
     U r0 = (U)readlane64((T)rr, src);
@@ -730,7 +733,7 @@ __device__ __forceinline__ bool small_reduce(int (&z)[NCH][2], unsigned mx, i64 
       unsigned g = (unsigned)g64;
       // every |z| and g below 2^20 (the rule on this path): remainders through a float reciprocal of the wave-uniform
       // g -- five full-rate instructions and two corrections per entry instead of the 32-bit division sequence
-      const bool tiny = g != 0 && g < (1u << 20) && __ballot((mx >> 20) != 0) == 0;
+      const bool tiny = g != 0 && g < (1u << 20) && ballot64((mx >> 20) != 0) == 0;
       for (;;) {
         unsigned rr = 0;
         if (tiny) {
@@ -752,7 +755,7 @@ __device__ __forceinline__ bool small_reduce(int (&z)[NCH][2], unsigned mx, i64 
               rr = rr ? rr : m;
             }
         }
-        const u64 nz = __ballot(rr != 0);
+        const u64 nz = ballot64(rr != 0);
         if (!nz) break;
         const unsigned r0 = __builtin_amdgcn_readlane(rr, __ffsll((long long)nz) - 1);
         g = gcd_u32(g, r0);
@@ -778,7 +781,7 @@ __device__ __forceinline__ bool small_reduce(int (&z)[NCH][2], unsigned mx, i64 
         const unsigned qd = ((unsigned)uabs64(g0) >> sh) * inv;
         newden = g0 < 0 ? wneg((i64)qd) : (i64)qd;
       }
-    } else if (__ballot(mx != 0) == 0) {
+    } else if (ballot64(mx != 0) == 0) {
       // a zero row under a denominator beyond 32 bits: gcd(g0, 0, ..., 0) = |g0|
       newden = g0 < 0 ? -1 : 1;
     } else {
@@ -793,7 +796,7 @@ __device__ __forceinline__ bool small_reduce(int (&z)[NCH][2], unsigned mx, i64 
           const unsigned a = (unsigned)(z[c][h] < 0 ? -z[c][h] : z[c][h]);
           first = first ? first : a;
         }
-      unsigned g = __builtin_amdgcn_readlane(first, __ffsll((long long)__ballot(first != 0)) - 1);
+      unsigned g = __builtin_amdgcn_readlane(first, __ffsll((long long)ballot64(first != 0)) - 1);
       while (g != 1) {
         unsigned rr = 0;
 #pragma unroll
@@ -804,7 +807,7 @@ __device__ __forceinline__ bool small_reduce(int (&z)[NCH][2], unsigned mx, i64 
             const unsigned m = a % g;
             rr = rr ? rr : m;
           }
-        const u64 nz = __ballot(rr != 0);
+        const u64 nz = ballot64(rr != 0);
         if (!nz) break;
         g = gcd_u32(g, __builtin_amdgcn_readlane(rr, __ffsll((long long)nz) - 1));
       }
@@ -963,7 +966,7 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
       a[c][h] = j < nvar ? (A)prow.v[c][h] : (A)0;
       cand[c][h] = a[c][h] > 0;
       u[c][h] = cand[c][h] ? (int)S.urow[j] : -1;
-      cm[ET<T>::CPL * c + h] = __ballot(cand[c][h]);
+      cm[ET<T>::CPL * c + h] = ballot64(cand[c][h]);
       count += __popcll(cm[ET<T>::CPL * c + h]);
     }
   if (count == 0) return -1;
@@ -982,7 +985,7 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
         rel = x != 0;
       }
     }
-    u64 relmask = __ballot(rel);
+    u64 relmask = ballot64(rel);
     while (relmask && count > 1) {
       const int kk = k0 + __ffsll((long long)relmask) - 1;
       relmask &= relmask - 1;
@@ -993,7 +996,7 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
 #pragma unroll
       for (int c = 0; c < NCH; c++)
 #pragma unroll
-        for (int h = 0; h < ET<T>::CPL; h++) nel += __popcll(__ballot(cand[c][h] && u[c][h] < kk));
+        for (int h = 0; h < ET<T>::CPL; h++) nel += __popcll(ballot64(cand[c][h] && u[c][h] < kk));
       if (nel == count) goto last_unit_wins;
       if (nel) {
 #pragma unroll
@@ -1001,7 +1004,7 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
 #pragma unroll
           for (int h = 0; h < ET<T>::CPL; h++) {
             if (u[c][h] < kk) cand[c][h] = false;
-            cm[ET<T>::CPL * c + h] = __ballot(cand[c][h]);
+            cm[ET<T>::CPL * c + h] = ballot64(cand[c][h]);
           }
         count -= nel;
         if (count == 1) break;
@@ -1051,8 +1054,8 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
               x = wsub(wmul(ab, n.v[c][h]), wmul(nb, a[c][h]));
             neg[c][h] = cand[c][h] && x < 0;
             bool zero = cand[c][h] && x == 0;
-            nneg += __popcll(__ballot(neg[c][h]));
-            nzero += __popcll(__ballot(zero));
+            nneg += __popcll(ballot64(neg[c][h]));
+            nzero += __popcll(ballot64(zero));
             if (!neg[c][h] && !zero) cand[c][h] = false;  // strictly larger: out
           }
         if (nneg == 0) {
@@ -1067,7 +1070,7 @@ __device__ int choose_column(const Shared<T> &S, const RowRegs<T, NCH> &prow, co
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
-          for (int h = 0; h < ET<T>::CPL; h++) cm[ET<T>::CPL * c + h] = __ballot(cand[c][h]);
+          for (int h = 0; h < ET<T>::CPL; h++) cm[ET<T>::CPL * c + h] = ballot64(cand[c][h]);
         if (nneg == 0 || count == 1) break;
       }
     }
@@ -1125,7 +1128,7 @@ __device__ int choose_column_slow(const Shared<T> &S, const T *vals, int W, int 
         }
         x = wsub(wmul(pivot, vj), wmul(vb, foo));
       }
-      const u64 nz = __ballot(x != 0);
+      const u64 nz = ballot64(x != 0);
       if (nz) {
         const int src = __ffsll((long long)nz) - 1;
         less = readlane64(x, src) < 0;
@@ -1184,12 +1187,12 @@ __device__ void sort_rows(const Shared<T> &S, int nvar, int nligne, double smax)
       const float sj = S.size[rf];
       if ((double)sj < smax) key = __float_as_uint(sj);
     }
-    const u64 units = __ballot(unit);
+    const u64 units = ballot64(unit);
     for (int i = 0; i < n; i++) {
       if ((units >> i) & 1) continue;
       const unsigned m = wave_minmax_u32<false>(lane >= i ? key : 0xFFFFFFFFu);
       if (m == 0xFFFFFFFFu) continue;  // nothing below smax is left: row i stays
-      const u64 hit = __ballot(lane >= i && key == m);
+      const u64 hit = ballot64(lane >= i && key == m);
       const int pv = __builtin_ctzll(hit);
       if (pv != i) {
         const unsigned ki = __builtin_amdgcn_readlane(key, i), ri = __builtin_amdgcn_readlane(rf, i);
@@ -1618,7 +1621,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
               r.v[c][h] = x;
             }
           }
-          const bool any_v = __ballot(okv) != 0, any_p = __ballot(okp) != 0;
+          const bool any_v = ballot64(okv) != 0, any_p = ballot64(okp) != 0;
           int verdict;
           if (any_p)
             verdict = PIPAMD_ST_NEED_PARMCUT;  // the host owns the context (find_parm/add_parm)
@@ -1700,7 +1703,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
       mc = 0;
       for (int s = lane; s < ni; s += 64)
         if (S.rcls[s] > mc) mc = S.rcls[s];
-      mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
+      mc = ballot64(mc == 3) ? 3 : (ballot64(mc == 2) ? 2 : (ballot64(mc == 1) ? 1 : 0));
       amax = 0;
 #pragma unroll
       for (int c = 0; c < NCH; c++)
@@ -1752,7 +1755,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
                 S.sig[s] &= ~0xC0;  // entry in the pivot column is 0: sign hint "zero"
             }
           }
-          const u64 m = __ballot(need);
+          const u64 m = ballot64(need);
           if (need) S.work[base + __popcll(m & ((1ull << lane) - 1))] = (u16)s;
           base += __popcll(m);
         }
@@ -2065,7 +2068,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
   if (wave == 0) {
     for (int s = lane; s < ni; s += 64)
       if (S.rcls[s] > mc) mc = S.rcls[s];
-    mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
+    mc = ballot64(mc == 3) ? 3 : (ballot64(mc == 2) ? 2 : (ballot64(mc == 1) ? 1 : 0));
   }
   if (tid == 0) {
     J->ni = ni;

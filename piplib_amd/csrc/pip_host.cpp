@@ -358,8 +358,10 @@ struct BatchRun {
       }
       // (then the general one-wave kernel over what the lean launch left -- measured with 14 batches in flight: sending
       // those ~12 % of the tableaux straight to the four-wave tail instead costs 10 % of the throughput)
-      rc = launch(1, budget, smax, lay.batch);
-      if (rc) return rc;
+      if (!(lean && e->lone_batches)) {  // (pipamd_engine_set_lone_batches: straight to the tail launches)
+        rc = launch(1, budget, smax, lay.batch);
+        if (rc) return rc;
+      }
       if (e->single_launch) {  // measurement aid: the bulk launch on its own (its tableaux stay PIPAMD_ST_RUN)
         HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         active = true;
@@ -553,6 +555,12 @@ extern "C" int pipamd_engine_set_round_pivots(pipamd_engine *e, int pivots) {
 extern "C" int pipamd_engine_set_tail_waves(pipamd_engine *e, int waves) {
   if (!e || (waves != 4 && waves != 8)) return PIPAMD_E_INVALID;
   e->tail_waves = waves;
+  return PIPAMD_OK;
+}
+
+extern "C" int pipamd_engine_set_lone_batches(pipamd_engine *e, int on) {
+  if (!e) return PIPAMD_E_INVALID;
+  e->lone_batches = on ? 1 : 0;
   return PIPAMD_OK;
 }
 

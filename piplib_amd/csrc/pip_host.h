@@ -18,6 +18,7 @@ struct pipamd_engine {
   int round_rows;    /* spare rows (Gomory cuts) in the bulk launch's LDS image (0 = default) */
   int bulk_min;      /* batches of at least this many tableaux start with the one-wave bulk launch (0 = default 2048) */
   int single_launch; /* debug: stop after one launch */
+  int lone_batches;  /* 1: no general one-wave launch between the lean launch and the tail (pipamd_engine_set_lone_batches) */
   int no_lean;       /* 1: bulk launches without the lean kernel (pip_lean.h) */
   int *h_run;        /* pinned: {jobs still running, their largest row count} */
   int *d_q;          /* launch-list control words (a pool, see pipamd_batch_solve) and the two job lists */

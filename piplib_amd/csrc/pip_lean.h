@@ -21,6 +21,9 @@
 #define PIP_LEAN_H
 #include "pip_advance.h"
 
+#ifndef PIP_LEAN_PF
+#define PIP_LEAN_PF 2  // rows of a pivot's work list in flight
+#endif
 #ifndef PIP_LEAN_WAVES
 #define PIP_LEAN_WAVES 8  // waves per SIMD the kernel is bounded to (64 VGPRs)
 #endif
@@ -69,8 +72,8 @@ __device__ __forceinline__ int lean_publish(const RowRegs32<1> &z, const Shared<
   }
   const int v0 = z.v[0][0], v1 = z.v[0][1];
   const unsigned mx = (unsigned)(v0 < 0 ? -v0 : v0) | (unsigned)(v1 < 0 ? -v1 : v1);
-  const u64 nz0 = __ballot(v0 != 0), nz1 = __ballot(v1 != 0);
-  const int cls = __ballot((mx >> 15) != 0) ? 1 : 0;
+  const u64 nz0 = ballot64(v0 != 0), nz1 = ballot64(v1 != 0);
+  const int cls = ballot64((mx >> 15) != 0) ? 1 : 0;
   if (lane == 0) {
     S.sig[s] = (u16)sig;
     S.rcls[s] = (u8)cls;
@@ -99,7 +102,7 @@ __device__ int choose_column32(const Shared<i64> &S, const RowRegs32<1> &prow, c
     a[h] = j < nvar ? prow.v[0][h] : 0;
     cand[h] = a[h] > 0;
     u[h] = cand[h] ? (int)S.urow[j] : -1;
-    cm[h] = __ballot(cand[h]);
+    cm[h] = ballot64(cand[h]);
     count += __popcll(cm[h]);
   }
   if (count == 0) return -1;
@@ -113,7 +116,7 @@ __device__ int choose_column32(const Shared<i64> &S, const RowRegs32<1> &prow, c
         rel = ((m[0] & cm[0]) | (m[1] & cm[1])) != 0;
       }
     }
-    u64 relmask = __ballot(rel);
+    u64 relmask = ballot64(rel);
     while (relmask && count > 1) {
       const int kk = k0 + __ffsll((long long)relmask) - 1;
       relmask &= relmask - 1;
@@ -121,13 +124,13 @@ __device__ int choose_column32(const Shared<i64> &S, const RowRegs32<1> &prow, c
       // unit rows above kk knock out their own column
       int nel = 0;
 #pragma unroll
-      for (int h = 0; h < 2; h++) nel += __popcll(__ballot(cand[h] && u[h] < kk));
+      for (int h = 0; h < 2; h++) nel += __popcll(ballot64(cand[h] && u[h] < kk));
       if (nel == count) goto last_unit_wins;
       if (nel) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           if (u[h] < kk) cand[h] = false;
-          cm[h] = __ballot(cand[h]);
+          cm[h] = ballot64(cand[h]);
         }
         count -= nel;
         if (count == 1) break;
@@ -155,8 +158,8 @@ __device__ int choose_column32(const Shared<i64> &S, const RowRegs32<1> &prow, c
           const int x = __mul24(ab, n.v[0][h]) - __mul24(nb, a[h]);
           neg[h] = cand[h] && x < 0;
           const bool zero = cand[h] && x == 0;
-          nneg += __popcll(__ballot(neg[h]));
-          nzero += __popcll(__ballot(zero));
+          nneg += __popcll(ballot64(neg[h]));
+          nzero += __popcll(ballot64(zero));
           if (!neg[h] && !zero) cand[h] = false;  // strictly larger: out
         }
         if (nneg == 0) {
@@ -166,8 +169,8 @@ __device__ int choose_column32(const Shared<i64> &S, const RowRegs32<1> &prow, c
           cand[1] = neg[1];
           count = nneg;
         }
-        cm[0] = __ballot(cand[0]);
-        cm[1] = __ballot(cand[1]);
+        cm[0] = ballot64(cand[0]);
+        cm[1] = ballot64(cand[1]);
         if (nneg == 0 || count == 1) break;
       }
     }
@@ -216,18 +219,15 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
     }
     return;
   }
-  const int L = J->L, Sl = J->S;
   T *vals = (T *)(arena + J->vals_off);
-  T *g_den = (T *)(arena + J->rows_off);
-  int *g_flag = (int *)(g_den + L);
-  int *g_ref = g_flag + L;
-  int npiv = J->npiv, ncut = J->ncut, nupd = J->nupd;
+  // (what only the prologue and the epilogue need -- the row tables in HBM, the saved summaries, the counters -- is
+  // derived from the job header where it is used, so that it holds no scalar registers across the pivot loop)
+  const int ncut0 = J->ncut - ni;  // cuts so far = ncut0 + ni (every row this kernel appends is a cut)
+  const int cap_ni = min(J->S, J->L - nvar);  // rows the job's block holds
+  int npiv = J->npiv, nupd = J->nupd;
   T *g_log = (T *)(arena + J->log_off);
   constexpr int LOGCAP = PIPAMD_DETLOG;
   int nlog = J->nlog;
-  u64 *g_nzm = (u64 *)(arena + J->state_off);
-  u16 *g_sig = (u16 *)(g_nzm + (size_t)Sl * NM);
-  u8 *g_rcls = (u8 *)(g_sig + Sl);
 
   Shared<T> S;  // the tables of pip_advance_kernel's image this kernel uses
   int *cst;     // [S] constant terms (ints here); the entry-time sort keys share their storage
@@ -261,6 +261,11 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
     sc.bad = 0;
   }
   __builtin_amdgcn_wave_barrier();
+  {
+  const int L = J->L;
+  const T *g_den = (const T *)(arena + J->rows_off);
+  const int *g_flag = (const int *)(g_den + L);
+  const int *g_ref = g_flag + L;
   for (int i = lane; i < nligne; i += 64) {
     const int f = g_flag[i], rf = g_ref[i];
     if (f & PIPAMD_F_UNIT) {
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
       S.den[rf] = g_den[i];
       S.nf[rf] = 0;
     }
+  }
   }
   __builtin_amdgcn_wave_barrier();
 
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         if (s >= ni || wide) break;
         const RowRegs<T, 1> &r = rr[qq];
         const bool fits = r.v[0][0] == (T)(int)r.v[0][0] && r.v[0][1] == (T)(int)r.v[0][1];
-        if (__ballot(!fits)) {
+        if (ballot64(!fits)) {
           wide = true;
           break;
         }
@@ -433,11 +439,11 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
           }
           r.v[0][h] = x;
         }
-        const bool any_v = __ballot(okv) != 0;
+        const bool any_v = ballot64(okv) != 0;
         int verdict;
         if (!any_v)
           verdict = PIPAMD_ST_NIL;  // integrer.c:482-485 case (b)
-        else if (ni >= Sl || nligne >= L)
+        else if (ni >= cap_ni)
           verdict = PIPAMD_ST_CAPACITY;
         else if (ni >= Smax || nligne >= Lmax)
           verdict = -1;  // no room in this launch's LDS image: pause
@@ -463,7 +469,6 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         pivi = nligne;
         ni++;
         nligne++;
-        ncut++;
         why = 2;
         if (mcw != 0) break;  // (cannot happen: the cut's entries are below D)
       }
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
             S.sig[s] &= ~0xC0;  // entry in the pivot column is 0: sign hint "zero"
         }
       }
-      const u64 m = __ballot(need);
+      const u64 m = ballot64(need);
       if (need) S.work[nwork + __popcll(m & ((1ull << lane) - 1))] = (u16)s;
       nwork += __popcll(m);
     }
@@ -524,23 +529,30 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
     // ---------------- B: eliminate the pivot column
     nupd += nwork - 1;
     {
-      RowRegs32<1> rr[2];
-      int sw0 = S.work[0], sw1 = S.work[nwork > 1 ? 1 : 0];
-      if (sw0 != pslot) row_load32p(rr[0], vals + (size_t)sw0 * W, lane);
-      if (nwork > 1 && sw1 != pslot) row_load32p(rr[1], vals + (size_t)sw1 * W, lane);
-      for (int w0 = 0; w0 < nwork; w0 += 2) {
-        if (w0) {
-          sw0 = S.work[w0];
-          sw1 = S.work[w0 + 1 < nwork ? w0 + 1 : w0];
-          if (sw0 != pslot) row_load32p(rr[0], vals + (size_t)sw0 * W, lane);
-          if (w0 + 1 < nwork && sw1 != pslot) row_load32p(rr[1], vals + (size_t)sw1 * W, lane);
-        }
+      // a queue of PF rows on their way from HBM / L2 (a row is two registers here): the row at its head is updated
+      // while the loads behind it are in flight
+      constexpr int PF = PIP_LEAN_PF;
+      RowRegs32<1> rq[PF];
+      int sq[PF];
 #pragma unroll
-        for (int qq = 0; qq < 2; qq++) {
-          if (w0 + qq >= nwork) break;
-          const int s = qq ? sw1 : sw0;
-          RowRegs32<1> &r = rr[qq];
-          T *row = vals + (size_t)s * W;
+      for (int q2 = 0; q2 < PF; q2++) {
+        sq[q2] = S.work[q2 < nwork ? q2 : 0];
+        if (q2 < nwork && sq[q2] != pslot) row_load32p(rq[q2], vals + (size_t)sq[q2] * W, lane);
+      }
+      for (int w = 0; w < nwork; w++) {
+        const int s = sq[0];
+        RowRegs32<1> r = rq[0];
+#pragma unroll
+        for (int q2 = 0; q2 + 1 < PF; q2++) {
+          rq[q2] = rq[q2 + 1];
+          sq[q2] = sq[q2 + 1];
+        }
+        if (w + PF < nwork) {
+          sq[PF - 1] = S.work[w + PF];
+          if (sq[PF - 1] != pslot) row_load32p(rq[PF - 1], vals + (size_t)sq[PF - 1] * W, lane);
+        }
+        T *row = vals + (size_t)s * W;
+        {
           if (s == pslot) {
             // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
 #pragma unroll
@@ -628,20 +640,30 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
 
   // ---- epilogue: the row tables, the header and (if any) the solution, as pip_advance_kernel writes them
   __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < nligne; i += 64) {
-    const int rf = S.ref[i];
-    if (rf & UNITBIT) {
-      g_den[i] = 1;
-      g_flag[i] = PIPAMD_F_UNIT | ((rf & UNITZERO) ? PIPAMD_F_ZERO : 0);
-      g_ref[i] = UNITCOL(rf);
-    } else {
-      g_den[i] = S.den[rf];
-      g_flag[i] = S.fl[rf];
-      g_ref[i] = rf;
+  {
+    const int L = J->L;
+    T *g_den = (T *)(arena + J->rows_off);
+    int *g_flag = (int *)(g_den + L);
+    int *g_ref = g_flag + L;
+    for (int i = lane; i < nligne; i += 64) {
+      const int rf = S.ref[i];
+      if (rf & UNITBIT) {
+        g_den[i] = 1;
+        g_flag[i] = PIPAMD_F_UNIT | ((rf & UNITZERO) ? PIPAMD_F_ZERO : 0);
+        g_ref[i] = UNITCOL(rf);
+      } else {
+        g_den[i] = S.den[rf];
+        g_flag[i] = S.fl[rf];
+        g_ref[i] = rf;
+      }
     }
   }
   tflags &= ~PIPAMD_T_STATE;
   if (status == PIPAMD_ST_RUN) {
+    const int Sl = J->S;
+    u64 *g_nzm = (u64 *)(arena + J->state_off);
+    u16 *g_sig = (u16 *)(g_nzm + (size_t)Sl * NM);
+    u8 *g_rcls = (u8 *)(g_sig + Sl);
     for (int s = lane; s < ni; s += 64) {
       g_sig[s] = S.sig[s];
       g_rcls[s] = S.rcls[s];
@@ -671,11 +693,11 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
   int mc = 0;
   for (int s = lane; s < ni; s += 64)
     if (S.rcls[s] > mc) mc = S.rcls[s];
-  mc = __ballot(mc == 3) ? 3 : (__ballot(mc == 2) ? 2 : (__ballot(mc == 1) ? 1 : 0));
+  mc = ballot64(mc == 3) ? 3 : (ballot64(mc == 2) ? 2 : (ballot64(mc == 1) ? 1 : 0));
   if (lane == 0) {
     J->ni = ni;
     J->npiv = npiv;
-    J->ncut = ncut;
+    J->ncut = ncut0 + ni;
     J->nupd = nupd;
     J->nlog = nlog;
     J->pad_ = why;

@@ -112,6 +112,11 @@ class Engine:
         lib().pipamd_engine_set_blocking_wait.argtypes = [C.c_void_p, C.c_int]
         _check(lib().pipamd_engine_set_blocking_wait(self._h, int(bool(on))))
 
+    def set_lone_batches(self, on):
+        """this engine's batches run one at a time (pipamd_engine_set_lone_batches)"""
+        lib().pipamd_engine_set_lone_batches.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().pipamd_engine_set_lone_batches(self._h, int(bool(on))))
+
     def set_tail_waves(self, n):
         lib().pipamd_engine_set_tail_waves.argtypes = [C.c_void_p, C.c_int]
         _check(lib().pipamd_engine_set_tail_waves(self._h, int(n)))

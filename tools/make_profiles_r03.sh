@@ -5,8 +5,9 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/p3_*
-B="python3 bench.py --no-cpu --no-dense --no-others --tail-waves 4"
-# 1. kernel stats: one batch at a time (the isolated launches bench.py's roofline times) and the default 12 in flight
+B="python3 bench.py --no-cpu --no-dense --no-others --tail-waves 4 --lone 0"
+# 1. kernel stats: one batch at a time (the isolated launches bench.py's roofline times; --lone 0 keeps the three-launch
+#    sequence of the pipelined run) and the default 16 in flight
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p3_np -- $B --steps 5 --warmup 1 --pipeline 1 > gpurun_out/p3_np.log 2>&1
 echo "np done"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p3_p -- $B --steps 20 --warmup 5 > gpurun_out/p3_p.log 2>&1
@@ -16,7 +17,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/p3_fetch -- $B --st
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/p3_write -- $B --steps 2 --warmup 1 --pipeline 1 > gpurun_out/p3_write.log 2>&1
 echo "hbm done"
 # 3. the same with row skipping off (roofline_dense_mode): trace pass, then the two counter passes
-D="python3 bench.py --no-cpu --no-others --tail-waves 4 --steps 2 --warmup 1 --pipeline 1"
+D="python3 bench.py --no-cpu --no-others --tail-waves 4 --lone 0 --steps 2 --warmup 1 --pipeline 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p3_dense -- $D > gpurun_out/p3_dense.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/p3_dense_fetch -- $D > gpurun_out/p3_dense_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/p3_dense_write -- $D > gpurun_out/p3_dense_write.log 2>&1

@@ -16,7 +16,10 @@ for src, dst in (("p3_np", "r03_kernel_stats.csv"), ("p3_p", "r03_kernel_stats_p
     shutil.copy(one(src + "/*/*kernel_stats.csv"), os.path.join(P, dst))
 
 
-def per_step(path, name, kernel="pip_advance_kernel", pick=None):
+PIVOT_KERNELS = ("pip_lean_kernel", "pip_advance_kernel")  # the launches that pivot: the lean bulk kernel and the general one
+
+
+def per_step(path, name, kernel=PIVOT_KERNELS, pick=None):
     """counter `name` of `kernel` summed per step (a step starts with a pip_batch_load_kernel dispatch)"""
     steps, cur = [], None
     for r in sorted(csv.DictReader(open(path)), key=lambda r: int(r["Dispatch_Id"])):
@@ -25,7 +28,7 @@ def per_step(path, name, kernel="pip_advance_kernel", pick=None):
         if "pip_batch_load_kernel" in r["Kernel_Name"]:
             cur = [0.0, 0.0]
             steps.append(cur)
-        elif kernel in r["Kernel_Name"] and cur is not None and (pick is None or pick(r)):
+        elif any(k in r["Kernel_Name"] for k in kernel) and cur is not None and (pick is None or pick(r)):
             cur[0] += float(r["Counter_Value"])
             cur[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     return [s for s in steps if s[0] > 0]
@@ -71,29 +74,35 @@ mix = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(one("p3_mix/*/*counter_collection.csv"))):
     mix[r["Kernel_Name"].split("(")[0]][r["Counter_Name"][9:]] += float(r["Counter_Value"])
 piv = 772044.0
+piv_lean = 741317.0  # of them in the lean launch (tools/lean_split.py)
 lines = ["# tools/make_profiles_r03.sh step 4: rocprofv3 --pmc SQ_INSTS_* -- python3 tools/pmc_one.py",
          "# one un-pipelined step of the headline batch (10,000 tableaux, 772,044 pivots): wave-instructions per kernel"]
-tot = collections.defaultdict(float)
+tot, tot_lean = collections.defaultdict(float), collections.defaultdict(float)
 for k, c in mix.items():
     if "pip_" in k:
         lines.append(f"{k} {dict((n, int(v)) for n, v in sorted(c.items()))}")
-    if "pip_advance_kernel" in k:
+    if any(pk in k for pk in PIVOT_KERNELS):
         for n, v in c.items():
             tot[n] += v
-lines.append("pip_advance_kernel per pivot: " + ", ".join(f"{n} {v / piv:.1f}" for n, v in sorted(tot.items())))
+            if "pip_lean_kernel" in k:
+                tot_lean[n] += v
+lines.append("pip_lean_kernel per pivot of its own (741,317): " + ", ".join(f"{n} {v / piv_lean:.1f}" for n, v in sorted(tot_lean.items())))
+lines.append("all pivot launches per pivot (772,044): " + ", ".join(f"{n} {v / piv:.1f}" for n, v in sorted(tot.items())))
 open(os.path.join(P, "r03_pmc_inst_mix.txt"), "w").write("\n".join(lines) + "\n")
 
 # issue utilisation of the launches (counter passes serialise the kernels: these are lone launches whatever --pipeline)
-issue = {"wave_instructions_per_pivot": {n: round(v / piv, 1) for n, v in sorted(tot.items())},
+issue = {"lean_kernel_wave_instructions_per_pivot": {n: round(v / piv_lean, 1) for n, v in sorted(tot_lean.items())},
+         "lean_kernel_wave_instructions_per_pivot_total": round(sum(tot_lean[n] for n in ("VALU", "SALU", "BRANCH", "LDS", "VMEM_RD", "VMEM_WR", "SMEM")) / piv_lean, 1),
+         "wave_instructions_per_pivot": {n: round(v / piv, 1) for n, v in sorted(tot.items())},
          "wave_instructions_per_pivot_total": round(sum(tot[n] for n in ("VALU", "SALU", "BRANCH", "LDS", "VMEM_RD", "VMEM_WR", "SMEM")) / piv, 1)}
 for mode in (1, 12):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for pat in (f"p3_sq_{mode}/*/*counter_collection.csv", f"p3_sq2_{mode}/*/*counter_collection.csv"):
         seen = set()
         for r in csv.DictReader(open(one(pat))):
-            if "pip_advance_kernel" not in r["Kernel_Name"]:
+            if not any(pk in r["Kernel_Name"] for pk in PIVOT_KERNELS):
                 continue
-            k = "bulk" if "1, 1, false" in r["Kernel_Name"] else "tail"
+            k = "lean" if "pip_lean_kernel" in r["Kernel_Name"] else ("bulk" if "1, 1, false" in r["Kernel_Name"] else "tail")
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if (pat, r["Dispatch_Id"]) not in seen and pat.startswith(f"p3_sq_{mode}"):
                 seen.add((pat, r["Dispatch_Id"]))
@@ -107,12 +116,12 @@ for mode in (1, 12):
             "share_of_wave_cycles": {n[3:]: round(c[n] / wc, 3) for n in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA",
                                                                            "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_MISC", "SQ_WAIT_ANY",
                                                                            "SQ_WAIT_INST_ANY") if n in c},
-            "avg_resident_waves_per_CU": round(wc * 4 / cyc / 256, 1),
+            "avg_resident_waves_per_CU": round(wc * 4 / cyc / 256, 1),  # of 32 (lean: 8 per SIMD) / 24 (general one-wave kernel)
             "valu_issue_utilisation_per_SIMD": round(c["SQ_ACTIVE_INST_VALU"] * 4 / cyc / 1024, 3),
             "salu_issue_utilisation_per_SIMD": round(c["SQ_ACTIVE_INST_SCA"] * 4 / cyc / 1024, 3),
             "icache_miss_rate": round(c["SQC_ICACHE_MISSES"] / max(1.0, c["SQC_ICACHE_REQ"]), 6)}
 issue["note"] = ("SQ_* cycle counters are quad-cycles (MI355X_MICROARCH.md); utilisation assumes 2.4 GHz.  A counter pass serialises the "
-                 "kernels, so pipeline12 shows the same lone launches as pipeline1 (12 batches, each launch on its own).")
+                 "kernels, so pipeline12 shows the same lone launches as pipeline1 (12 batches, each launch on its own).  lean = pip_lean_kernel, bulk = the general one-wave launch over what it left, tail = the four-wave launches.")
 json.dump(issue, open(os.path.join(P, "r03_pmc_issue.json"), "w"), indent=1)
 
 print(json.dumps({k: v for k, v in out.items() if "bytes" in k or k in ("dense_mode", "cfg4")}, indent=1))
