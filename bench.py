@@ -417,7 +417,8 @@ def roofline_of(b, e, k_ms, cfg, extra=None, split=None):
              "pivots_per_launch": dom["pivots"], "share_of_the_steps_pivots": dom["pivots"] / max(1, c["pivots"]),
              "rows_rewritten_per_pivot": dom["rows_rewritten_per_pivot"], "step": step}
     else:
-        r = dict({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel": "pip_advance_kernel"}, **step)
+        r = dict({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                  "kernel": "the pivot launches of a step (pip_lean_kernel where the shape has one, pip_advance_kernel)"}, **step)
     if extra:
         r.update(extra)
     return r

@@ -343,10 +343,10 @@ struct BatchRun {
       const int budget = e->iter_limit < K1 ? e->iter_limit : K1;
       int smax = lay.ni + (KA < budget ? KA : budget);
       if (smax > curS) smax = curS;
-      // 127 unknowns + constant in 64 bits, rows skipped, plain cuts: the lean kernel (pip_lean.h) goes first -- it
-      // finishes the tableaux whose entries stay below 2^15 and leaves the others to the general kernel's launch
-      const bool lean = !e->no_lean && lay.ebits != 128 && lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 &&
-                        lay.W == 128 && !(lay.tflags & (PIPAMD_T_NOSKIP | PIPAMD_T_DEEPEST)) && pipk_static_class(smax) != 0;
+      // no parameters, at most 128 columns of 64-bit entries, rows skipped, plain cuts: the lean kernel (pip_lean.h) goes
+      // first -- it finishes the tableaux whose entries stay below 2^15 and leaves the others to the general kernel's launch
+      const bool lean = !e->no_lean && lay.ebits != 128 && lay.nparm == 0 && lay.bigparm < 0 && lay.W <= 128 && !(lay.W & 1) &&
+                        !(lay.tflags & (PIPAMD_T_NOSKIP | PIPAMD_T_DEEPEST)) && pipk_lean_class(smax) != 0;
       if (lean) {
         rc = launch(1, budget, smax, lay.batch, true);
         if (rc) return rc;

@@ -59,6 +59,7 @@ extern "C" {
  * the engine if this stays within the 159 KiB a workgroup can get (PIPAMD_LDS_BUDGET) */
 size_t pipk_advance_lds_bytes(int Lmax, int Smax, int Wmax, int ebits);
 int pipk_static_class(int smax);
+int pipk_lean_class(int smax);
 hipError_t pipk_launch_advance(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
                                int waves_per_job, int ebits, unsigned long long *prof, hipStream_t stream);
 hipError_t pipk_launch_advance_q(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,

@@ -13,7 +13,7 @@ PIP_ADV_GROUP_B(PIP_ADV_EXTERN)
 PIP_ADV_GROUP_C(PIP_ADV_EXTERN)
 PIP_ADV_GROUP_D(PIP_ADV_EXTERN)
 #undef PIP_ADV_EXTERN
-#define PIP_LEAN_EXTERN(SC) extern template hipError_t launch_lean<SC>(const AdvanceLaunch &);
+#define PIP_LEAN_EXTERN(SC, FULL) extern template hipError_t launch_lean<SC, FULL>(const AdvanceLaunch &);
 PIP_LEAN_CLASSES(PIP_LEAN_EXTERN)
 #undef PIP_LEAN_EXTERN
 
@@ -563,18 +563,24 @@ extern "C" int pipk_static_class(int smax) {
   if (s > 140 && s <= 160) return 160;
   return 0;
 }
-// the lean bulk kernel (pip_lean.h) over a launch list; the caller has checked pipk_static_class(a.Smax) != 0
+// Row-capacity class of the lean kernel (pip_lean.h) for `smax` row slots: the smallest that holds them (a class too
+// large costs a little occupancy, no class costs the lean launch); 0 = none.
+extern "C" int pipk_lean_class(int smax) {
+  const int s = (smax + 3) & ~3;
+  return s <= 64 ? 64 : (s <= 96 ? 96 : (s <= 112 ? 112 : (s <= 128 ? 128 : (s <= 160 ? 160 : 0))));
+}
+// the lean bulk kernel over a launch list; the caller has checked pipk_lean_class(a.Smax) != 0
 static hipError_t launch_lean_class(AdvanceLaunch a) {
-  const int sc = pipk_static_class(a.Smax);
+  const int sc = pipk_lean_class(a.Smax);
   a.Smax = sc;
   a.Lmax = sc + 128;
   a.shm = pipk_advance_lds_bytes(a.Lmax, a.Smax, 128, 64);
   switch (sc) {
-    case 64: return launch_lean<64>(a);
-    case 96: return launch_lean<96>(a);
-    case 112: return launch_lean<112>(a);
-    case 128: return launch_lean<128>(a);
-    case 160: return launch_lean<160>(a);
+    case 64: return a.full ? launch_lean<64, true>(a) : launch_lean<64, false>(a);
+    case 96: return a.full ? launch_lean<96, true>(a) : launch_lean<96, false>(a);
+    case 112: return a.full ? launch_lean<112, true>(a) : launch_lean<112, false>(a);
+    case 128: return a.full ? launch_lean<128, true>(a) : launch_lean<128, false>(a);
+    case 160: return a.full ? launch_lean<160, true>(a) : launch_lean<160, false>(a);
   }
   return hipErrorInvalidValue;
 }
@@ -618,9 +624,10 @@ static hipError_t launch_by_shape(const AdvanceLaunch &a, bool one, int wp, int 
 // (re)allocates when the row tables of the launch do not fit LDS (64-bit entries only): the launch
 // then keeps them there, `grid` blocks of the image size.  Without it such a launch is refused.
 // hints: bit 0 = every job of the launch has no parameters, no big parameter and nvar + 1 == W ==
-// the wave's column coverage (the caller knows its batch is uniform): see FULL.  Bit 1 (with bit 0, one wave per job,
-// 64-bit entries and pipk_static_class(Smax) != 0, else refused) = the lean kernel of pip_lean.h: it runs the jobs it
-// can and leaves the others PIPAMD_ST_RUN on the output list for a launch without this bit.
+// the wave's column coverage (the caller knows its batch is uniform): see FULL.  Bit 1 (one wave per job, 64-bit entries, at
+// most 128 columns and pipk_lean_class(Smax) != 0, else refused) = the lean kernel of pip_lean.h: it runs the jobs it
+// can (no parameters, entries below 2^15) and leaves the others PIPAMD_ST_RUN on the output list for a launch without
+// this bit.
 extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
                                             int iter_limit, int waves_per_job, int ebits, void *const *q5, int grid,
                                             void **big, int hints, unsigned long long *prof, hipStream_t stream) {
@@ -683,7 +690,7 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
   const int wp = wp_of(Wmax, ebits);
   hipError_t le;
   if (hints & 2) {
-    if (!(hints & 1) || !one || ebits != 64 || wp != 128 || a.gimg || !pipk_static_class(a.Smax)) return hipErrorInvalidValue;
+    if (!one || ebits != 64 || wp != 128 || a.gimg || !pipk_lean_class(a.Smax)) return hipErrorInvalidValue;
     le = launch_lean_class(a);
   } else {
     le = launch_by_shape(a, one, wp, ebits);

@@ -29,42 +29,44 @@
 #endif
 
 // a packed row: lane l holds columns 2l, 2l+1 as ints, 8 bytes per lane
-__device__ __forceinline__ void row_load32p(RowRegs32<1> &r, const i64 *slot, int lane) {
-  const int2 t = *reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(slot) + 2 * lane);
+// (W: the columns of a row, even and <= 128; lanes beyond them hold zeros)
+__device__ __forceinline__ void row_load32p(RowRegs32<1> &r, const i64 *slot, int lane, int W = 128) {
+  int2 t = {0, 0};
+  if (2 * lane < W) t = *reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(slot) + 2 * lane);
   r.v[0][0] = t.x;
   r.v[0][1] = t.y;
 }
-__device__ __forceinline__ void row_store32p(const RowRegs32<1> &r, i64 *slot, int lane) {
+__device__ __forceinline__ void row_store32p(const RowRegs32<1> &r, i64 *slot, int lane, int W = 128) {
   int2 t;
   t.x = r.v[0][0];
   t.y = r.v[0][1];
-  *reinterpret_cast<int2 *>(reinterpret_cast<int *>(slot) + 2 * lane) = t;
+  if (2 * lane < W) *reinterpret_cast<int2 *>(reinterpret_cast<int *>(slot) + 2 * lane) = t;
 }
 
 // rows [0, n) of a block, packed -> the general format, each within its own slot (the loads of a group of rows are back
 // before their slots are overwritten)
-__device__ __forceinline__ void rows_unpack(i64 *vals, int n, int lane) {
+__device__ __forceinline__ void rows_unpack(i64 *vals, int n, int lane, int W) {
   for (int s0 = 0; s0 < n; s0 += 4) {
     RowRegs32<1> rr[4];
 #pragma unroll
     for (int qq = 0; qq < 4; qq++)
-      if (s0 + qq < n) row_load32p(rr[qq], vals + (size_t)(s0 + qq) * 128, lane);
+      if (s0 + qq < n) row_load32p(rr[qq], vals + (size_t)(s0 + qq) * W, lane, W);
 #pragma unroll
     for (int qq = 0; qq < 4; qq++)
-      if (s0 + qq < n) {
+      if (s0 + qq < n && 2 * lane < W) {
         longlong2 t;
         t.x = (i64)rr[qq].v[0][0];
         t.y = (i64)rr[qq].v[0][1];
-        *reinterpret_cast<longlong2 *>(vals + (size_t)(s0 + qq) * 128 + 2 * lane) = t;
+        *reinterpret_cast<longlong2 *>(vals + (size_t)(s0 + qq) * W + 2 * lane) = t;
       }
   }
 }
 
 // row_publish32<1> for this kernel's LDS image (constant terms kept as ints): sign summary, non-zero bitmap and
-// magnitude class of a row of 127 unknowns + constant; returns the class (0: every entry below 2^15)
+// magnitude class of a row of nvar unknowns + constant; returns the class (0: every entry below 2^15)
 __device__ __forceinline__ int lean_publish(const RowRegs32<1> &z, const Shared<i64> &S, int *cst, int s, int pivj, int extra_sig,
-                                            int lane) {
-  const int cz = __builtin_amdgcn_readlane(z.v[0][1], 63);  // column 127
+                                            int lane, int nvar = 127) {
+  const int cz = row_entry32<1>(z, 0, nvar & 1, nvar >> 1);  // the constant term, column nvar
   int sig = extra_sig | (cz > 0 ? 1 : (cz < 0 ? 2 : 0));
   if (pivj >= 0) {
     const int pz = row_entry32<1>(z, 0, pivj & 1, pivj >> 1);
@@ -88,9 +90,9 @@ __device__ __forceinline__ int lean_publish(const RowRegs32<1> &z, const Shared<
 __host__ __device__ constexpr size_t lean_lds_bytes(int SC) { return ((size_t)39 * SC + 2 * 128 + 2 * 128 + 15) & ~(size_t)15; }
 
 // choisir_piv (traiter.c:297-341) as choose_column<i64, 1, true> does it, on packed rows
-__device__ int choose_column32(const Shared<i64> &S, const RowRegs32<1> &prow, const i64 *vals, int nvar, int nligne,
-                               int pivi, Scalars *sc) {
-  constexpr int NM = 2, W = 128;
+__device__ __forceinline__ int choose_column32(const Shared<i64> &S, const RowRegs32<1> &prow, const i64 *vals, int W, int nvar,
+                                               int nligne, int pivi, Scalars *sc) {
+  constexpr int NM = 2;
   const int lane = threadIdx.x & 63;
   int a[2], u[2];
   bool cand[2];
@@ -138,7 +140,7 @@ __device__ int choose_column32(const Shared<i64> &S, const RowRegs32<1> &prow, c
       if (!((S.nzm[(size_t)sl * NM] & cm[0]) | (S.nzm[(size_t)sl * NM + 1] & cm[1]))) continue;  // cannot separate them
       // real row kk: keep the minimal ratios
       RowRegs32<1> n;
-      row_load32p(n, vals + (size_t)sl * W, lane);
+      row_load32p(n, vals + (size_t)sl * W, lane, W);
       for (;;) {
         // reference column b = first remaining candidate
         int ab, nb;
@@ -187,11 +189,13 @@ last_unit_wins:
   return sc->tmp2 & 1023;
 }
 
-template <int SC>
+// FULL: 127 unknowns + constant, a row fills the wave's 128 columns (the launcher's promise, as for pip_advance_kernel);
+// else any number of unknowns up to 127 without parameters, rows of W <= 128 columns (W even).
+template <int SC, bool FULL>
 __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jobs, i64 *arena, int njobs, int iter_limit,
                                                                       PipQueue q) {
   typedef i64 T;
-  constexpr int Smax = SC, Lmax = SC + 128, WP = 128, NM = 2, W = 128, nvar = 127;
+  constexpr int Smax = SC, Lmax = SC + 128, WP = 128, NM = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Scalars sc;
   const int nq = q.in_count ? *q.in_count : njobs;
@@ -208,10 +212,12 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
   }
   int tflags = J->tflags;
   int ni = J->ni;
+  const int nvar = FULL ? 127 : J->nvar, W = FULL ? 128 : J->W;
   int nligne = nvar + ni;
   // what this kernel does not do stays with pip_advance_kernel: the job goes on the launch list untouched
-  const bool mine = J->nvar == nvar && J->nparm == 0 && J->bigparm < 0 && J->W == W && J->ebits != 128 &&
-                    !(tflags & (PIPAMD_T_NOSKIP | PIPAMD_T_DEEPEST | PIPAMD_T_STATE)) && ni <= Smax && nligne <= Lmax;
+  const bool mine = J->nvar == nvar && nvar < 128 && J->nparm == 0 && J->bigparm < 0 && J->W == W && W <= 128 && !(W & 1) &&
+                    J->ebits != 128 && !(tflags & (PIPAMD_T_NOSKIP | PIPAMD_T_DEEPEST | PIPAMD_T_STATE)) && ni <= Smax &&
+                    nligne <= Lmax;
   if (!mine) {
     if (lane == 0 && q.out_count) {
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
@@ -289,13 +295,14 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
     constexpr int PF0 = 4;
     const bool fresh = (tflags & PIPAMD_T_FRESHROWS) != 0;
     const T *src = fresh ? (const T *)(uintptr_t)J->src_rows : vals;
+    const int pitch = fresh ? nvar + 1 : W;  // the caller's rows are nvar + 1 wide (an even number: pipamd_batch_load), the block's W
     int npacked = 0;
     bool wide = false;
     for (int s0 = 0; s0 < ni && !wide; s0 += PF0) {
       RowRegs<T, 1> rr[PF0];
 #pragma unroll
       for (int qq = 0; qq < PF0; qq++)
-        if (s0 + qq < ni) row_load<T, 1>(rr[qq], src + (size_t)(s0 + qq) * W, W, lane);
+        if (s0 + qq < ni) row_load<T, 1>(rr[qq], src + (size_t)(s0 + qq) * pitch, (nvar + 2) & ~1, lane);
 #pragma unroll
       for (int qq = 0; qq < PF0; qq++) {
         const int s = s0 + qq;
@@ -309,10 +316,10 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         RowRegs32<1> z;
         z.v[0][0] = (int)r.v[0][0];
         z.v[0][1] = (int)r.v[0][1];
-        row_store32p(z, vals + (size_t)s * W, lane);
+        row_store32p(z, vals + (size_t)s * W, lane, W);
         npacked = s + 1;
         const bool den1 = S.den[s] == 1;
-        mcw = max(mcw, lean_publish(z, S, cst, s, -1, den1 ? SIG_RED : 0, lane));
+        mcw = max(mcw, lean_publish(z, S, cst, s, -1, den1 ? SIG_RED : 0, lane, nvar));
         if (tflags & PIPAMD_T_SORT) {
           // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns (as pip_advance_kernel computes it)
           int sz = 0;
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
     if (wide) {
       // an entry beyond 32 bits: not a job for this kernel.  Its header is untouched (FRESHROWS and SORT still stand);
       // rows that came from the block itself and were already rewritten as ints are widened again.
-      if (!fresh) rows_unpack(vals, npacked, lane);
+      if (!fresh) rows_unpack(vals, npacked, lane, W);
       if (lane == 0 && q.out_count) {
         q.out_list[atomicAdd(q.out_count, 1)] = jb;
         atomicMax(q.out_maxni, ni);
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         if (D64 <= 0 || D64 >= ((T)1 << 15)) break;  // the cut's entries would not be of class 0: the general kernel goes on
         const int D = (int)D64;
         RowRegs32<1> r;
-        row_load32p(r, vals + (size_t)cslot * W, lane);
+        row_load32p(r, vals + (size_t)cslot * W, lane, W);
         bool okv = false;
         const float rD = __builtin_amdgcn_rcpf((float)D);
 #pragma unroll
@@ -449,8 +456,8 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
           verdict = -1;  // no room in this launch's LDS image: pause
         else {
           verdict = PIPAMD_ST_RUN;
-          row_store32p(r, vals + (size_t)ni * W, lane);
-          mcw = max(mcw, lean_publish(r, S, cst, ni, -1, 0, lane));
+          row_store32p(r, vals + (size_t)ni * W, lane, W);
+          mcw = max(mcw, lean_publish(r, S, cst, ni, -1, 0, lane, nvar));
           if (lane == 0) {
             S.fl[ni] = PIPAMD_F_MINUS;
             S.nf[ni] = 0;
@@ -485,9 +492,9 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
     why = 0;
     npiv++;
     RowRegs32<1> pr;
-    row_load32p(pr, vals + (size_t)pslot * W, lane);
+    row_load32p(pr, vals + (size_t)pslot * W, lane, W);
     const int psig_v = S.sig[pslot];
-    const int pj = choose_column32(S, pr, vals, nvar, nligne, pivi, &sc);
+    const int pj = choose_column32(S, pr, vals, W, nvar, nligne, pivi, &sc);
     if (pj == -1) {  // traiter.c:782-785
       status = PIPAMD_ST_NIL;
       break;
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
 #pragma unroll
       for (int q2 = 0; q2 < PF; q2++) {
         sq[q2] = S.work[q2 < nwork ? q2 : 0];
-        if (q2 < nwork && sq[q2] != pslot) row_load32p(rq[q2], vals + (size_t)sq[q2] * W, lane);
+        if (q2 < nwork && sq[q2] != pslot) row_load32p(rq[q2], vals + (size_t)sq[q2] * W, lane, W);
       }
       for (int w = 0; w < nwork; w++) {
         const int s = sq[0];
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         }
         if (w + PF < nwork) {
           sq[PF - 1] = S.work[w + PF];
-          if (sq[PF - 1] != pslot) row_load32p(rq[PF - 1], vals + (size_t)sq[PF - 1] * W, lane);
+          if (sq[PF - 1] != pslot) row_load32p(rq[PF - 1], vals + (size_t)sq[PF - 1] * W, lane, W);
         }
         T *row = vals + (size_t)s * W;
         {
@@ -557,8 +564,8 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
             // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
 #pragma unroll
             for (int h = 0; h < 2; h++) r.v[0][h] = (2 * lane + h == pivj) ? (int)dpiv : -pr.v[0][h];
-            row_store32p(r, row, lane);
-            mcw = max(mcw, lean_publish(r, S, cst, s, pivj, pred, lane));
+            row_store32p(r, row, lane, W);
+            mcw = max(mcw, lean_publish(r, S, cst, s, pivj, pred, lane, nvar));
             continue;
           }
           // multipliers from the row's own pivot-column entry (traiter.c:470-476); everything below 2^15
@@ -589,8 +596,8 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
           }
           r.v[0][0] = z[0][0];
           r.v[0][1] = z[0][1];
-          row_store32p(r, row, lane);
-          mcw = max(mcw, lean_publish(r, S, cst, s, pivj, SIG_RED, lane));
+          row_store32p(r, row, lane, W);
+          mcw = max(mcw, lean_publish(r, S, cst, s, pivj, SIG_RED, lane, nvar));
           if (lane == 0) S.den[s] = nd;
         }
       }
@@ -688,7 +695,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
   }
   if (status == PIPAMD_ST_RUN || status == PIPAMD_ST_CAPACITY) {
     // the job goes on elsewhere (pip_advance_kernel, pip_rehouse_kernel): its rows in the general format again
-    rows_unpack(vals, ni, lane);
+    rows_unpack(vals, ni, lane, W);
   }
   int mc = 0;
   for (int s = lane; s < ni; s += 64)
@@ -717,14 +724,15 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
   }
 }
 
-template <int SC>
+template <int SC, bool FULL>
 hipError_t launch_lean(const AdvanceLaunch &a) {
   const int grid = a.grid > 0 && a.grid < a.njobs ? a.grid : a.njobs;
   const size_t shm = lean_lds_bytes(SC);
-  hipLaunchKernelGGL((pip_lean_kernel<SC>), dim3(grid), dim3(64), shm, a.stream, a.jobs, a.arena, a.njobs, a.iter_limit, a.q);
+  hipLaunchKernelGGL((pip_lean_kernel<SC, FULL>), dim3(grid), dim3(64), shm, a.stream, a.jobs, a.arena, a.njobs, a.iter_limit, a.q);
   return hipGetLastError();
 }
 // the row-capacity classes of launch_static (pip_kernels.hip)
-#define PIP_LEAN_CLASSES(X) X(64) X(96) X(112) X(128) X(160)
-#define PIP_LEAN_DEFINE(SC) template hipError_t launch_lean<SC>(const AdvanceLaunch &);
+#define PIP_LEAN_CLASSES(X) \
+  X(64, true) X(96, true) X(112, true) X(128, true) X(160, true) X(64, false) X(96, false) X(112, false) X(128, false) X(160, false)
+#define PIP_LEAN_DEFINE(SC, FULL) template hipError_t launch_lean<SC, FULL>(const AdvanceLaunch &);
 #endif  // PIP_LEAN_H

@@ -634,7 +634,7 @@ def test_rows_fetched_by_the_pivot_kernel(nvar, ni, nq, waves):
     ("beyond-32-bits-fetched", 64, 1, dict(scale=1 << 33), None, True),
     ("overflow", 64, 1, dict(cmax=40000, x0max=3), None, True),   # "Integer overflow" (traiter.c:424,442) on every tableau
     ("class-160", 100, 1, dict(), None, True),         # the largest row-capacity class
-    ("no-class", 113, 1, dict(), None, True),          # 161 row slots: no static class, the general kernel does it all
+    ("no-class", 113, 1, dict(), None, True),          # 161 row slots: beyond the largest class, the general kernel does it all
     ("spare-rows-spent", 64, 1, dict(), 6, True),      # PIPAMD_ST_CAPACITY inside the lean kernel, then expanser
 ])
 def test_lean_kernel_paths(name, ni, nq, kw, cap, stay):
@@ -700,6 +700,52 @@ def test_lean_kernel_paths(name, ni, nq, kw, cap, stay):
             assert st[k] == {2: eng.ST_OVERFLOW, 4: eng.ST_MAXCOL}.get(r.abort_code, eng.ST_OVERFLOW), (k, st[k], r.abort_code)
             continue
         assert st[k] in (eng.ST_SOLUTION, eng.ST_NIL), (k, st[k])
+        assert pv[k] == r.pivots, (k, pv[k], r.pivots)
+        got = "()" if st[k] == eng.ST_NIL else pb.squash(solution_text(num[k], den[k]))
+        assert got == pb.squash(r.text), k
+
+
+@pytest.mark.parametrize("nvar,ni,nq,stay", [
+    (63, 32, 0, True),     # BASELINE configs[1]: 32 x 64, rational
+    (63, 32, 1, True),
+    (41, 30, 1, True),     # 42 columns (even): the rows are fetched by the kernel
+    (40, 30, 1, True),     # 41 columns (odd): pipamd_batch_load copies them, the kernel packs them in place
+    (100, 60, 1, False),
+    (5, 8, 1, True),
+    (126, 64, 1, True),    # 127 columns -> rows of 128 with a zero column
+])
+def test_lean_kernel_other_widths(nvar, ni, nq, stay):
+    """The lean bulk kernel on tableaux of fewer than 127 unknowns (its instantiation with run-time column counts):
+    identical to the same batch without it and to the oracle."""
+    import torch
+    from gpu_common import oracle_batch, solution_text
+    import pipbatch as pb
+    from piplib_amd import engine as eng, synth
+    batch = 200
+    kw = dict(nnz=3, cmax=3, x0max=5) if nvar < 10 else {}
+    rows = synth.lexmin_batch(5000 + nvar, batch, nvar, ni, **kw)
+    outs, launches = [], []
+    for lean in (0, 1):
+        e = eng.Engine(0)
+        e.set_bulk_min(64)
+        e.set_max_rows(ni + 1024)
+        e.debug_lean(lean)
+        b = eng.Batch(e, rows, nvar, 0, tflags=(eng.T_INT if nq else 0) | (eng.T_ROWS_STAY if stay else 0))
+        for _ in range(2):
+            b.load()
+            b.solve()
+        launches.append(e.last_solve_launches())
+        b.fetch()
+        torch.cuda.synchronize()
+        outs.append((b.status.cpu().numpy(), b.pivots.cpu().numpy(), b.cuts.cpu().numpy(), b.sol_num.cpu().numpy(),
+                     b.sol_den.cpu().numpy()))
+    assert launches[1] > launches[0], launches
+    for x, y in zip(*outs):
+        assert (x == y).all()
+    st, pv, _, num, den = outs[1]
+    o = oracle_batch(rows, nvar, 0, nq).results
+    for k, r in enumerate(o):
+        assert r.status != pb.ST_ABORT and st[k] in (eng.ST_SOLUTION, eng.ST_NIL), (k, st[k])
         assert pv[k] == r.pivots, (k, pv[k], r.pivots)
         got = "()" if st[k] == eng.ST_NIL else pb.squash(solution_text(num[k], den[k]))
         assert got == pb.squash(r.text), k

@@ -7,7 +7,7 @@ import torch
 import bench
 oc = [c for c in bench.OTHERS if c["key"] == "configs[%s]" % sys.argv[1]][0]
 od = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-args = types.SimpleNamespace(waves=int(sys.argv[3]) if len(sys.argv) > 3 else 0, round=int(sys.argv[4]) if len(sys.argv) > 4 else 0, round_rows=int(sys.argv[5]) if len(sys.argv) > 5 else 0, tail_waves=0, blocking_wait=-1, bulk_min=-1, copy_rows=False)
+args = types.SimpleNamespace(waves=int(sys.argv[3]) if len(sys.argv) > 3 else 0, round=int(sys.argv[4]) if len(sys.argv) > 4 else 0, round_rows=int(sys.argv[5]) if len(sys.argv) > 5 else 0, tail_waves=0, blocking_wait=-1, bulk_min=int(sys.argv[6]) if len(sys.argv) > 6 else -1, copy_rows=False)
 dev = torch.device("cuda", 0)
 def barrier(): torch.cuda.synchronize(dev)
 fuse = max(1, min(16, 5000 // oc["batch"])) if oc["ebits"] == 64 else 1
