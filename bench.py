@@ -757,7 +757,8 @@ def main():
             others = []
             for oc in OTHERS:
                 progress(oc["key"])
-                od = args.pipeline
+                # (128-bit tableaux of 256 columns: 12 lanes -- 40 M pivots/s against 26 M with 16, whose working sets crowd the L2)
+                od = args.pipeline if oc["ebits"] == 64 else min(args.pipeline, 12)
                 # batches of a thousand small tableaux are a tenth of a millisecond of GPU work each: five of them share a
                 # workspace and a launch sequence (pipamd_batch_load_part), as the shards of a strong-scaling run do
                 ofuse = max(1, min(16, 5000 // oc["batch"])) if oc["ebits"] == 64 else 1
