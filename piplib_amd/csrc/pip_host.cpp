@@ -191,7 +191,7 @@ struct BatchRun {
   long long *arena;
   hipStream_t st;
   int *pool, *over, *list[2];
-  bool over_zeroed, have_list, active, finishing;
+  bool over_zeroed, have_list, active, finishing, replay_pending;
   int stage;       // launches issued
   int curS;        // row capacity of the largest block in play (grows when tableaux are re-housed)
   int grow_round;
@@ -261,7 +261,7 @@ struct BatchRun {
     return PIPAMD_OK;
   }
 
-  int launch(int waves, int budget, int smax, int grid, bool lean = false) {
+  int launch(int waves, int budget, int smax, int grid, bool lean = false, bool replay = true) {
     int rcs = next_stage();
     if (rcs) return rcs;
     if (smax > curS) smax = curS;
@@ -281,7 +281,7 @@ struct BatchRun {
     }
     void *big[2] = {&e->d_scratch, &e->scratch_bytes};
     // a uniform batch without parameters whose rows fill a wave's 128 columns exactly: FULL kernels
-    const int hints = ((lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 && lay.W == 128) ? 1 : 0) | (lean ? 2 : 0);
+    const int hints = ((lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 && lay.W == 128) ? 1 : 0) | (lean ? 2 : 0) | (replay ? 0 : 4);
     HIPCHK(pipk_launch_advance_q(jobs, arena, lay.batch, lay.nvar + smax, smax, lay.W, budget, waves, lay.ebits, q5, grid,
                                  big, hints, e->d_prof, st));
     if (!e->no_timing) HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
@@ -293,8 +293,17 @@ struct BatchRun {
 
   // a tail launch over what is left, and the copy of its control words to the host
   int tail() {
-    int rc = launch(tail_waves, e->iter_limit, curS, upper);
+    // The determinant logs of the bulk launches are replayed once, behind the first tail launch, for all tableaux
+    // (pipk_launch_replay_all): a replay kernel between two launches is a tiny launch that waits milliseconds for a
+    // turn on a device busy with other batches' bulk launches, and nothing in the pivot launches depends on it -- a
+    // tableau that overflowed goes on pivoting until the replay says so, its status and pivot count are the same.
+    // The bulk launches log at most 2 x 96 pivots per tableau, the log holds PIPAMD_DETLOG.
+    int rc = launch(tail_waves, e->iter_limit, curS, upper, false, !replay_pending);
     if (rc) return rc;
+    if (replay_pending) {
+      HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, st));
+      replay_pending = false;
+    }
     HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     return PIPAMD_OK;
   }
@@ -332,6 +341,7 @@ struct BatchRun {
     stage = 0;
     have_list = false;
     finishing = false;
+    replay_pending = false;
     curS = lay.S;
     grow_round = 0;
     const bool integer = (lay.tflags & PIPAMD_T_INT) != 0;
@@ -347,10 +357,16 @@ struct BatchRun {
       // first -- it finishes the tableaux whose entries stay below 2^15 and leaves the others to the general kernel's launch
       const bool lean = !e->no_lean && lay.ebits != 128 && lay.nparm == 0 && lay.bigparm < 0 && lay.W <= 128 && !(lay.W & 1) &&
                         !(lay.tflags & (PIPAMD_T_NOSKIP | PIPAMD_T_DEEPEST)) && pipk_lean_class(smax) != 0;
+      // (the bulk launches leave their determinant logs to the replay behind the first tail launch; two of them log at
+      // most 2 * budget pivots per tableau)
+      const bool defer = 2 * budget <= PIPAMD_DETLOG / 2;
       if (lean) {
-        rc = launch(1, budget, smax, lay.batch, true);
+        rc = launch(1, budget, smax, lay.batch, true, !defer);
         if (rc) return rc;
+        replay_pending = defer;
         if (e->single_launch == 2) {  // measurement aid: the lean launch on its own
+          if (replay_pending) HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, st));
+          replay_pending = false;
           HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
           active = true;
           return PIPAMD_OK;
@@ -359,10 +375,13 @@ struct BatchRun {
       // (then the general one-wave kernel over what the lean launch left -- measured with 14 batches in flight: sending
       // those ~12 % of the tableaux straight to the four-wave tail instead costs 10 % of the throughput)
       if (!(lean && e->lone_batches)) {  // (pipamd_engine_set_lone_batches: straight to the tail launches)
-        rc = launch(1, budget, smax, lay.batch);
+        rc = launch(1, budget, smax, lay.batch, false, !defer);
         if (rc) return rc;
+        replay_pending = defer;
       }
       if (e->single_launch) {  // measurement aid: the bulk launch on its own (its tableaux stay PIPAMD_ST_RUN)
+        if (replay_pending) HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, st));
+        replay_pending = false;
         HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         active = true;
         return PIPAMD_OK;

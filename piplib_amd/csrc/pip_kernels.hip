@@ -627,7 +627,7 @@ static hipError_t launch_by_shape(const AdvanceLaunch &a, bool one, int wp, int 
 // the wave's column coverage (the caller knows its batch is uniform): see FULL.  Bit 1 (one wave per job, 64-bit entries, at
 // most 128 columns and pipk_lean_class(Smax) != 0, else refused) = the lean kernel of pip_lean.h: it runs the jobs it
 // can (no parameters, entries below 2^15) and leaves the others PIPAMD_ST_RUN on the output list for a launch without
-// this bit.
+// this bit.  Bit 2: no determinant replay behind the launch (see pipk_launch_replay_all).
 extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
                                             int iter_limit, int waves_per_job, int ebits, void *const *q5, int grid,
                                             void **big, int hints, unsigned long long *prof, hipStream_t stream) {
@@ -696,7 +696,8 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
     le = launch_by_shape(a, one, wp, ebits);
   }
   if (le != hipSuccess) return le;
-  // the determinant bookkeeping of the pivots just logged
+  // the determinant bookkeeping of the pivots just logged (hints bit 2: the caller replays later -- pipk_launch_replay_all)
+  if (hints & 4) return hipGetLastError();
   const int nrep = a.grid > 0 && a.grid < njobs ? a.grid : njobs;
   if (one) {  // behind a bulk launch: fewest instructions
     if (ebits == 128)
@@ -709,6 +710,19 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
     else
       hipLaunchKernelGGL(pip_det_replay_kernel<i64>, dim3(nrep), dim3(64), 0, stream, jobs, arena, njobs, a.q);
   }
+  return hipGetLastError();
+}
+
+// The determinant logs of ALL jobs 0..njobs-1 replayed, one lane per job (jobs with an empty log cost a load): behind a
+// sequence of launches that ran with hints bit 2.  The log holds PIPAMD_DETLOG pivots and the pivot kernels pause a
+// job whose log is full, so a sequence may log at most that many pivots per job between replays.
+extern "C" hipError_t pipk_launch_replay_all(PipJob *jobs, i64 *arena, int njobs, int ebits, hipStream_t stream) {
+  if (njobs <= 0) return hipSuccess;
+  const PipQueue q{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (ebits == 128)
+    hipLaunchKernelGGL(pip_det_replay_lanes_kernel<i128>, dim3((njobs + 63) / 64), dim3(64), 0, stream, jobs, arena, njobs, q);
+  else
+    hipLaunchKernelGGL(pip_det_replay_lanes_kernel<i64>, dim3((njobs + 63) / 64), dim3(64), 0, stream, jobs, arena, njobs, q);
   return hipGetLastError();
 }
 
