@@ -19,7 +19,7 @@ workload with one batch at a time.  `other_configs` carries BASELINE configs[1] 
 measured the same way (shorter runs).
 Multi-GPU (--gpus N > 1): BASELINE configs[3] -- every 10k-tableau batch is sharded over the ranks
 (strong scaling), no data-path collective; a rank fuses its shards of several batches in flight into
-one workspace (pipamd_batch_load_part) so that one launch sequence serves ~5,000 tableaux whatever N;
+one workspace (pipamd_batch_load_part) so that one launch sequence serves ~10,000 tableaux whatever N (pick_fuse);
 RCCL only sums the totals here (the results gather is piplib_amd.dist.gather_results).  The
 weak-scaling figure (10k tableaux per GPU and batch) is measured as well and reported as
 `other_scaling`.
@@ -484,6 +484,18 @@ def profile_json(*names):
     return None, None
 
 
+def pick_fuse(shard, steps, target=10000):
+    """How many batches (or shards) of `shard` tableaux share one workspace and launch sequence: about `target`
+    tableaux per sequence (one MI355X, 1,250-tableau shards, 192 steps: 4 per sequence 454 M pivots/s, 8: 502 M,
+    20: 501 M), as a divisor of the step count where one is near, so that a short run is whole passes (the
+    driver's 20 steps at 1,250: 4 per sequence 211 M, 8 -- three passes, 24 steps -- 215 M, 10: 267 M, 20: 244 M)."""
+    f0 = max(1, min(16, target // max(1, shard)))
+    if f0 == 1 or steps % f0 == 0:
+        return f0
+    near = [d for d in range(max(1, f0 // 2), min(16, 2 * f0) + 1) if steps % d == 0]
+    return min(near, key=lambda d: (abs(d - f0), -d)) if near else f0
+
+
 def kernel_ms_of(b, parts=None, reps=2):
     b.e.set_timing(True)
     ms = []
@@ -520,7 +532,7 @@ def main():
                          "one thread over pipamd_batch_solve_async / pipamd_batch_wait")
     ap.add_argument("--fuse", type=int, default=0,
                     help="strong scaling: shards of this many batches share a workspace and a launch sequence (0 = enough "
-                         "for about 5,000 tableaux per launch sequence)")
+                         "for about 10,000 tableaux per launch sequence, pick_fuse)")
     ap.add_argument("--stagger", type=float, default=0.0, help="(ignored; kept for old command lines)")
     ap.add_argument("--blocking-wait", type=int, default=-1,
                     help="1: host threads sleep while the device works, 0: they poll; -1: sleep when there are more lanes than CPUs")
@@ -574,11 +586,11 @@ def main():
         if scaling == "strong":
             # BASELINE configs[3]: every 10k-tableau batch is sharded over the GPUs: a GPU holds 1/world of every
             # batch in flight.  The shards are independent tableaux, so a rank loads its shards of `fuse` batches
-            # into ONE workspace (pipamd_batch_load_part) and one bulk + tail launch pair serves them: about 5,000
+            # into ONE workspace (pipamd_batch_load_part) and one launch sequence serves them: about 10,000
             # tableaux per launch sequence whatever the world size, instead of 24 launch sequences of 1,250 tableaux
             # (round 2: 262 M pivots/s per GPU at 1,250, 304 M at 2,500, 350 M at 5,000, 362 M at 10,000).
             shard = max(1, (args.batch + world - 1) // world)
-            fuse = args.fuse if args.fuse > 0 else max(1, min(16, 5000 // shard))
+            fuse = args.fuse if args.fuse > 0 else pick_fuse(shard, args.steps)
             depth = max(1, min(args.pipeline, (args.steps + fuse - 1) // fuse))
             lo, hi = pdist.shard_range(args.batch, rank, world)
             cfg["batch"] = hi - lo
@@ -588,7 +600,7 @@ def main():
                 return synth.lexmin_batch(seed, args.batch, cfg["nvar"], cfg["ni"])[lo:hi]
         else:
             # small batches (--batch below 2,500 per GPU) are fused the same way: a lane's workspace holds `fuse` of them
-            fuse = args.fuse if args.fuse > 0 else max(1, min(16, 5000 // max(1, args.batch)))
+            fuse = args.fuse if args.fuse > 0 else pick_fuse(args.batch, args.steps)
             depth = max(1, min(args.pipeline, (args.steps + fuse - 1) // fuse))
             # batch i of rank r: seed 1000 + r + 7919 * i
             seeds = [pdist.shard_seed(1000, rank) + 7919 * i for i in range(depth)]
@@ -759,9 +771,10 @@ def main():
                 progress(oc["key"])
                 # (128-bit tableaux of 256 columns: 12 lanes -- 40 M pivots/s against 26 M with 16, whose working sets crowd the L2)
                 od = args.pipeline if oc["ebits"] == 64 else min(args.pipeline, 12)
-                # batches of a thousand small tableaux are a tenth of a millisecond of GPU work each: five of them share a
+                # batches of a thousand small tableaux are a tenth of a millisecond of GPU work each: ten of them share a
                 # workspace and a launch sequence (pipamd_batch_load_part), as the shards of a strong-scaling run do
-                ofuse = max(1, min(16, 5000 // oc["batch"])) if oc["ebits"] == 64 else 1
+                # (5 per sequence 617 M pivots/s, 10: 651 M, 16: 662 M)
+                ofuse = max(1, min(16, 10000 // oc["batch"])) if oc["ebits"] == 64 else 1
                 ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args, fuse=ofuse)
                 osteps = 16 * od * ofuse
                 # The median of three timed regions: a region here is 35 ms to 1.4 s long, and the first region of a

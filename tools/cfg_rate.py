@@ -10,7 +10,7 @@ od = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 args = types.SimpleNamespace(waves=int(sys.argv[3]) if len(sys.argv) > 3 else 0, round=int(sys.argv[4]) if len(sys.argv) > 4 else 0, round_rows=int(sys.argv[5]) if len(sys.argv) > 5 else 0, tail_waves=0, blocking_wait=-1, bulk_min=int(sys.argv[6]) if len(sys.argv) > 6 else -1, copy_rows=False)
 dev = torch.device("cuda", 0)
 def barrier(): torch.cuda.synchronize(dev)
-fuse = max(1, min(16, 5000 // oc["batch"])) if oc["ebits"] == 64 else 1
+fuse = int(os.environ.get("CFG_FUSE", "0")) or (max(1, min(16, 10000 // oc["batch"])) if oc["ebits"] == 64 else 1)
 ol = bench.Lanes(oc, od, dev, 0, [2000 + 7919 * i for i in range(od)], args, fuse=fuse)
 regs = sorted((bench.timed(ol, 8 * od * fuse, od, barrier) for _ in range(3)), key=lambda r: r[0])
 dt, sh = regs[1]
