@@ -1,22 +1,26 @@
 // piplib_amd/csrc/pip_lean.h -- the lean bulk kernel: pip_advance_kernel's pivot loop specialised for the regime the
 // headline workload lives in.
 //
-// One wave per tableau, 127 unknowns + constant (W == 128), no parameters, no big parameter, 64-bit Entier, compile-time
-// row capacity SC -- and EVERY entry of EVERY row below 2^15 in magnitude (magnitude class 0), the pivot row's
-// denominator too.  Under that invariant every product of a pivot fits 31 bits, so
-//   * rows live in HBM as int32 (512 bytes per row, in the first half of the row's 1 KiB slot): half the traffic of the
-//     reference's long long rows, half the working set;
+// One wave per tableau, at most 127 unknowns + constant in rows of W <= 128 columns (FULL: exactly 127 + 1, compile-time
+// column counts), no parameters, no big parameter, 64-bit Entier, compile-time row capacity SC, rows skipped, plain
+// cuts -- and EVERY entry of EVERY row below 2^15 in magnitude (magnitude class 0), the pivot row's denominator and a
+// cut's denominator too.  Under that invariant every product of a pivot fits 31 bits, so
+//   * rows live in HBM as int32 (4 W bytes per row, in the first half of the row's slot of W long longs): half the
+//     traffic of the reference's long long rows, half the working set;
 //   * a row is two 32-bit registers per lane; the elimination, the row gcd (float-reciprocal remainders), the exact
 //     division, the summaries, choisir_piv's cross products (24-bit multiplies) and the cuts are 32-bit arithmetic;
 //   * none of the general kernel's other paths (64-bit update, wide tournament, parameters, deepest cuts, row tables in
-//     HBM) is compiled in: less code, fewer registers, fewer branches.
-// The invariant is checked between pivots (the running maximum of the magnitude classes and the pivot row's denominator).
-// A tableau that leaves it -- or anything else this kernel does not do -- is written back in the general format (rows
-// widened to int64 in place, the same row tables and saved summaries as a paused job of pip_advance_kernel) and stays
-// PIPAMD_ST_RUN on the launch list: the tail launch of pipamd_batch_solve (pip_advance_kernel, four waves per tableau)
-// takes it from there.  Same algorithm, same statuses, same bits as pip_advance_kernel -- the reference's
-// traiter()/pivoter()/choisir_piv()/exam_coef()/integrer()/tab_sort_rows (traiter.c:101-159, 297-548, 556-623, 628-791;
-// integrer.c:305-486) -- which the parity tests check tableau by tableau.
+//     HBM) is compiled in, the pivot row stays in registers, the LDS image is smaller (lean_lds_bytes): 64 VGPRs, no
+//     scratch, eight waves per SIMD.
+// The invariant is checked between pivots (the running maximum of the magnitude classes the row summaries compute anyway,
+// the pivot row's denominator, a cut's denominator).  A tableau that leaves it -- or anything else this kernel does not
+// do: entries beyond 32 bits at entry, PIPAMD_T_NOSKIP / _DEEPEST, a paused job -- is handed over in the general format
+// (rows widened to int64 in place, the same row tables and saved summaries as a paused job of pip_advance_kernel) and
+// stays PIPAMD_ST_RUN on the launch list: pipamd_batch_solve's next launches (pip_advance_kernel: one wave per tableau
+// over what this launch left, then four waves per tableau) take it from there.  Same algorithm, same statuses, same
+// bits as pip_advance_kernel -- the reference's traiter()/pivoter()/choisir_piv()/exam_coef()/integrer()/tab_sort_rows
+// (traiter.c:101-159, 297-548, 556-623, 628-791; integrer.c:305-486) -- which the parity tests check tableau by tableau
+// (tests/test_gpu_parity.py: test_lean_kernel_paths, test_lean_kernel_other_widths, and every batch test of the suite).
 #ifndef PIP_LEAN_H
 #define PIP_LEAN_H
 #include "pip_advance.h"

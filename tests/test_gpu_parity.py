@@ -210,8 +210,8 @@ def test_batch_layer_rehouses_full_tableaux(batch, nvar, ni, cap, ebits, step):
 
 
 def test_bench_lane_seeds_all_finish():
-    """bench.py's headline lanes draw their batches from seeds 1000 + 7919 * lane.  Three of the first 12 lanes'
-    120,000 tableaux are ones on which Gomory's cuts do not converge (the CPU oracle does not finish them within
+    """bench.py's headline lanes draw their batches from seeds 1000 + 7919 * lane.  Three of the 16 lanes'
+    160,000 tableaux are ones on which Gomory's cuts do not converge (the CPU oracle does not finish them within
     minutes: found with it in round 3, listed below); bench.py replaces exactly those (piplib_amd.engine.slow_converging:
     not converged within 448 cut rows).  Every other tableau must end with a status the reference has (solution or nil)
     -- tableaux that need more than the default ni + 64 spare rows are re-housed -- and the oracle agrees on every
@@ -224,7 +224,7 @@ def test_bench_lane_seeds_all_finish():
     e = eng.Engine(0)
     e.set_max_rows(ni + 1024)
     grown = 0
-    for lane in range(12):
+    for lane in range(16):
         rows = synth.lexmin_batch(1000 + 7919 * lane, 10000, nvar, ni)
         slow = eng.slow_converging(e, torch.as_tensor(rows).to("cuda:0"), nvar)
         assert slow == known_slow.get(lane, []), (lane, slow)
