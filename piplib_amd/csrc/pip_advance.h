@@ -66,6 +66,9 @@ typedef unsigned short u16;
 typedef unsigned char u8;
 
 #ifndef PIP_OPT_CSMALL
+#ifndef PIP_OPT_NARROW128
+#define PIP_OPT_NARROW128 1  // (A/B switch) 128-bit rows of class 0: the row update on 64-bit registers
+#endif
 #define PIP_OPT_CSMALL 1   // (A/B switch) choisir_piv with 24-bit cross products while every row is in class 0
 #endif
 #ifndef PIP_MINWAVES128
@@ -625,24 +628,11 @@ __device__ __forceinline__ int row_publish32(const RowRegs32<NCH> &z, const Shar
 // 1; gcd is associative, so any evaluation order gives the same g.  We refine
 // g downwards: reduce every z modulo the current g, fold in one non-zero
 // remainder, repeat until all remainders vanish (typically <= 2 rounds).
-template <class T, int NCH>
-__device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, int pivj, T lpiv, T foo, T dpiv, T g0,
-                                           int lane, T &newden) {
+// The second half: z (N entries per lane, `mx` = OR of the lane's |z|) is divided by g = gcd(g0, z_0, ..., z_n) in place;
+// newden = g0 / g.  False where the reference would divide by zero.
+template <class T, int N>
+__device__ __forceinline__ bool row_reduce(T (&z)[N], typename ET<T>::U mx, T g0, int lane, T &newden) {
   typedef typename ET<T>::U U;
-  constexpr int CPL = ET<T>::CPL;
-  (void)CPL;
-  U mx = 0;
-#pragma unroll
-  for (int c = 0; c < NCH; c++)
-#pragma unroll
-    for (int h = 0; h < ET<T>::CPL; h++) {
-      int j = colof<T>(c, lane, h);
-      T q = prow[j];
-      T z = wsub(wmul(r.v[c][h], lpiv), wmul(q, foo));
-      if (j == pivj) z = wmul(dpiv, foo);
-      r.v[c][h] = z;
-      mx |= uabs64(z);
-    }
   newden = g0;
   if (g0 == 1) return true;
   U g = (U)uni64((T)uabs64(g0));
@@ -652,13 +642,11 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
   for (;;) {
     U rr = 0;
 #pragma unroll
-    for (int c = 0; c < NCH; c++)
-#pragma unroll
-      for (int h = 0; h < ET<T>::CPL; h++) {
-        U a = uabs64(r.v[c][h]);
-        U m = g == 0 ? a : umod_small(a, g, small);
-        rr = rr ? rr : m;
-      }
+    for (int e = 0; e < N; e++) {
+      U a = uabs64(z[e]);
+      U m = g == 0 ? a : umod_small(a, g, small);
+      rr = rr ? rr : m;
+    }
     CNT(13, 1);
     CNT(14, small ? 0 : 1);
     u64 nz = ballot64(rr != 0);
@@ -682,13 +670,11 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
     inv *= 2u - m * inv;
     inv *= 2u - m * inv;
 #pragma unroll
-    for (int c = 0; c < NCH; c++)
-#pragma unroll
-      for (int h = 0; h < ET<T>::CPL; h++) {
-        const T z = r.v[c][h];
-        const unsigned q = ((unsigned)uabs64(z) >> s) * inv;
-        r.v[c][h] = z < 0 ? wneg((T)q) : (T)q;
-      }
+    for (int e = 0; e < N; e++) {
+      const T zz = z[e];
+      const unsigned q = ((unsigned)uabs64(zz) >> s) * inv;
+      z[e] = zz < 0 ? wneg((T)q) : (T)q;
+    }
     const unsigned qd = ((unsigned)uabs64(g0) >> s) * inv;
     newden = g0 < 0 ? wneg((T)qd) : (T)qd;
     return true;
@@ -696,11 +682,54 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
   int s = ctzU(g);
   U inv = inv_odd64(g >> s);
 #pragma unroll
-  for (int c = 0; c < NCH; c++)
-#pragma unroll
-    for (int h = 0; h < ET<T>::CPL; h++) r.v[c][h] = (T)((U)(r.v[c][h] >> s) * inv);
+  for (int e = 0; e < N; e++) z[e] = (T)((U)(z[e] >> s) * inv);
   newden = (T)((U)(g0 >> s) * inv);
   return true;
+}
+
+template <class T, int NCH>
+__device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, int pivj, T lpiv, T foo, T dpiv, T g0,
+                                           int lane, T &newden) {
+  typedef typename ET<T>::U U;
+  U mx = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int h = 0; h < ET<T>::CPL; h++) {
+      int j = colof<T>(c, lane, h);
+      T q = prow[j];
+      T z = wsub(wmul(r.v[c][h], lpiv), wmul(q, foo));
+      if (j == pivj) z = wmul(dpiv, foo);
+      r.v[c][h] = z;
+      mx |= uabs64(z);
+    }
+  return row_reduce<T, NCH * ET<T>::CPL>(reinterpret_cast<T(&)[NCH * ET<T>::CPL]>(r.v), mx, g0, lane, newden);
+}
+
+// The same for 128-bit rows whose operands are all below 2^31 (the row and the pivot row in magnitude class 0, the
+// multipliers and the pivot row's denominator below 2^31) under a denominator product g0 that fits 63 bits: every
+// product is below 2^62 and every z below 2^63, so the update runs on 64-bit registers -- and, when the z's and g0 fit 32
+// bits as well, on row_reduce's 32-bit remainders and quotients -- with the same bits as the 128-bit code.
+template <int NCH>
+__device__ __forceinline__ bool update_row_narrow(RowRegs<i128, NCH> &r, const i128 *prow, int pivj, i64 lpiv, i64 foo, i64 dpiv,
+                                                  i64 g0, int lane, i128 &newden) {
+  i64 z[NCH];
+  u64 mx = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int j = colof<i128>(c, lane, 0);
+    const i64 p = (i64)r.v[c][0], q = (i64)prow[j];
+    i64 v = p * lpiv - q * foo;
+    if (j == pivj) v = dpiv * foo;
+    z[c] = v;
+    mx |= uabs64(v);
+  }
+  i64 nd;
+  const bool ok = row_reduce<i64, NCH>(z, mx, g0, lane, nd);
+#pragma unroll
+  for (int c = 0; c < NCH; c++) r.v[c][0] = (i128)z[c];
+  newden = (i128)nd;
+  return ok;
 }
 
 // a mod g for a, g < 2^20, g >= 1, rg = v_rcp_f32(g): the float quotient estimate is off by at most one either way
@@ -1949,6 +1978,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
                 for (int c = 0; c < NCH; c++)
 #pragma unroll
                   for (int h = 0; h < 2; h++) r.v[c][h] = (T)z32.v[c][h];
+                done_small = true;
+              }
+            }
+            if constexpr (sizeof(T) == 16) {
+              // 128-bit entries whose operands are all below 2^31 (both rows in magnitude class 0) under a denominator
+              // product of at most 63 bits: the update on 64-bit registers (update_row_narrow)
+              const T lim = (T)1 << 31, glim = (T)1 << 62;
+              if (PIP_OPT_NARROW128 && S.rcls[s] == 0 && prow_cls == 0 && lp < lim && foo < lim && foo > -lim && dpiv < lim &&
+                  dpiv > -lim && g0 < glim && g0 > -glim) {
+                if (!update_row_narrow<NCH>(r, S.prow, pivj, (i64)lp, (i64)foo, (i64)dpiv, (i64)g0, lane, nd)) {
+                  if (lane == 0) sc.bad = 1;
+                }
                 done_small = true;
               }
             }
