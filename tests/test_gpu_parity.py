@@ -749,3 +749,30 @@ def test_lean_kernel_other_widths(nvar, ni, nq, stay):
         assert pv[k] == r.pivots, (k, pv[k], r.pivots)
         got = "()" if st[k] == eng.ST_NIL else pb.squash(solution_text(num[k], den[k]))
         assert got == pb.squash(r.text), k
+
+
+def test_lone_batches_option():
+    """pipamd_engine_set_lone_batches: the tableaux the lean launch leaves go straight to the tail launches (one launch
+    less); statuses, pivot and cut counts and solutions are those of the default sequence."""
+    import torch
+    from piplib_amd import engine as eng, synth
+    nvar, ni = 127, 64
+    rows = synth.lexmin_batch(6100, 600, nvar, ni)
+    outs, launches = [], []
+    for lone in (0, 1):
+        e = eng.Engine(0)
+        e.set_bulk_min(64)
+        e.set_max_rows(ni + 1024)
+        e.set_lone_batches(lone)
+        b = eng.Batch(e, rows, nvar, 0, tflags=eng.T_INT | eng.T_ROWS_STAY)
+        b.load()
+        b.solve()
+        launches.append(e.last_solve_launches())
+        b.fetch()
+        torch.cuda.synchronize()
+        outs.append((b.status.cpu().numpy(), b.pivots.cpu().numpy(), b.cuts.cpu().numpy(), b.sol_num.cpu().numpy(),
+                     b.sol_den.cpu().numpy()))
+    assert launches[1] < launches[0], launches
+    for x, y in zip(*outs):
+        assert (x == y).all()
+    assert (outs[0][0] != eng.ST_RUN).all()
