@@ -301,7 +301,7 @@ struct BatchRun {
     int rc = launch(tail_waves, e->iter_limit, curS, upper, false, !replay_pending);
     if (rc) return rc;
     if (replay_pending) {
-      HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, st));
+      HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, e->lone_batches, st));
       replay_pending = false;
     }
     HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -365,7 +365,7 @@ struct BatchRun {
         if (rc) return rc;
         replay_pending = defer;
         if (e->single_launch == 2) {  // measurement aid: the lean launch on its own
-          if (replay_pending) HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, st));
+          if (replay_pending) HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, e->lone_batches, st));
           replay_pending = false;
           HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
           active = true;
@@ -380,7 +380,7 @@ struct BatchRun {
         replay_pending = defer;
       }
       if (e->single_launch) {  // measurement aid: the bulk launch on its own (its tableaux stay PIPAMD_ST_RUN)
-        if (replay_pending) HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, st));
+        if (replay_pending) HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, e->lone_batches, st));
         replay_pending = false;
         HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         active = true;

@@ -66,7 +66,7 @@ hipError_t pipk_launch_advance_q(PipJob *jobs, long long *arena, int njobs, int 
                                  int waves_per_job, int ebits, void *const *q5, int grid, void **big, int hints,
                                  unsigned long long *prof,
                                  hipStream_t stream);
-hipError_t pipk_launch_replay_all(PipJob *jobs, long long *arena, int njobs, int ebits, hipStream_t stream);
+hipError_t pipk_launch_replay_all(PipJob *jobs, long long *arena, int njobs, int ebits, int wave_per_job, hipStream_t stream);
 hipError_t pipk_launch_batch_load(PipJob *jobs, long long *arena, const long long *rows, PipBatchLayout lay, int first,
                                   int count, hipStream_t stream);
 hipError_t pipk_launch_batch_results(const PipJob *jobs, const long long *arena, int njobs, int nvar, int nparm,

@@ -713,13 +713,20 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
   return hipGetLastError();
 }
 
-// The determinant logs of ALL jobs 0..njobs-1 replayed, one lane per job (jobs with an empty log cost a load): behind a
-// sequence of launches that ran with hints bit 2.  The log holds PIPAMD_DETLOG pivots and the pivot kernels pause a
-// job whose log is full, so a sequence may log at most that many pivots per job between replays.
-extern "C" hipError_t pipk_launch_replay_all(PipJob *jobs, i64 *arena, int njobs, int ebits, hipStream_t stream) {
+// The determinant logs of ALL jobs 0..njobs-1 replayed: behind a sequence of launches that ran with hints bit 2.
+// wave_per_job = 0: one lane per job (jobs with an empty log cost a load) -- fewest instructions, what counts when other
+// batches keep the device busy; 1: one wave per job -- shortest latency (a lane walks its up to 200 log entries alone for
+// half a millisecond), for a caller that runs one batch at a time.  The log holds PIPAMD_DETLOG pivots and the pivot
+// kernels pause a job whose log is full, so a sequence may log at most that many pivots per job between replays.
+extern "C" hipError_t pipk_launch_replay_all(PipJob *jobs, i64 *arena, int njobs, int ebits, int wave_per_job, hipStream_t stream) {
   if (njobs <= 0) return hipSuccess;
   const PipQueue q{nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (ebits == 128)
+  if (wave_per_job) {
+    if (ebits == 128)
+      hipLaunchKernelGGL(pip_det_replay_kernel<i128>, dim3(njobs), dim3(64), 0, stream, jobs, arena, njobs, q);
+    else
+      hipLaunchKernelGGL(pip_det_replay_kernel<i64>, dim3(njobs), dim3(64), 0, stream, jobs, arena, njobs, q);
+  } else if (ebits == 128)
     hipLaunchKernelGGL(pip_det_replay_lanes_kernel<i128>, dim3((njobs + 63) / 64), dim3(64), 0, stream, jobs, arena, njobs, q);
   else
     hipLaunchKernelGGL(pip_det_replay_lanes_kernel<i64>, dim3((njobs + 63) / 64), dim3(64), 0, stream, jobs, arena, njobs, q);
