@@ -744,6 +744,17 @@ __device__ __forceinline__ unsigned umod_tiny(unsigned a, unsigned g, float rg) 
   r = dn < r ? dn : r;   // q one too small
   return r;
 }
+// The same with a reciprocal scaled down by (1 - 2^-20), for 2 <= g < 2^20 and a < 2^20: rgl = v_rcp_f32(g) * (1 - 2^-20).
+// With x = a / g < 2^19 the estimate a * rgl is x (1 - d), d in [0.75, 1.25] * 2^-20 (reciprocal 1 ulp, two roundings):
+// below x, above x - 0.625 -- its floor is the quotient or one less, never more.  So a - q g is r or r + g and ONE unsigned
+// minimum picks r (seven instructions per entry instead of nine).
+__device__ __forceinline__ float rcp_low(unsigned g) { return __builtin_amdgcn_rcpf((float)g) * 0.99999904632568359375f; }
+__device__ __forceinline__ unsigned umod_tiny_low(unsigned a, unsigned g, float rgl) {
+  const unsigned q = (unsigned)((float)a * rgl);
+  const unsigned r = a - __umul24(q, g);
+  const unsigned dn = r - g;
+  return dn < r ? dn : r;
+}
 
 // The same row update when every operand is small: the row's and the pivot row's entries below
 // 2^15 (magnitude class 0) and |lpiv|, |foo|, |dpiv| < 2^15.  Then every product is below 2^30 and
@@ -762,17 +773,18 @@ __device__ __forceinline__ bool small_reduce(int (&z)[NCH][2], unsigned mx, i64 
       unsigned g = (unsigned)g64;
       // every |z| and g below 2^20 (the rule on this path): remainders through a float reciprocal of the wave-uniform
       // g -- five full-rate instructions and two corrections per entry instead of the 32-bit division sequence
-      const bool tiny = g != 0 && g < (1u << 20) && ballot64((mx >> 20) != 0) == 0;
+      // (g == 1 -- a denominator product of -1 -- takes the division path below: a % 1; inside the loop g >= 2)
+      const bool tiny = g >= 2 && g < (1u << 20) && ballot64((mx >> 20) != 0) == 0;
       for (;;) {
         unsigned rr = 0;
         if (tiny) {
-          const float rg = __builtin_amdgcn_rcpf((float)g);
+          const float rgl = rcp_low(g);
 #pragma unroll
           for (int c = 0; c < NCH; c++)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
               const unsigned a = (unsigned)(z[c][h] < 0 ? -z[c][h] : z[c][h]);
-              rr = rr ? rr : umod_tiny(a, g, rg);
+              rr = rr ? rr : umod_tiny_low(a, g, rgl);
             }
         } else {
 #pragma unroll
