@@ -16,7 +16,8 @@ regs = sorted((bench.timed(ol, 8 * od * fuse, od, barrier) for _ in range(3)), k
 dt, sh = regs[1]
 t = ol.totals(sh)
 o1 = bench.Lanes(oc, 1, dev, 0, [2000], args)
-dt1, sh1 = bench.timed(o1, 12, 2, barrier)
+n1 = int(os.environ.get("LONE_STEPS", "12"))
+dt1, sh1 = bench.timed(o1, n1, 2, barrier)
 t1 = o1.totals(sh1)
 print("round %d rows %d: " % (args.round, args.round_rows), end="")
 print("%s lib %s: %.1f M pivots/s with %d lanes (fuse %d), %.2f M one batch at a time; %s" % (oc["key"], os.path.basename(bench.__dict__.get("x", "") or os.environ.get("PIPAMD_LIB", "libpipamd.so")), t[0] / dt / 1e6, od, fuse, t1[0] / dt1 / 1e6, ol.status_histogram()))
