@@ -28,6 +28,9 @@
 #ifndef PIP_LEAN_PF
 #define PIP_LEAN_PF 2  // rows of a pivot's work list in flight
 #endif
+#ifndef PIP_LEAN_RECYCLE_FIRST
+#define PIP_LEAN_RECYCLE_FIRST 1  // (A/B switch) the recycled pivot slot is rewritten while the first work rows are in flight
+#endif
 #ifndef PIP_LEAN_WAVES
 #define PIP_LEAN_WAVES 8  // waves per SIMD the kernel is bounded to (64 VGPRs)
 #endif
@@ -550,6 +553,17 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         sq[q2] = S.work[q2 < nwork ? q2 : 0];
         if (q2 < nwork && sq[q2] != pslot) row_load32p(rq[q2], vals + (size_t)sq[q2] * W, lane, W);
       }
+#if PIP_LEAN_RECYCLE_FIRST
+      {
+        // while the first rows are on their way: the pivot slot is recycled for the row replacing ku's unit row
+        // (traiter.c:461-465,503-513) -- it needs no load, the pivot row is in registers
+        RowRegs32<1> r;
+#pragma unroll
+        for (int h = 0; h < 2; h++) r.v[0][h] = (2 * lane + h == pivj) ? (int)dpiv : -pr.v[0][h];
+        row_store32p(r, vals + (size_t)pslot * W, lane, W);
+        mcw = max(mcw, lean_publish(r, S, cst, pslot, pivj, pred, lane, nvar));
+      }
+#endif
       for (int w = 0; w < nwork; w++) {
         const int s = sq[0];
         RowRegs32<1> r = rq[0];
@@ -564,6 +578,9 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         }
         T *row = vals + (size_t)s * W;
         {
+#if PIP_LEAN_RECYCLE_FIRST
+          if (s == pslot) continue;
+#else
           if (s == pslot) {
             // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
 #pragma unroll
@@ -572,6 +589,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
             mcw = max(mcw, lean_publish(r, S, cst, s, pivj, pred, lane, nvar));
             continue;
           }
+#endif
           // multipliers from the row's own pivot-column entry (traiter.c:470-476); everything below 2^15
           int foo = __builtin_amdgcn_readlane(r.v[0][0], pl) * (1 - pe) + __builtin_amdgcn_readlane(r.v[0][1], pl) * pe;
           const T den_s = uni64(S.den[s]);
