@@ -698,8 +698,10 @@ def main():
         out["other_scaling"] = other
     traffic, traffic_src = None, None
     t, src = profile_json("r03_pmc_hbm.json", "r02_pmc_hbm.json")
+    step_traffic = None
     if t and t.get("batch_per_gpu") == my_batch:
         traffic, traffic_src = t["hbm_bytes_per_step"], src
+        step_traffic = traffic
     c0 = b.counters()
     issue, issue_src = profile_json("r03_pmc_issue.json")
     split = None
@@ -708,8 +710,12 @@ def main():
             split = launch_split(b, e, cfg, parts0)
         except Exception as ex:
             split = {"error": repr(ex)}
+    # `roofline` is about the dominant launch: its own counter figure where the profile has one (the lean launch)
+    if (isinstance(split, list) and split and "pip_lean_kernel" in max(split, key=lambda l: l["pivots"])["launch"]
+            and t and t.get("batch_per_gpu") == my_batch and t.get("lean_launch")):
+        traffic = t["lean_launch"]["hbm_bytes"]
     out["roofline"] = roofline_of(b, e, k_ms, cfg, split=split, extra={
-        "traffic": traffic,
+        "traffic": traffic, "traffic_of_all_pivot_launches_of_a_step": step_traffic,
         "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command with --pipeline 1; "
                            "read from the file, not measured in this run)") if traffic_src else None,
         "launches": split,

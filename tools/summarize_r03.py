@@ -50,6 +50,13 @@ f, w = hbm("")
 # same batch, the mean over them is the step)
 rd, wr = 2 * 1024 * sum(s[0] for s in f) / len(f), 1024 * sum(s[0] for s in w) / len(w)
 out.update({"hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr, "hbm_bytes_per_step": rd + wr, "steps_seen": [len(f), len(w)]})
+# the lean launch alone (the dominant kernel of bench.py's `roofline`)
+fl = per_step(one("p3_fetch/*/*counter_collection.csv"), "FETCH_SIZE", kernel=("pip_lean_kernel",))
+wl = per_step(one("p3_write/*/*counter_collection.csv"), "WRITE_SIZE", kernel=("pip_lean_kernel",))
+if fl and wl:
+    rdl, wrl = 2 * 1024 * sum(s[0] for s in fl) / len(fl), 1024 * sum(s[0] for s in wl) / len(wl)
+    out["lean_launch"] = {"hbm_read_bytes": rdl, "hbm_write_bytes": wrl, "hbm_bytes": rdl + wrl,
+                          "kernel_ms_under_the_counter_pass": sum(s[1] for s in fl) / len(fl)}
 # dense mode: the NOSKIP launches are the long four-wave ones (>= 8 ms)
 fd = per_step(one("p3_dense_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
 wd = per_step(one("p3_dense_write/*/*counter_collection.csv"), "WRITE_SIZE")
