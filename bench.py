@@ -194,7 +194,7 @@ class Lanes:
     small batches), loaded part by part with pipamd_batch_load_part into one workspace: one launch sequence per G
     steps; such a pass counts as G steps."""
 
-    def __init__(self, cfg, depth, dev, local, seeds, args, gen=None, threads=False, fuse=1):
+    def __init__(self, cfg, depth, dev, local, seeds, args, gen=None, threads=False, fuse=1, passes=None):
         import torch
         from piplib_amd import engine as eng
         from piplib_amd import synth
@@ -203,6 +203,11 @@ class Lanes:
         self.lanes, self.batches = [], []
         self.screened = {}  # seed -> indices of the tableaux replaced (slow-converging cuts)
         self.next_step = 0  # steps handed out so far (the batches take turns across timed regions)
+        # Few launch sequences in flight, or a run so short that every sequence has a lane to itself: nothing runs beside a
+        # sequence's middle launch for long, so the engines run in their lone-batches mode (pipamd_engine_set_lone_batches).
+        # One MI355X, 96 steps of 10k tableaux: 2 lanes 234 -> 281 M pivots/s, 4 lanes 404 -> 393 M, 6 lanes 496 -> 432 M;
+        # 20 steps of 1,250-tableau shards, five per sequence on 4 lanes: 265 -> 330 M.
+        self.lone = depth <= 3 or (passes is not None and passes <= depth <= 5)
         gen = gen or (lambda seed: synth.lexmin_batch(seed, cfg["batch"], cfg["nvar"], cfg["ni"], **cfg["gen"]))
         # the input rows stay resident and untouched in HBM for the whole run: T_ROWS_STAY lets the first pivot
         # launch read them where they are instead of a copy pass (--copy-rows switches that off)
@@ -236,13 +241,13 @@ class Lanes:
                 e.set_round_pivots(args.round)
             if args.round_rows:
                 e.set_round_rows(args.round_rows)
-            # a lone batch is latency-bound in its tail: eight waves per tableau there (+8 % for one batch
-            # at a time, -3 % with 12 in flight, where the waves of a tail crowd out other batches' bulk)
-            tw = getattr(args, "tail_waves", 0) or (8 if depth == 1 and cfg["ebits"] == 64 and cfg["nvar"] + 1 <= 128
+            # a lone batch is latency-bound in its tail: eight waves per tableau there (+8 % for one batch at a time, +3 %
+            # with two in flight, -8 % with five, -3 % with 12, where the waves of a tail crowd out other batches' bulk)
+            tw = getattr(args, "tail_waves", 0) or (8 if depth <= 3 and cfg["ebits"] == 64 and cfg["nvar"] + 1 <= 128
                                                     and shape[0] >= 2048 else 0)
             if tw:
                 e.set_tail_waves(tw)
-            if depth == 1 and getattr(args, "lone", -1) != 0:
+            if self.lone and getattr(args, "lone", -1) != 0:
                 e.set_lone_batches(True)
             # safety net: a tableau that escaped the screening ends PIPAMD_ST_CAPACITY (and voids the line) instead of
             # growing for minutes
@@ -487,13 +492,15 @@ def profile_json(*names):
 def pick_fuse(shard, steps, target=10000):
     """How many batches (or shards) of `shard` tableaux share one workspace and launch sequence: about `target`
     tableaux per sequence (one MI355X, 1,250-tableau shards, 192 steps: 4 per sequence 454 M pivots/s, 8: 502 M,
-    20: 501 M), as a divisor of the step count where one is near, so that a short run is whole passes (the
-    driver's 20 steps at 1,250: 4 per sequence 211 M, 8 -- three passes, 24 steps -- 215 M, 10: 267 M, 20: 244 M)."""
+    20: 501 M), as a divisor of the step count where one is near -- the nearest one below, else the nearest above --
+    so that a short run is whole passes with a lane each (the driver's 20 steps at 1,250, lanes in lone-batches mode:
+    4 per sequence 268 M, 5: 330 M, 10: 315 M; 8 -- three passes, 24 steps -- 215 M)."""
     f0 = max(1, min(16, target // max(1, shard)))
     if f0 == 1 or steps % f0 == 0:
         return f0
-    near = [d for d in range(max(1, f0 // 2), min(16, 2 * f0) + 1) if steps % d == 0]
-    return min(near, key=lambda d: (abs(d - f0), -d)) if near else f0
+    below = [d for d in range(max(1, (f0 + 1) // 2), f0) if steps % d == 0]
+    above = [d for d in range(f0 + 1, min(16, 2 * f0) + 1) if steps % d == 0]
+    return max(below) if below else (min(above) if above else f0)
 
 
 def kernel_ms_of(b, parts=None, reps=2):
@@ -605,7 +612,8 @@ def main():
             # batch i of rank r: seed 1000 + r + 7919 * i
             seeds = [pdist.shard_seed(1000, rank) + 7919 * i for i in range(depth)]
             gen = None
-        return cfg, Lanes(cfg, depth, dev, local, seeds, args, gen, threads=threads, fuse=fuse), depth, seeds, gen
+        return cfg, Lanes(cfg, depth, dev, local, seeds, args, gen, threads=threads, fuse=fuse,
+                          passes=(args.steps + fuse - 1) // fuse), depth, seeds, gen
 
     progress("building the lanes")
     cfg, lanes, depth, seeds, gen = build_lanes(args.scaling, args.threads)

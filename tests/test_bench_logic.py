@@ -26,8 +26,8 @@ def test_pick_fuse_targets_ten_thousand_tableaux_in_whole_passes():
     assert bench.pick_fuse(10000, 20) == 1
     assert bench.pick_fuse(5000, 20) == 2 and bench.pick_fuse(2500, 20) == 4
     assert bench.pick_fuse(1250, 192) == 8 and bench.pick_fuse(1250, 96) == 8
-    # the driver's 20 steps at the N = 8 shard size: a divisor of the step count near 8 (two passes of ten)
-    assert bench.pick_fuse(1250, 20) == 10
+    # the driver's 20 steps at the N = 8 shard size: the nearest divisor of the step count below 8 (four passes of five)
+    assert bench.pick_fuse(1250, 20) == 5
     for shard in (1, 7, 300, 1250, 3334, 9999, 10000, 50000):
         for steps in (1, 5, 7, 20, 96):
             f = bench.pick_fuse(shard, steps)
