@@ -465,6 +465,10 @@ def launch_split(b, e, cfg, parts):
                      lean["finished"]))
         legs.append(("general bulk (pip_advance_kernel, one wave per tableau) over what the lean launch left", ms[1],
                      bulk["pivots"] - lean["pivots"], bulk["rows_rewritten"] - lean["rows_rewritten"], bulk["finished"] - lean["finished"]))
+    elif cfg["ebits"] == 64 and cfg["nvar"] <= 127 and cfg["ni"] + (48 if cfg["integer"] else 0) <= 160:
+        # (an engine in lone-batches mode: the lean launch is the whole bulk stage)
+        legs.append(("lean bulk (pip_lean_kernel, one wave per tableau, int rows)", ms[0], bulk["pivots"], bulk["rows_rewritten"],
+                     bulk["finished"]))
     else:
         legs.append(("bulk (pip_advance_kernel, one wave per tableau)", ms[0], bulk["pivots"], bulk["rows_rewritten"], bulk["finished"]))
     legs.append(("tail (pip_advance_kernel, four waves per tableau, %d launch%s)" % (n - nb, "" if n - nb == 1 else "es"), sum(ms[nb:]),
