@@ -22,7 +22,13 @@ Multi-GPU (--gpus N > 1): BASELINE configs[3] -- every 10k-tableau batch is shar
 one workspace (pipamd_batch_load_part) so that one launch sequence serves ~10,000 tableaux whatever N (pick_fuse);
 RCCL only sums the totals here (the results gather is piplib_amd.dist.gather_results).  The
 weak-scaling figure (10k tableaux per GPU and batch) is measured as well and reported as
-`other_scaling`.
+`other_scaling`.  `python bench.py --gpus N` on its own starts the N ranks itself (a child
+`python -m torch.distributed.run`, before this process touches the GPU); under a launcher the world size must be N.
+
+What is timed is checked: which tableaux are left out of a batch (slow-converging cuts) comes from a committed list
+made by the CPU oracle (tests/golden/bench_screen.json), the engine must agree with it, the pivots of the pre-pass
+must be the oracle's, and after every timed region the status / pivot arrays the lanes fetched are reduced on the
+device and compared with the pre-pass (`regions_checked`).  A mismatch voids the line (exit code 3).
 
 Prints ONE JSON line (rank 0).
 """
@@ -42,17 +48,52 @@ STATUS_NAMES = {0: "run", 1: "solution", 2: "nil", 3: "need_compa", 4: "need_par
                 7: "range", 8: "internal", 9: "maxcol"}
 
 # name, tableaux per batch, unknowns, rows, integer solve?, entry bits, generator keywords
+# batch g of a family is synth.lexmin_batch(seed_base + 7919 * g, ...) (see batch_rows)
 MAIN = dict(key="configs[2]", workload="10k-batch synthetic 64x128 tableaux, int64, integer solve with Gomory cuts",
-            batch=10000, nvar=127, ni=64, integer=True, ebits=64, gen={})
+            batch=10000, nvar=127, ni=64, integer=True, ebits=64, gen={}, seed_base=1000, screen="bench_screen")
 OTHERS = [
     dict(key="configs[1]", workload="1k-batch synthetic 32x64 tableaux, int64, rational (non-integer) solve",
-         batch=1000, nvar=63, ni=32, integer=False, ebits=64, gen={}),
-    # coefficients up to 30 in up to 6 columns per row: the determinant limbs of the int64 build overflow
-    # on these ("Integer overflow", traiter.c:424,442), the 128-bit Entier build solves them
-    dict(key="configs[4]", workload="1k-batch synthetic 128x256 tableaux, 128-bit Entier, integer solve "
-                                    "(inputs on which the int64 build stops with 'Integer overflow')",
-         batch=1000, nvar=255, ni=128, integer=True, ebits=128, gen=dict(nnz=6, cmax=30)),
+         batch=1000, nvar=63, ni=32, integer=False, ebits=64, gen={}, seed_base=2000, screen=None),
+    # The batch tests/test_gpu_parity.py::test_full_size_int128_config holds, tableau by tableau, against the outputs of
+    # the reference's own GMP build (tests/golden/gmp/wide128.json): up to 16 non-zeros of magnitude <= 30 per row, 587 of
+    # the 1,000 tableaux form entries beyond 2^63 (the int64 build stops with "Integer overflow" or wraps on them).
+    # Every lane solves this one batch.
+    dict(key="configs[4]", workload="1k-batch synthetic 128x256 tableaux, 128-bit Entier, integer solve: the `wide128` "
+                                    "family pinned by tests/golden/gmp/wide128.json (587 of 1,000 tableaux leave 64 bits)",
+         batch=1000, nvar=255, ni=128, integer=True, ebits=128, gen=dict(nnz=16, cmax=30), family="wide128",
+         screen="wide128", screen_cuts=1024, max_rows=128 + 1280),  # every one of them finishes within 1,024 cuts
 ]
+SCREEN_CUTS = 448  # a tableau on which integrer() asks for more constant cuts than this (cfg["screen_cuts"]) is left out
+
+
+def screen_records(name):
+    """tests/golden/bench_screen.json, made by the CPU oracle (tests/golden/make_bench_screen.py): batch index ->
+    {slow, unfinished, pivots_screened}; {} when the file did not travel"""
+    path = os.path.join(ROOT, "tests", "golden", "bench_screen.json")
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return {}
+    return doc.get("batches" if name == "bench_screen" else name, {})
+
+
+def batch_rows(cfg, g):
+    """the whole batch g of a workload as a host array (batch, ni, nvar + 1), before anything is screened"""
+    from piplib_amd import synth
+    if cfg.get("family") == "wide128":
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import make_bigint_fixtures as mk
+        return mk.rows_full("wide128")
+    return synth.lexmin_batch(cfg["seed_base"] + 7919 * g, cfg["batch"], cfg["nvar"], cfg["ni"], **cfg["gen"])
+
+
+def replacement(b, slow, n):
+    """the tableau that stands in for slow tableau b: the next one (cyclically) that is not slow itself"""
+    return next(x % n for x in range(b + 1, b + n) if x % n not in slow)
+
+
+class VoidLine(Exception):
+    """the workload that was timed is not the workload the line names: the line is void"""
 
 
 def cpu_baseline(rows, nvar, ni):
@@ -194,44 +235,86 @@ class Lanes:
     small batches), loaded part by part with pipamd_batch_load_part into one workspace: one launch sequence per G
     steps; such a pass counts as G steps."""
 
-    def __init__(self, cfg, depth, dev, local, seeds, args, gen=None, threads=False, fuse=1, passes=None):
+    def __init__(self, cfg, depth, dev, local, gids, args, shard=None, threads=False, fuse=1, passes=None):
+        """gids: per lane the `fuse` batch indices of the workload its workspace holds (batch_rows(cfg, g));
+        shard = (lo, hi): this rank's slice of every batch (strong scaling)"""
+        import numpy as np
         import torch
         from piplib_amd import engine as eng
-        from piplib_amd import synth
         self.torch, self.eng, self.cfg, self.dev, self.depth = torch, eng, cfg, dev, depth
         self.threads, self.fuse = threads, fuse
         self.lanes, self.batches = [], []
-        self.screened = {}  # seed -> indices of the tableaux replaced (slow-converging cuts)
+        self.screened = {}      # batch index -> indices of the tableaux replaced (slow-converging cuts)
+        self.screen_source = {}  # batch index -> who said so
+        self.want = []          # per lane batch: what the oracle says about it (None: no record)
         self.next_step = 0  # steps handed out so far (the batches take turns across timed regions)
+        self.last_of_lane = {}  # lane -> the batch its arrays hold (set by the runners)
+        self.checked_passes = 0
         # Few launch sequences in flight, or a run so short that every sequence has a lane to itself: nothing runs beside a
         # sequence's middle launch for long, so the engines run in their lone-batches mode (pipamd_engine_set_lone_batches).
         # One MI355X, 96 steps of 10k tableaux: 2 lanes 234 -> 281 M pivots/s, 4 lanes 404 -> 393 M, 6 lanes 496 -> 432 M;
         # 20 steps of 1,250-tableau shards, five per sequence on 4 lanes: 265 -> 330 M.
         self.lone = depth <= 3 or (passes is not None and passes <= depth <= 5)
-        gen = gen or (lambda seed: synth.lexmin_batch(seed, cfg["batch"], cfg["nvar"], cfg["ni"], **cfg["gen"]))
         # the input rows stay resident and untouched in HBM for the whole run: T_ROWS_STAY lets the first pivot
         # launch read them where they are instead of a copy pass (--copy-rows switches that off)
         stay = 0 if getattr(args, "copy_rows", False) else eng.T_ROWS_STAY
         tf = (eng.T_INT if cfg["integer"] else 0) | stay
         screen_engine = eng.Engine(local)
+        records = screen_records(cfg["screen"]) if cfg.get("screen") else {}
+        full_batch = cfg["batch"]
+        lo, hi = shard if shard else (0, full_batch)
+        cache = {}
 
-        def resident(seed):
-            """a batch in HBM; integer workloads: without the tableaux on which Gomory's cuts do not converge (about 3
-            in 100,000: the reference itself does not finish them within minutes), replaced by their neighbours -- see
-            piplib_amd.engine.slow_converging"""
-            t = torch.as_tensor(gen(seed), dtype=torch.int64).to(dev).contiguous()
-            if cfg["integer"] and cfg.get("screen", True) and t.shape[0] > 1:
-                bad = eng.slow_converging(screen_engine, t, cfg["nvar"], entier_bits=cfg["ebits"])
-                for b_ in bad:
-                    nb = next(x % t.shape[0] for x in range(b_ + 1, b_ + t.shape[0]) if x % t.shape[0] not in bad)
-                    t[b_] = t[nb]
-                if bad:
-                    self.screened[seed] = bad
-            return t
+        def resident(g):
+            """This rank's part of batch g in HBM.  Integer workloads: without the tableaux on which Gomory's cuts do not
+            converge (about 3 in 100,000: integrer() asks for more than SCREEN_CUTS constant cuts; the reference itself
+            does not finish them within minutes), replaced by their neighbours.  Which ones is the CPU oracle's verdict
+            (tests/golden/bench_screen.json); the engine solves the unscreened part under the same row budget and
+            must leave exactly those at PIPAMD_ST_CAPACITY, else the line is void.  A batch the file has no record of
+            (another --batch) is screened by the engine alone and the line says so."""
+            if g in cache:
+                return cache[g]
+            rows = batch_rows(cfg, g)
+            assert rows.shape[0] == full_batch
+            rec = records.get(str(g)) if rows.shape[0] == full_batch else None
+            want = None
+            if cfg["integer"] and rows.shape[0] > 1:
+                mine = torch.as_tensor(rows[lo:hi], dtype=torch.int64).to(dev).contiguous()
+                ncuts = cfg.get("screen_cuts", SCREEN_CUTS)
+                bad = [b_ + lo for b_ in eng.slow_converging(screen_engine, mine, cfg["nvar"], cut_rows=ncuts,
+                                                            entier_bits=cfg["ebits"])]
+                del mine
+                if rec is not None:
+                    slow = sorted(rec["slow"])
+                    if bad != [b_ for b_ in slow if lo <= b_ < hi]:
+                        raise VoidLine(f"{cfg['key']} batch {g}: the engine leaves tableaux {bad} at PIPAMD_ST_CAPACITY under a budget "
+                                       f"of {ncuts} cuts, the oracle's list (tests/golden/bench_screen.json) says {slow}")
+                    src = "tests/golden/bench_screen.json (CPU oracle)"
+                    want = rec
+                    rows = rows.copy()
+                    for b_ in slow:
+                        rows[b_] = rows[replacement(b_, set(slow), full_batch)]
+                    rows = rows[lo:hi]
+                else:
+                    src = "the engine itself (no oracle record for this batch)"
+                    slow = bad
+                    rows = rows[lo:hi].copy()
+                    for b_ in slow:
+                        rows[b_ - lo] = rows[replacement(b_ - lo, {x - lo for x in slow}, hi - lo)]
+                if slow:
+                    self.screened[g] = slow
+                self.screen_source[g] = src
+            else:
+                rows = rows[lo:hi]
+            cache[g] = (torch.as_tensor(np.ascontiguousarray(rows), dtype=torch.int64).to(dev).contiguous(), want)
+            return cache[g]
 
         for i in range(depth):
             # G row arrays (the shards of G different batches, or G small batches) per batch of the lanes
-            self.batches.append([resident(seeds[i] + 104729 * k) for k in range(fuse)])
+            got = [resident(g) for g in gids[i]]
+            self.batches.append([t for t, _ in got])
+            self.want.append([w for _, w in got])
+        self.gids = gids
         shape = (sum(p_.shape[0] for p_ in self.batches[0]),) + tuple(self.batches[0][0].shape[1:])
         for i in range(depth):
             e = eng.Engine(local)
@@ -262,20 +345,68 @@ class Lanes:
             b = eng.Batch(e, None, cfg["nvar"], 0, tflags=tf, entier_bits=cfg["ebits"], shape=shape)
             self.lanes.append((e, b, lane_stream(torch, dev, i)))
         # what one solve of each batch does (pivots, cuts, rows rewritten, tableaux, finished tableaux) and how it ends:
-        # every batch once through lane 0
-        self.per_batch, self.hist = [], {}
+        # every batch once through lane 0 -- the pre-pass.  Its per-tableau arrays are reduced on the device: `sums` =
+        # (sum of the pivot counts, sum of the cut counts, histogram of the statuses) is what every later solve of the
+        # batch must reproduce (check_lanes), and the pivots of the tableaux that finished must be the oracle's.
+        self.per_batch, self.hist, self.sums, self.fin_piv, self.want_piv = [], {}, [], [], []
+        self.oracle_checked = 0
         e0, b0, _ = self.lanes[0]
-        for parts in self.batches:
+        for k, parts in enumerate(self.batches):
             b0.load_parts(parts)
             b0.solve()
             c = b0.counters()
             self.per_batch.append((c["pivots"], c["cuts"], c["rows_rewritten"], shape[0], c["finished"]))
             b0.fetch()
-            h = torch.bincount(b0.status.to(torch.int64), minlength=10).cpu().tolist()
-            for k, v in enumerate(h):
+            self.sums.append(self._reduce(b0))
+            h = self.sums[-1][2]
+            for st_, v in enumerate(h):
                 if v:
-                    self.hist[k] = self.hist.get(k, 0) + v
+                    self.hist[st_] = self.hist.get(st_, 0) + v
+            if self.sums[-1][0] != c["pivots"]:
+                raise VoidLine(f"{cfg['key']}: pipamd_batch_counters and the fetched pivot array disagree on batch {gids[k]}")
+            # the oracle's word on the batch that is timed: which tableaux do not finish, and the pivots of the others
+            done = (b0.status == eng.ST_SOLUTION) | (b0.status == eng.ST_NIL)
+            fin_piv = int((b0.pivots.to(torch.int64) * done).sum().item())
+            unfinished = torch.nonzero(~done).flatten().cpu().tolist()
+            self.fin_piv.append(fin_piv)
+            if all(w is not None for w in self.want[k]):
+                off, want_unf = 0, []
+                for w, part in zip(self.want[k], parts):
+                    want_unf += [off + x - lo for x in w.get("unfinished", []) if lo <= x < hi]
+                    off += part.shape[0]
+                want_piv = sum(w["pivots_screened"] for w in self.want[k])
+                self.want_piv.append(want_piv)
+                # (a rank that holds a shard of every batch can only check its share of the list; the pivots of the shards
+                # are summed over the ranks by the caller: oracle_pivot_check)
+                if unfinished != want_unf or (shard is None and fin_piv != want_piv):
+                    raise VoidLine(f"{cfg['key']} batches {gids[k]}: the engine finishes all but {unfinished[:8]} with {fin_piv} pivots, "
+                                   f"the oracle (tests/golden/bench_screen.json) all but {want_unf[:8]} with {want_piv}")
+                self.oracle_checked += 1
+            else:
+                self.want_piv.append(None)
         self.workers = None
+
+    def _reduce(self, b):
+        """(sum of pivots, sum of cuts, status histogram) of the arrays a lane's pipamd_batch_results filled, reduced on
+        the device"""
+        torch = self.torch
+        h = torch.bincount(b.status.to(torch.int64), minlength=10)
+        v = torch.cat([b.pivots.to(torch.int64).sum().reshape(1), b.cuts.to(torch.int64).sum().reshape(1), h]).cpu().tolist()
+        return v[0], v[1], v[2:]
+
+    def check_lanes(self):
+        """Outside the timed bracket: what every lane's last pass left in its status / pivot / cut arrays against the
+        pre-pass of the same batch.  Returns the number of passes checked; raises VoidLine on a difference."""
+        self.torch.cuda.synchronize(self.dev)
+        n = 0
+        for i, k in sorted(self.last_of_lane.items()):
+            got = self._reduce(self.lanes[i][1])
+            if got != self.sums[k]:
+                raise VoidLine(f"{self.cfg['key']}: lane {i} solved batch {self.gids[k]} in the timed region with (pivots, cuts, statuses) = "
+                               f"{got}, the pre-pass with {self.sums[k]}")
+            n += 1
+        self.checked_passes += n
+        return n
 
     def _take(self, npass):
         """the batches of the next `npass` steps"""
@@ -304,6 +435,7 @@ class Lanes:
                     if self.lanes[i][1].poll():
                         # solution(): status, pivot and cut counts and the solutions into the caller's arrays
                         self.lanes[i][1].fetch(self.lanes[i][2].cuda_stream)
+                        self.last_of_lane[i] = active[i]
                         done.append(active.pop(i))
                         start(i)
         return done
@@ -325,6 +457,7 @@ class Lanes:
                         bi.solve(st.cuda_stream)
                         bi.fetch(st.cuda_stream)
                         with lock:
+                            self.last_of_lane[i] = k
                             done.append(k)
             except BaseException as ex:  # surfaced below
                 failed.append(ex)
@@ -383,7 +516,9 @@ def timed(lanes, steps, warmup, barrier, stagger_arg=0):
     t0 = time.perf_counter()
     solved = lanes.run(steps)
     barrier()
-    return time.perf_counter() - t0, solved
+    dt = time.perf_counter() - t0
+    lanes.check_lanes()  # outside the bracket: the arrays the lanes fetched against the pre-pass
+    return dt, solved
 
 
 def timed_regions(lanes, steps, warmup, barrier, stagger_arg, n=3):
@@ -397,6 +532,7 @@ def timed_regions(lanes, steps, warmup, barrier, stagger_arg, n=3):
         share = lanes.run(steps)
         barrier()
         out.append((time.perf_counter() - t0, share))
+        lanes.check_lanes()  # outside the bracket: the arrays the lanes fetched against the pre-pass
     return sorted(out, key=lambda r: r[0])
 
 
@@ -426,6 +562,10 @@ def roofline_of(b, e, k_ms, cfg, extra=None, split=None):
                   "kernel": "the pivot launches of a step (pip_lean_kernel where the shape has one, pip_advance_kernel)"}, **step)
     if extra:
         r.update(extra)
+    if dom and r.get("traffic"):
+        # the same launch on the bytes the counters saw (int rows: fewer than the 8-byte convention of `achieved`)
+        r["achieved_counter_bytes"] = r["traffic"] / (dom["ms"] * 1e-3) / 1e9
+        r["frac_counter_bytes"] = r["achieved_counter_bytes"] / HBM_PEAK_GBS
     return r
 
 
@@ -520,6 +660,33 @@ def kernel_ms_of(b, parts=None, reps=2):
     return sum(ms) / len(ms)
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_command(ngpus, argv, port):
+    """the launcher `bench.py --gpus N` starts when nobody launched it: one rank per GPU of this node"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(ngpus, argv):
+    """`python bench.py --gpus N` without a launcher: N ranks as a CHILD process (this process has not touched the GPU and
+    never does; no exec), rank 0's JSON line passed through, the child's exit code returned"""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(spawn_command(ngpus, argv, free_port()), env=env)
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -555,6 +722,13 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-others", action="store_true", help="skip other_configs and pipeline1_value")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={os.environ.get('WORLD_SIZE')}: "
+                         "the line would be labelled with the wrong GPU count")
 
     # Batches in flight run on separate HIP streams; the runtime multiplexes streams onto
     # GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels that share a queue serialise, so
@@ -590,10 +764,9 @@ def main():
         args.scaling = "strong" if world > 1 else "weak"
 
     def build_lanes(scaling, threads=False):
-        """the lanes of one measurement: (cfg, lanes, depth, seeds, gen)"""
+        """the lanes of one measurement: (cfg, lanes, depth)"""
         cfg = dict(MAIN)
         cfg["batch"] = args.batch
-        fuse = 1
         if scaling == "strong":
             # BASELINE configs[3]: every 10k-tableau batch is sharded over the GPUs: a GPU holds 1/world of every
             # batch in flight.  The shards are independent tableaux, so a rank loads its shards of `fuse` batches
@@ -603,37 +776,66 @@ def main():
             shard = max(1, (args.batch + world - 1) // world)
             fuse = args.fuse if args.fuse > 0 else pick_fuse(shard, args.steps)
             depth = max(1, min(args.pipeline, (args.steps + fuse - 1) // fuse))
-            lo, hi = pdist.shard_range(args.batch, rank, world)
-            cfg["batch"] = hi - lo
-            seeds = [1000 + 7919 * i for i in range(depth)]
-
-            def gen(seed):
-                return synth.lexmin_batch(seed, args.batch, cfg["nvar"], cfg["ni"])[lo:hi]
+            span = pdist.shard_range(args.batch, rank, world)
+            # lane i holds this rank's shards of batches i * fuse .. i * fuse + fuse - 1 (the same on every rank)
+            gids = [[i * fuse + k for k in range(fuse)] for i in range(depth)]
         else:
             # small batches (--batch below 2,500 per GPU) are fused the same way: a lane's workspace holds `fuse` of them
             fuse = args.fuse if args.fuse > 0 else pick_fuse(args.batch, args.steps)
             depth = max(1, min(args.pipeline, (args.steps + fuse - 1) // fuse))
-            # batch i of rank r: seed 1000 + r + 7919 * i
-            seeds = [pdist.shard_seed(1000, rank) + 7919 * i for i in range(depth)]
-            gen = None
-        return cfg, Lanes(cfg, depth, dev, local, seeds, args, gen, threads=threads, fuse=fuse,
-                          passes=(args.steps + fuse - 1) // fuse), depth, seeds, gen
+            span = None
+            # every rank has batches of its own: rank r takes batches r * depth * fuse ...
+            gids = [[(rank * depth + i) * fuse + k for k in range(fuse)] for i in range(depth)]
+        return cfg, Lanes(cfg, depth, dev, local, gids, args, shard=span, threads=threads, fuse=fuse,
+                          passes=(args.steps + fuse - 1) // fuse), depth
+
+    def oracle_pivot_check(ln):
+        """strong scaling: the pivots of the shards of a batch, summed over the ranks, against the oracle's count for the
+        batch; returns the number of lane batches checked (every rank calls this)"""
+        if not ln.want_piv or any(w is None for w in ln.want_piv):
+            return 0
+        got, _ = pdist.gather_totals(ln.fin_piv, 0.0, dev)
+        if rank == 0 and [int(x) for x in got] != ln.want_piv:
+            raise VoidLine(f"pivots of the sharded batches over all ranks {[int(x) for x in got]}, the oracle's {ln.want_piv}")
+        return len(got)
 
     progress("building the lanes")
-    cfg, lanes, depth, seeds, gen = build_lanes(args.scaling, args.threads)
+    try:
+        cfg, lanes, depth = build_lanes(args.scaling, args.threads)
+        oracle_batches = lanes.oracle_checked if args.scaling == "weak" else oracle_pivot_check(lanes)
+    except VoidLine as ex:
+        print(json.dumps({"error": "void: " + str(ex), "metric": "pivots/sec", "value": None}), flush=True)
+        raise SystemExit(3)
     progress(f"{depth} lanes ready; timing")
     my_batch = cfg["batch"]
     fuse = lanes.fuse
     e, b, _ = lanes.lanes[0]
 
     # three timed regions of --steps steps each; the median is the line's value, all three are printed
-    regions = timed_regions(lanes, args.steps, args.warmup, barrier, args.stagger)
+    try:
+        regions = timed_regions(lanes, args.steps, args.warmup, barrier, args.stagger)
+    except VoidLine as ex:
+        print(json.dumps({"error": "void: " + str(ex), "metric": "pivots/sec", "value": None}), flush=True)
+        raise SystemExit(3)
+    regions_checked_passes = lanes.checked_passes
     dt, share = regions[1]
     steps_done = len(share) * fuse   # == --steps unless shards are fused (whole passes of `fuse` steps)
     progress(f"regions {[round(r[0] * 1e3, 2) for r in regions]} ms")
     tot = lanes.totals(share)
     hist = lanes.status_histogram()
     screened0 = dict(lanes.screened)
+    screen_src0 = sorted(set(lanes.screen_source.values()))
+    gids0 = lanes.gids
+    # the same lanes over a longer run: the driver's 20 steps are one round of 16 batches that start together plus four
+    # stragglers (pipeline fill and drain); 96 steps show the rate of a steady stream of batches
+    steady = None
+    if args.steps < 96:
+        try:
+            sdt, sshare = timed(lanes, 96, 0, barrier)
+            sgt, sdt_max = pdist.gather_totals(lanes.totals(sshare), sdt, dev)
+            steady = {"value": sgt[0] / sdt_max, "steps": len(sshare) * fuse, "ms_per_step": sdt_max / (len(sshare) * fuse) * 1e3}
+        except VoidLine as ex:
+            steady = {"error": str(ex)}
 
     # the advance kernel's own launch durations (HIP events on its stream), un-overlapped
     parts0 = lanes.batches[0]
@@ -647,8 +849,14 @@ def main():
         lanes.close()
         del lanes
         torch.cuda.empty_cache()
-        cfg2, lanes2, depth2, _, _ = build_lanes(mode2, args.threads)
-        dt2, share2 = timed(lanes2, args.steps, args.warmup, barrier, args.stagger)
+        try:
+            cfg2, lanes2, depth2 = build_lanes(mode2, args.threads)
+            if mode2 == "strong":
+                oracle_pivot_check(lanes2)
+            dt2, share2 = timed(lanes2, args.steps, args.warmup, barrier, args.stagger)
+        except VoidLine as ex:
+            print(json.dumps({"error": "void (other_scaling): " + str(ex), "metric": "pivots/sec", "value": None}), flush=True)
+            raise SystemExit(3)
         gt2, dt2_max = pdist.gather_totals(lanes2.totals(share2), dt2, dev)
         other = {"scaling": mode2, "value": gt2[0] / dt2_max, "unit": "pivots/s",
                  "ms_per_step": dt2_max / (len(share2) * lanes2.fuse) * 1e3,
@@ -682,15 +890,28 @@ def main():
                                                      " sharded over the ranks (BASELINE configs[3])"),
                    "batch_per_gpu": my_batch, "nvar": cfg["nvar"], "nparm": 0, "ni": cfg["ni"],
                    "parallelism": f"{world} x independent batches (one workgroup per tableau)",
-                   "pipeline_depth": depth, "lane_seeds": "1000 + rank + 7919 * lane (strong: 1000 + 7919 * lane)",
+                   "pipeline_depth": depth,
+                   "batches": "batch g = synth.lexmin_batch(1000 + 7919 * g, ...); weak scaling: lane i of rank r holds batch "
+                              "r * lanes + i; strong: lane i holds every rank's shard of batches i * fuse .. i * fuse + fuse - 1",
+                   "rank0_batches": gids0,
                    "host_threads": depth if args.threads else 1,
                    "driver": "one host thread per lane, pipamd_batch_solve" if args.threads else
                              "one host thread, pipamd_batch_solve_async / pipamd_batch_wait",
                    "fused_batches_per_launch_sequence": fuse,
-                   "screened_out": {"what": "tableaux on which Gomory's cuts have not converged within 448 cut rows (the "
-                                            "reference does not finish them within minutes either), replaced by their "
-                                            "neighbours before anything is timed; seed -> indices",
+                   "screened_count": sum(len(v) for v in screened0.values()),
+                   "screened_by": "; ".join(screen_src0),
+                   "screened_out": {"what": "tableaux on which integrer() asks for more than 448 constant cuts (Gomory's cuts do "
+                                            "not converge: the reference does not finish them within minutes either), replaced "
+                                            "by their neighbours before anything is timed; batch -> indices (rank 0's lanes)",
                                     "rank0": {str(k): v for k, v in sorted(screened0.items())}}},
+        "rccl_ranks": pdist.world_size(), "backend": backend if world > 1 else None,
+        "regions_checked": regions_checked_passes > 0, "regions_checked_passes": regions_checked_passes,
+        "regions_checked_how": "after every timed region the status / pivot / cut arrays each lane's last pipamd_batch_results "
+                               "filled are reduced on the device (sums, status histogram) and compared with the pre-pass of "
+                               "the same batch; a difference voids the line",
+        "oracle_checked_batches": oracle_batches,
+        "oracle_checked_how": "pre-pass: the tableaux the engine leaves at PIPAMD_ST_CAPACITY under a 448-cut budget must be the CPU "
+                              "oracle's list and the pivots of each batch the oracle's count (tests/golden/bench_screen.json)",
         "steps_timed": steps_done,
         "regions_ms": [round(r[0] * 1e3, 3) for r in regions],
         "problems_per_sec": gt[3] / dt_max,
@@ -708,14 +929,17 @@ def main():
         raise SystemExit(3)
     if other:
         out["other_scaling"] = other
+    if steady:
+        out["steady_state_value"] = steady.get("value")
+        out["steady_state"] = steady
     traffic, traffic_src = None, None
-    t, src = profile_json("r03_pmc_hbm.json", "r02_pmc_hbm.json")
+    t, src = profile_json("r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json")
     step_traffic = None
     if t and t.get("batch_per_gpu") == my_batch:
         traffic, traffic_src = t["hbm_bytes_per_step"], src
         step_traffic = traffic
     c0 = b.counters()
-    issue, issue_src = profile_json("r03_pmc_issue.json")
+    issue, issue_src = profile_json("r04_pmc_issue.json", "r03_pmc_issue.json")
     split = None
     if fuse == 1:
         try:
@@ -736,6 +960,14 @@ def main():
         "measured": "HIP events around each launch, 2 un-pipelined steps after the timed region "
                     "(= `bench.py --pipeline 1`, the command of profiles/r02_kernel_stats.csv)",
         "timed_region_GBps_per_gpu": 8.0 * (cfg["nvar"] + 1) * (2.0 * gt[2] + 2.0 * gt[0]) / world / dt_max / 1e9,
+        # the regime that is timed (16 batches in flight), per GPU: algorithmic bytes at the reference's 8 bytes per entry,
+        # and the HBM bytes the counters saw for one step (the file's figure: int rows) over the measured time per step
+        "timed_region": {
+            "hbm_GBps_algorithmic": 8.0 * (cfg["nvar"] + 1) * (2.0 * gt[2] + 2.0 * gt[0]) / world / dt_max / 1e9,
+            "frac_algorithmic": 8.0 * (cfg["nvar"] + 1) * (2.0 * gt[2] + 2.0 * gt[0]) / world / dt_max / 1e9 / HBM_PEAK_GBS,
+            "hbm_GBps_counter_bytes": (step_traffic / (ms_step * 1e-3) / 1e9) if step_traffic else None,
+            "frac": (step_traffic / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
+            "counter_bytes_per_step": step_traffic, "counter_bytes_source": traffic_src},
         "dense_equivalent_GBps": b.pivot_bytes() * c0["pivots"] / (k_ms * 1e-3) / 1e9,
         "note": "sparse workload: ~2.7 of ~80 rows change per pivot, so the pivot loop is latency/issue-bound, "
                 "not HBM-bound; see roofline_dense_mode for the HBM-bound regime of the same kernel"})
@@ -775,7 +1007,7 @@ def main():
             del lanes
             torch.cuda.empty_cache()
             progress("one batch at a time")
-            one = Lanes(cfg, 1, dev, local, seeds[:1], args, gen)  # a fresh engine with its defaults for a lone batch
+            one = Lanes(cfg, 1, dev, local, [[0]], args)  # a fresh engine with its defaults for a lone batch
             n1 = max(8, min(24, args.steps))
             dt1, sh1 = timed(one, n1, 2, barrier, 0)
             t1 = one.totals(sh1)
@@ -793,7 +1025,13 @@ def main():
                 # workspace and a launch sequence (pipamd_batch_load_part), as the shards of a strong-scaling run do
                 # (5 per sequence 617 M pivots/s, 10: 651 M, 16: 662 M)
                 ofuse = max(1, min(16, 10000 // oc["batch"])) if oc["ebits"] == 64 else 1
-                ol = Lanes(oc, od, dev, local, [2000 + 7919 * i for i in range(od)], args, fuse=ofuse)
+                # (configs[4]: every lane holds the one pinned batch)
+                ogids = [[0] for _ in range(od)] if oc.get("family") else [[i * ofuse + k for k in range(ofuse)] for i in range(od)]
+                try:
+                    ol = Lanes(oc, od, dev, local, ogids, args, fuse=ofuse)
+                except VoidLine as ex:
+                    others.append({"config": oc["key"], "workload": oc["workload"], "error": "void: " + str(ex), "value": None})
+                    continue
                 osteps = 16 * od * ofuse
                 # The median of three timed regions: a region here is 35 ms to 1.4 s long, and the first region of a
                 # fresh set of lanes came out 2-3x slower than every later one on configs[1] (cause not found).
@@ -803,7 +1041,7 @@ def main():
                 ot = ol.totals(osh)
                 oe, ob, _ = ol.lanes[0]
                 okm = kernel_ms_of(ob, ol.batches[0])
-                o1 = Lanes(oc, 1, dev, local, [2000], args)
+                o1 = Lanes(oc, 1, dev, local, [[0]], args)
                 odt1, osh1 = timed(o1, 16, 2, barrier, 0)
                 ot1 = o1.totals(osh1)
                 others.append({
@@ -813,6 +1051,8 @@ def main():
                     "regions_ms": [round(r[0] * 1e3, 3) for r in regions], "problems_per_sec": ot[3] / odt, "pivots_per_step": ot[0] / osteps,
                     "finished_fraction": ot[4] / max(1, ot[3]),
                     "status_histogram": {STATUS_NAMES.get(k, str(k)): v for k, v in sorted(ol.status_histogram().items())},
+                    "regions_checked": ol.checked_passes > 0, "oracle_checked_batches": ol.oracle_checked,
+                    "screened_count": sum(len(v) for v in ol.screened.values()),
                     "pipeline1_value": ot1[0] / odt1, "pipeline1_ms_per_step": odt1 / 16 * 1e3,
                     "roofline": roofline_of(ob, oe, okm, oc)})
                 ol.close()
@@ -831,7 +1071,7 @@ def main():
 
     if not args.no_cpu and world == 1:  # the CPU baseline belongs to the one-GPU line
         progress("cpu baseline")
-        rows_h = gen(seeds[0]) if gen else synth.lexmin_batch(seeds[0], args.batch, cfg["nvar"], cfg["ni"])
+        rows_h = batch_rows(cfg, 0)  # (batch 0 has no slow-converging tableau)
         cb = cpu_baseline(rows_h, cfg["nvar"], cfg["ni"])
         if cb:
             out["cpu_baseline"] = cb

@@ -106,6 +106,7 @@ struct ora {
   int ncell;
   int deepest;
   long long pivots, cuts;
+  long long max_cuts; /* checker-side budget (ORACLE_MAX_CUTS, 0 = none): see ORA_ERR_BUDGET */
   jmp_buf trap;
   int trapcode;
 };
@@ -661,6 +662,9 @@ static int gomory(ora *o, otab *tp, otab *cx, int *pnvar, int *pnparm, int *pni,
         t = e_sub(D, t);
         cut[nvar] = e_neg(t);
       }
+      /* not the reference's: a budget of constant cuts for the screening of benchmark batches
+       * (tests/golden/make_bench_screen.py); the reference grows without bound here */
+      if (o->max_cuts > 0 && o->cuts >= o->max_cuts) fail(o, ORA_ERR_BUDGET);
       tab_reserve(o, tp, nligne, tp->width);
       nr = &tp->row[nligne];
       nr->flag = OF_MINUS;
@@ -788,7 +792,12 @@ static void simplify_rows(otab *t, int cst) {
 }
 
 /* ------------------------------------------------------------------- public */
-ora *ora_new(void) { return calloc(1, sizeof(ora)); }
+ora *ora_new(void) {
+  ora *o = calloc(1, sizeof(ora));
+  const char *b = getenv("ORACLE_MAX_CUTS");
+  if (o && b) o->max_cuts = atoll(b);
+  return o;
+}
 void ora_free(ora *o) {
   if (!o) return;
   a_reset(o, 0);

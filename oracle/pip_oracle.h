@@ -47,7 +47,9 @@ enum {
   ORA_ERR_SOLSIZE = 5,   /* "The solution is too complex", sol.c:97 (exit 26) */
   ORA_ERR_ASSERT = 6,    /* assert(ok_var), integrer.c:499 */
   ORA_ERR_INTERNAL = 7,
-  ORA_ERR_NOPIVOT = 8
+  ORA_ERR_NOPIVOT = 8,
+  ORA_ERR_BUDGET = 9     /* not the reference's: more constant cuts than the environment's ORACLE_MAX_CUTS allows
+                            (the screening of benchmark batches, tests/golden/make_bench_screen.py) */
 };
 
 typedef struct ora_cell {

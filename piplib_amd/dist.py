@@ -121,9 +121,57 @@ def solve_sharded(rows, nvar, nparm=0, tflags=1, entier_bits=64, device=None, en
     return gather_results(parts, total, gdev)
 
 
+def solve_sharded_fused(batches, nvar, nparm=0, tflags=1, entier_bits=64, device=None, engine_device=None):
+    """Several batches over all ranks with ONE launch sequence per rank (BASELINE configs[3] as bench.py runs it): every
+    rank loads its shard_range slice of every batch into one workspace (pipamd_batch_load_part, one call per shard),
+    solves them together, and every batch's results are gathered to rank 0 in input order.  `batches`: a list of row
+    arrays of the same (ni, ncol).  Returns the list of result dicts on rank 0, None elsewhere."""
+    import torch
+    from piplib_amd import engine as eng
+    rank, world, local = env_rank()
+    if engine_device is None:
+        engine_device = local % max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", engine_device)
+    spans = [shard_range(int(r.shape[0]), rank, world) for r in batches]
+    parts = [torch.as_tensor(r[lo:hi], dtype=torch.int64).to(dev).contiguous() for r, (lo, hi) in zip(batches, spans)]
+    n = sum(hi - lo for lo, hi in spans)
+    ni, ncol = int(batches[0].shape[1]), int(batches[0].shape[2])
+    ew = (2,) if entier_bits == 128 else ()
+    with torch.cuda.device(dev):
+        if n > 0:
+            e = eng.Engine(engine_device)
+            b = eng.Batch(e, None, nvar, nparm, tflags=tflags, entier_bits=entier_bits, shape=(n, ni, ncol))
+            b.load_parts([p for p in parts if p.shape[0]])
+            b.solve()
+            b.fetch()
+            torch.cuda.synchronize(dev)
+            res = {"status": b.status, "pivots": b.pivots, "cuts": b.cuts, "sol_num": b.sol_num, "sol_den": b.sol_den}
+        else:
+            res = {"status": torch.zeros(0, dtype=torch.int32, device=dev), "pivots": torch.zeros(0, dtype=torch.int32, device=dev),
+                   "cuts": torch.zeros(0, dtype=torch.int32, device=dev),
+                   "sol_num": torch.zeros((0, nvar, nparm + 1) + ew, dtype=torch.int64, device=dev),
+                   "sol_den": torch.zeros((0, nvar) + ew, dtype=torch.int64, device=dev)}
+    import torch.distributed as dist
+    gdev = dev if (device is None and _active() and dist.get_backend() == "nccl") else (device or "cpu")
+    out, off = [], 0
+    for r, (lo, hi) in zip(batches, spans):
+        mine = {k: v[off:off + hi - lo] for k, v in res.items()}
+        off += hi - lo
+        out.append(gather_results(mine, int(r.shape[0]), gdev))
+    return out if rank == 0 or not _active() else None
+
+
 def _active():
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    """ranks of the initialised process group (1 without one)"""
+    if _active():
+        import torch.distributed as dist
+        return dist.get_world_size()
+    return 1
 
 
 def barrier():

@@ -32,3 +32,38 @@ def test_pick_fuse_targets_ten_thousand_tableaux_in_whole_passes():
         for steps in (1, 5, 7, 20, 96):
             f = bench.pick_fuse(shard, steps)
             assert 1 <= f <= 16 and (f * shard <= 2 * 10000 or f == 1)
+
+
+def test_gpus_n_spawns_one_rank_per_gpu_on_localhost():
+    cmd = bench.spawn_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29555)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert 1024 < bench.free_port() < 65536
+
+
+def test_screen_list_comes_from_the_oracle_and_names_the_known_tableaux():
+    """tests/golden/bench_screen.json (CPU oracle, ORACLE_MAX_CUTS=448): 128 batches of the headline workload; the three
+    slow-converging tableaux round 3 found with the engine are in it, found without it"""
+    rec = bench.screen_records("bench_screen")
+    assert len(rec) == 128 and all(set(r) >= {"seed", "slow", "pivots_screened", "pivots_finishing"} for r in rec.values())
+    assert rec["0"]["slow"] == [] and rec["0"]["pivots_screened"] == 772044 and rec["0"]["seed"] == 1000
+    assert rec["4"]["slow"] == [893] and rec["7"]["slow"] == [6225] and rec["11"]["slow"] == [4572]
+    assert all(r["seed"] == 1000 + 7919 * int(g) for g, r in rec.items())
+    w = bench.screen_records("wide128")
+    assert set(w) == {"0"} and w["0"]["pivots_screened"] > 0
+
+
+def test_replacement_is_the_next_tableau_that_is_not_slow():
+    assert bench.replacement(893, {893}, 10000) == 894
+    assert bench.replacement(9999, {9999, 0}, 10000) == 1
+    assert bench.replacement(5, {5, 6, 7}, 10) == 8
+
+
+def test_batch_rows_are_the_seeded_batches():
+    import numpy as np
+    from piplib_amd import synth
+    cfg = dict(bench.MAIN, batch=50)
+    assert np.array_equal(bench.batch_rows(cfg, 3), synth.lexmin_batch(1000 + 7919 * 3, 50, 127, 64))
+    w = bench.batch_rows(bench.OTHERS[1], 0)
+    assert w.shape == (1000, 128, 256) and np.array_equal(w, bench.batch_rows(bench.OTHERS[1], 5))

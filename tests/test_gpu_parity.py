@@ -210,36 +210,41 @@ def test_batch_layer_rehouses_full_tableaux(batch, nvar, ni, cap, ebits, step):
 
 
 def test_bench_lane_seeds_all_finish():
-    """bench.py's headline lanes draw their batches from seeds 1000 + 7919 * lane.  Three of the 16 lanes'
-    160,000 tableaux are ones on which Gomory's cuts do not converge (the CPU oracle does not finish them within
-    minutes: found with it in round 3, listed below); bench.py replaces exactly those (piplib_amd.engine.slow_converging:
-    not converged within 448 cut rows).  Every other tableau must end with a status the reference has (solution or nil)
-    -- tableaux that need more than the default ni + 64 spare rows are re-housed -- and the oracle agrees on every
-    tableau that needed more than ni + 64 cuts plus 150 others per lane."""
+    """bench.py's headline batches are synth.lexmin_batch(1000 + 7919 * g, ...).  Which of their tableaux are left out
+    (Gomory's cuts do not converge: integrer() asks for more than 448 constant cuts) is the CPU oracle's word,
+    tests/golden/bench_screen.json (tests/golden/make_bench_screen.py) -- made without the engine.  Here the engine is
+    held to it on the 16 batches of a one-GPU run: under the same budget it leaves exactly the listed tableaux at
+    PIPAMD_ST_CAPACITY (piplib_amd.engine.slow_converging), and on the screened batch every tableau ends with a status the
+    reference has (solution or nil) -- tableaux that need more than the default ni + 64 spare rows are re-housed --, the
+    batch's pivot total is the oracle's, and the oracle agrees on every tableau that needed more than ni + 64 cuts plus
+    150 others per batch."""
     import numpy as np
     import torch
+    import bench
     from piplib_amd import engine as eng, synth
     nvar, ni = 127, 64
-    known_slow = {4: [893], 7: [6225], 11: [4572]}   # lane -> tableaux the oracle did not finish within 300 s
+    rec = bench.screen_records("bench_screen")
+    assert rec["4"]["slow"] == [893] and rec["7"]["slow"] == [6225] and rec["11"]["slow"] == [4572]
     e = eng.Engine(0)
     e.set_max_rows(ni + 1024)
     grown = 0
-    for lane in range(16):
-        rows = synth.lexmin_batch(1000 + 7919 * lane, 10000, nvar, ni)
-        slow = eng.slow_converging(e, torch.as_tensor(rows).to("cuda:0"), nvar)
-        assert slow == known_slow.get(lane, []), (lane, slow)
+    for g_ in range(16):
+        rows = synth.lexmin_batch(1000 + 7919 * g_, 10000, nvar, ni)
+        slow = eng.slow_converging(e, torch.as_tensor(rows).to("cuda:0"), nvar, cut_rows=bench.SCREEN_CUTS)
+        assert slow == rec[str(g_)]["slow"], (g_, slow)
         for b in slow:
-            rows[b] = rows[b + 1]
+            rows[b] = rows[bench.replacement(b, set(slow), 10000)]
         g = eng.Batch(e, rows, nvar, 0, tflags=eng.T_INT)
         g.load()
         g.solve()
         g.fetch()
         torch.cuda.synchronize()
         st, ct = g.status.cpu().numpy(), g.cuts.cpu().numpy()
-        assert np.isin(st, [eng.ST_SOLUTION, eng.ST_NIL]).all(), (lane, np.unique(st, return_counts=True))
+        assert np.isin(st, [eng.ST_SOLUTION, eng.ST_NIL]).all(), (g_, np.unique(st, return_counts=True))
+        assert int(g.pivots.sum().item()) == rec[str(g_)]["pivots_screened"], g_
         big = np.nonzero(ct > ni + 64)[0]
         grown += len(big)
-        ids = np.unique(np.concatenate([big, np.random.default_rng(lane).choice(10000, 150, replace=False)]))
+        ids = np.unique(np.concatenate([big, np.random.default_rng(g_).choice(10000, 150, replace=False)]))
         _compare_ids(g, rows, ids, nvar, 1)
         del g
     print("tableaux that needed more than ni + 64 cut rows and were re-housed:", grown)
