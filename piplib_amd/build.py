@@ -30,7 +30,7 @@ def build(force=False, verbose=True, profile=False):
     if profile == "events":
         return _compile(os.path.join(HERE, "libpipamd_prof_events.so"), ["-DPIP_PROFILE", "-DPIP_PROFILE_EVENTS", "-DPIP_MINWAVES=1"], verbose)
     if profile:
-        return _compile(os.path.join(HERE, "libpipamd_prof.so"), ["-DPIP_PROFILE", "-DPIP_MINWAVES=1"], verbose)
+        return _compile(os.path.join(HERE, "libpipamd_prof.so"), ["-DPIP_PROFILE", "-DPIP_MINWAVES=1", "-DPIP_LEAN_WAVES=4"], verbose)
     if os.environ.get("PIP_MINWAVES"):  # tuning experiments only
         return _compile(os.path.join(HERE, "libpipamd_mw%s.so" % os.environ["PIP_MINWAVES"]),
                         ["-DPIP_MINWAVES=" + os.environ["PIP_MINWAVES"]], verbose)

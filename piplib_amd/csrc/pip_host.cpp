@@ -46,6 +46,8 @@ extern "C" int pipamd_engine_create(pipamd_engine **out, int device) {
   {
     const char *nl = getenv("PIPAMD_NO_LEAN");  // measurement aid, like pipamd_debug_lean(e, 0)
     e->no_lean = nl && nl[0] == '1';
+    const char *n2 = getenv("PIPAMD_NO_LEAN2");  // measurement aid: the general one-wave kernel as the second bulk launch
+    e->no_lean2 = n2 && n2[0] == '1';
   }
   pthread_mutex_init(&e->dt_lock, nullptr);
   *out = e;
@@ -372,12 +374,23 @@ struct BatchRun {
           return PIPAMD_OK;
         }
       }
-      // (then the general one-wave kernel over what the lean launch left -- measured with 14 batches in flight: sending
-      // those ~12 % of the tableaux straight to the four-wave tail instead costs 10 % of the throughput)
+      // Then what the lean launch left (on the headline: the 6 % of the tableaux that spent its pivot budget) in a second
+      // one-wave launch: the lean kernel again, which resumes its own paused jobs, with the largest row-capacity class and
+      // a budget that covers the longest tableaux -- and leaves what it cannot take (rows beyond ints, more rows than its
+      // image) to the tail.  Where the shape has no lean kernel: the general one-wave kernel.  (Measured with 14 batches
+      // in flight: sending those tableaux straight to the four-wave tail instead costs 10 % of the throughput.)
       if (!(lean && e->lone_batches)) {  // (pipamd_engine_set_lone_batches: straight to the tail launches)
-        rc = launch(1, budget, smax, lay.batch, false, !defer);
+        const bool lean2 = lean && !e->no_lean2 && pipk_lean_class(lay.ni + 96 < curS ? lay.ni + 96 : curS) != 0;
+        if (lean2) {
+          int smax2 = lay.ni + 96 < curS ? lay.ni + 96 : curS;
+          const int b2 = e->iter_limit < 160 ? e->iter_limit : 160;
+          rc = launch(1, b2, smax2, lay.batch, true, false);
+          replay_pending = true;
+        } else {
+          rc = launch(1, budget, smax, lay.batch, false, !defer);
+          replay_pending = defer;
+        }
         if (rc) return rc;
-        replay_pending = defer;
       }
       if (e->single_launch) {  // measurement aid: the bulk launch on its own (its tableaux stay PIPAMD_ST_RUN)
         if (replay_pending) HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, e->lone_batches, st));

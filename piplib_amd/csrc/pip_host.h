@@ -20,6 +20,7 @@ struct pipamd_engine {
   int single_launch; /* debug: stop after one launch */
   int lone_batches;  /* 1: no general one-wave launch between the lean launch and the tail (pipamd_engine_set_lone_batches) */
   int no_lean;       /* 1: bulk launches without the lean kernel (pip_lean.h) */
+  int no_lean2;      /* 1: the second one-wave bulk launch is the general kernel even where the lean kernel could resume */
   int *h_run;        /* pinned: {jobs still running, their largest row count} */
   int *d_q;          /* launch-list control words (a pool, see pipamd_batch_solve) and the two job lists */
   unsigned solve_seq; /* solves since the control pool was last zeroed */

@@ -3,22 +3,28 @@
 //
 // One wave per tableau, at most 127 unknowns + constant in rows of W <= 128 columns (FULL: exactly 127 + 1, compile-time
 // column counts), no parameters, no big parameter, 64-bit Entier, compile-time row capacity SC, rows skipped, plain
-// cuts -- and EVERY entry of EVERY row below 2^15 in magnitude (magnitude class 0), the pivot row's denominator and a
-// cut's denominator too.  Under that invariant every product of a pivot fits 31 bits, so
+// cuts -- and EVERY entry of EVERY row below 2^31 in magnitude, i.e. an int.  Under that invariant
 //   * rows live in HBM as int32 (4 W bytes per row, in the first half of the row's slot of W long longs): half the
-//     traffic of the reference's long long rows, half the working set;
-//   * a row is two 32-bit registers per lane; the elimination, the row gcd (float-reciprocal remainders), the exact
-//     division, the summaries, choisir_piv's cross products (24-bit multiplies) and the cuts are 32-bit arithmetic;
-//   * none of the general kernel's other paths (64-bit update, wide tournament, parameters, deepest cuts, row tables in
-//     HBM) is compiled in, the pivot row stays in registers, the LDS image is smaller (lean_lds_bytes): 64 VGPRs, no
+//     traffic of the reference's long long rows, half the working set; a row is two 32-bit registers per lane;
+//   * while the rows involved are in magnitude class 0 (entries below 2^15; pivot row's denominator too) every product of
+//     a pivot fits 31 bits: the elimination is 24-bit multiplies, the row gcd float-reciprocal remainders, the exact
+//     division, the summaries, choisir_piv's cross products (24-bit) and the cuts 32-bit arithmetic (the "small" path,
+//     96 % of the headline's pivots);
+//   * a row of class 1 (an entry between 2^15 and 2^31), or a pivot row of class 1, takes the "mid" path (round 4): the same
+//     int rows, products in 64-bit registers (v_mad_i64_i32; below 2^62 each, so nothing wraps), the row gcd and the
+//     division through row_reduce<i64> -- the code pip_advance_kernel runs on such a row, on the same values -- and
+//     choisir_piv's cross products in 64 bits.  The result is an int row again, almost always;
+//   * none of the general kernel's other paths (wide tournament, parameters, deepest cuts, row tables in HBM) is
+//     compiled in, the pivot row stays in registers, the LDS image is smaller (lean_lds_bytes): 64 VGPRs, no
 //     scratch, eight waves per SIMD.
-// The invariant is checked between pivots (the running maximum of the magnitude classes the row summaries compute anyway,
-// the pivot row's denominator, a cut's denominator).  A tableau that leaves it -- or anything else this kernel does not
-// do: entries beyond 32 bits at entry, PIPAMD_T_NOSKIP / _DEEPEST, a paused job -- is handed over in the general format
-// (rows widened to int64 in place, the same row tables and saved summaries as a paused job of pip_advance_kernel) and
-// stays PIPAMD_ST_RUN on the launch list: pipamd_batch_solve's next launches (pip_advance_kernel: one wave per tableau
-// over what this launch left, then four waves per tableau) take it from there.  Same algorithm, same statuses, same
-// bits as pip_advance_kernel -- the reference's traiter()/pivoter()/choisir_piv()/exam_coef()/integrer()/tab_sort_rows
+// A rewritten row that does NOT fit ints any more is stored in the general format (W long longs, the whole slot) and
+// summarised with pip_advance_kernel's magnitude classes (2, 3); the pivot is finished -- no row is read twice in a pivot
+// -- and the running maximum of the classes, checked between pivots, then ends the lean run.  A tableau that leaves --
+// or anything else this kernel does not do: entries beyond ints at entry, a cut under a denominator of 2^31 or more,
+// PIPAMD_T_NOSKIP / _DEEPEST, a paused job -- is handed over in the general format (int rows widened to int64 in
+// place, the same row tables and saved summaries as a paused job of pip_advance_kernel) and stays PIPAMD_ST_RUN on the
+// launch list: pipamd_batch_solve's next launches (pip_advance_kernel) take it from there.  Same algorithm, same
+// statuses, same bits as pip_advance_kernel -- the reference's traiter()/pivoter()/choisir_piv()/exam_coef()/integrer()/tab_sort_rows
 // (traiter.c:101-159, 297-548, 556-623, 628-791; integrer.c:305-486) -- which the parity tests check tableau by tableau
 // (tests/test_gpu_parity.py: test_lean_kernel_paths, test_lean_kernel_other_widths, and every batch test of the suite).
 #ifndef PIP_LEAN_H
@@ -27,9 +33,6 @@
 
 #ifndef PIP_LEAN_PF
 #define PIP_LEAN_PF 2  // rows of a pivot's work list in flight
-#endif
-#ifndef PIP_LEAN_RECYCLE_FIRST
-#define PIP_LEAN_RECYCLE_FIRST 1  // (A/B switch) the recycled pivot slot is rewritten while the first work rows are in flight
 #endif
 #ifndef PIP_LEAN_WAVES
 #define PIP_LEAN_WAVES 8  // waves per SIMD the kernel is bounded to (64 VGPRs)
@@ -50,17 +53,28 @@ __device__ __forceinline__ void row_store32p(const RowRegs32<1> &r, i64 *slot, i
   if (2 * lane < W) *reinterpret_cast<int2 *>(reinterpret_cast<int *>(slot) + 2 * lane) = t;
 }
 
+// a row that no longer fits ints: the general format, the whole slot
+__device__ __forceinline__ void row_store64w(const i64 (&z)[2], i64 *slot, int lane, int W = 128) {
+  longlong2 t;
+  t.x = z[0];
+  t.y = z[1];
+  if (2 * lane < W) *reinterpret_cast<longlong2 *>(slot + 2 * lane) = t;
+}
+
 // rows [0, n) of a block, packed -> the general format, each within its own slot (the loads of a group of rows are back
-// before their slots are overwritten)
-__device__ __forceinline__ void rows_unpack(i64 *vals, int n, int lane, int W) {
+// before their slots are overwritten); rows of class 2 or 3 (rcls, LDS) are in the general format already
+__device__ __forceinline__ void rows_unpack(i64 *vals, int n, int lane, int W, const u8 *rcls) {
   for (int s0 = 0; s0 < n; s0 += 4) {
     RowRegs32<1> rr[4];
+    bool packed[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) {
+      packed[qq] = s0 + qq < n && rcls[s0 + qq] < 2;
+      if (packed[qq]) row_load32p(rr[qq], vals + (size_t)(s0 + qq) * W, lane, W);
+    }
 #pragma unroll
     for (int qq = 0; qq < 4; qq++)
-      if (s0 + qq < n) row_load32p(rr[qq], vals + (size_t)(s0 + qq) * W, lane, W);
-#pragma unroll
-    for (int qq = 0; qq < 4; qq++)
-      if (s0 + qq < n && 2 * lane < W) {
+      if (packed[qq] && 2 * lane < W) {
         longlong2 t;
         t.x = (i64)rr[qq].v[0][0];
         t.y = (i64)rr[qq].v[0][1];
@@ -93,10 +107,34 @@ __device__ __forceinline__ int lean_publish(const RowRegs32<1> &z, const Shared<
   return cls;
 }
 
+// the same for a row that left the ints (z: lane l's columns 2l, 2l+1 as long longs): pip_advance_kernel's classes
+// (2: below 2^47, 3: beyond; 1 only for an entry of exactly -2^31...); the constant term kept here is truncated -- the
+// lean run ends before anything reads it
+__device__ __forceinline__ int lean_publish_wide(const i64 (&z)[2], const Shared<i64> &S, int *cst, int s, int pivj, int extra_sig,
+                                                 int lane, int nvar = 127) {
+  const i64 cz = readlane64((nvar & 1) ? z[1] : z[0], nvar >> 1);
+  int sig = extra_sig | sign_code(cz);
+  if (pivj >= 0) sig |= sign_code(readlane64((pivj & 1) ? z[1] : z[0], pivj >> 1)) << 6;
+  const u64 nz0 = ballot64(z[0] != 0), nz1 = ballot64(z[1] != 0);
+  int cls = cls_of<i64>(uabs64(z[0]) | uabs64(z[1]));
+  if (cls < 2) cls = 2;  // (it does not fit an int: at least 2^31)
+  if (lane == 0) {
+    S.sig[s] = (u16)sig;
+    S.rcls[s] = (u8)cls;
+    cst[s] = (int)cz;
+    S.nzm[(size_t)s * 2] = nz0;
+    S.nzm[(size_t)s * 2 + 1] = nz1;
+  }
+  return cls;
+}
+
 // bytes of this kernel's LDS image for SC row slots (smaller than pip_advance_kernel's: no pivot row, int constants)
 __host__ __device__ constexpr size_t lean_lds_bytes(int SC) { return ((size_t)39 * SC + 2 * 128 + 2 * 128 + 15) & ~(size_t)15; }
 
-// choisir_piv (traiter.c:297-341) as choose_column<i64, 1, true> does it, on packed rows
+// choisir_piv (traiter.c:297-341) as choose_column<i64, 1, SMALL> does it, on packed rows.  SMALL: every row of the
+// tableau is in class 0, the cross products are 24-bit multiplies; else entries are below 2^31, the products below 2^62
+// and their difference a long long.
+template <bool SMALL>
 __device__ __forceinline__ int choose_column32(const Shared<i64> &S, const RowRegs32<1> &prow, const i64 *vals, int W, int nvar,
                                                int nligne, int pivi, Scalars *sc) {
   constexpr int NM = 2;
@@ -164,9 +202,18 @@ __device__ __forceinline__ int choose_column32(const Shared<i64> &S, const RowRe
         int nneg = 0, nzero = 0;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-          const int x = __mul24(ab, n.v[0][h]) - __mul24(nb, a[h]);
-          neg[h] = cand[h] && x < 0;
-          const bool zero = cand[h] && x == 0;
+          bool xneg, xzero;
+          if constexpr (SMALL) {
+            const int x = __mul24(ab, n.v[0][h]) - __mul24(nb, a[h]);
+            xneg = x < 0;
+            xzero = x == 0;
+          } else {
+            const i64 x = (i64)ab * (i64)n.v[0][h] - (i64)nb * (i64)a[h];
+            xneg = x < 0;
+            xzero = x == 0;
+          }
+          neg[h] = cand[h] && xneg;
+          const bool zero = cand[h] && xzero;
           nneg += __popcll(ballot64(neg[h]));
           nzero += __popcll(ballot64(zero));
           if (!neg[h] && !zero) cand[h] = false;  // strictly larger: out
@@ -200,8 +247,16 @@ last_unit_wins:
 // else any number of unknowns up to 127 without parameters, rows of W <= 128 columns (W even).
 template <int SC, bool FULL>
 __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jobs, i64 *arena, int njobs, int iter_limit,
-                                                                      PipQueue q) {
+                                                                      PipQueue q
+#ifdef PIP_PROFILE
+                                                                      , u64 *prof
+#endif
+) {
   typedef i64 T;
+  // (diagnostic build only, tools/dbg_prof_lean.py: cycle stamps per piece of the loop -- 0 exam/integrer, 1 pivot row
+  // load, 2 choisir_piv, 3 work list, 4 queue + recycled slot, 5 wait for a work row, 6 multipliers, 7 products + row gcd +
+  // division, 8 store + summary, 9 phase C, 10 entry, 11 epilogue)
+  PROF_DECL;
   constexpr int Smax = SC, Lmax = SC + 128, WP = 128, NM = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ Scalars sc;
@@ -223,8 +278,8 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
   int nligne = nvar + ni;
   // what this kernel does not do stays with pip_advance_kernel: the job goes on the launch list untouched
   const bool mine = J->nvar == nvar && nvar < 128 && J->nparm == 0 && J->bigparm < 0 && J->W == W && W <= 128 && !(W & 1) &&
-                    J->ebits != 128 && !(tflags & (PIPAMD_T_NOSKIP | PIPAMD_T_DEEPEST | PIPAMD_T_STATE)) && ni <= Smax &&
-                    nligne <= Lmax;
+                    J->ebits != 128 && !(tflags & (PIPAMD_T_NOSKIP | PIPAMD_T_DEEPEST)) && ni <= Smax && nligne <= Lmax &&
+                    (!(tflags & PIPAMD_T_STATE) || J->state_nch == 1);
   if (!mine) {
     if (lane == 0 && q.out_count) {
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
@@ -296,10 +351,13 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
   __builtin_amdgcn_wave_barrier();
 
   // ---- one pass over the tableau: the rows become ints (rows of a job loaded with PIPAMD_T_ROWS_STAY come from the
-  // caller's array), summaries, sort keys.  A row with an entry of 2^15 or more ends the lean run before its first pivot.
-  int mcw = 0;  // largest magnitude class published so far: the lean invariant is mcw == 0
+  // caller's array), summaries, sort keys.  A row with an entry of 2^31 or more: not a job for this kernel.
+  int mcw = 0;  // largest magnitude class published so far: 0 small path everywhere, 1 int rows, beyond: the lean run ends
   {
     constexpr int PF0 = 4;
+    // a job that paused in an earlier launch (this kernel's or pip_advance_kernel's, rows in the general format): what the
+    // entry pass cannot see in the rows -- "gcd(row, denominator) is known to be 1" -- comes from the saved summaries
+    const u16 *g_sig = (tflags & PIPAMD_T_STATE) ? (const u16 *)((const u64 *)(arena + J->state_off) + (size_t)J->S * NM) : nullptr;
     const bool fresh = (tflags & PIPAMD_T_FRESHROWS) != 0;
     const T *src = fresh ? (const T *)(uintptr_t)J->src_rows : vals;
     const int pitch = fresh ? nvar + 1 : W;  // the caller's rows are nvar + 1 wide (an even number: pipamd_batch_load), the block's W
@@ -315,7 +373,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         const int s = s0 + qq;
         if (s >= ni || wide) break;
         const RowRegs<T, 1> &r = rr[qq];
-        const bool fits = r.v[0][0] == (T)(int)r.v[0][0] && r.v[0][1] == (T)(int)r.v[0][1];
+        const bool fits = ((uabs64(r.v[0][0]) | uabs64(r.v[0][1])) >> 31) == 0;  // below 2^31 in magnitude
         if (ballot64(!fits)) {
           wide = true;
           break;
@@ -326,7 +384,8 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         row_store32p(z, vals + (size_t)s * W, lane, W);
         npacked = s + 1;
         const bool den1 = S.den[s] == 1;
-        mcw = max(mcw, lean_publish(z, S, cst, s, -1, den1 ? SIG_RED : 0, lane, nvar));
+        const int red = g_sig ? (g_sig[s] & SIG_RED) : (den1 ? SIG_RED : 0);
+        mcw = max(mcw, lean_publish(z, S, cst, s, -1, red, lane, nvar));
         if (tflags & PIPAMD_T_SORT) {
           // traiter.c:576-589: size = max_j |(int)(v_j / den)| over the unknowns (as pip_advance_kernel computes it)
           int sz = 0;
@@ -357,7 +416,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
     if (wide) {
       // an entry beyond 32 bits: not a job for this kernel.  Its header is untouched (FRESHROWS and SORT still stand);
       // rows that came from the block itself and were already rewritten as ints are widened again.
-      if (!fresh) rows_unpack(vals, npacked, lane, W);
+      if (!fresh) rows_unpack(vals, npacked, lane, W, S.rcls);
       if (lane == 0 && q.out_count) {
         q.out_list[atomicAdd(q.out_count, 1)] = jb;
         atomicMax(q.out_maxni, ni);
@@ -390,15 +449,16 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
   }
   __builtin_amdgcn_wave_barrier();
 
+  PROF(10);
   int status = PIPAMD_ST_RUN;
   int why = 0;  // why a job left this kernel unfinished (PipJob.pad_, read by tools/lean_split.py): 1 pivot budget,
-                // 2 a row beyond class 0, 3 a cut's denominator, 4 the pivot row's denominator, 5 no room in the LDS image
+                // 2 a row beyond ints, 3 a cut's denominator, 5 no room in the LDS image
   for (int iter = 0;; iter++) {
     why = 1;
     if (iter >= iter_limit) break;  // status stays RUN: the next launch resumes the job
     if (nlog >= LOGCAP) break;
     why = 2;
-    if (mcw != 0) break;  // a row left magnitude class 0: the general kernel goes on
+    if (mcw > 1) break;  // a row left the ints (it is stored in the general format): the general kernel goes on
     why = 0;
     int pivi = sc.pivi;
     if (pivi == BIG_I) {
@@ -431,19 +491,26 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         const int cslot = S.ref[ci];
         const T D64 = uni64(S.den[cslot]);
         why = 3;
-        if (D64 <= 0 || D64 >= ((T)1 << 15)) break;  // the cut's entries would not be of class 0: the general kernel goes on
+        if (D64 <= 0 || D64 >= ((T)1 << 31)) break;  // the cut's entries (below D) might not be ints: the general kernel goes on
         const int D = (int)D64;
         RowRegs32<1> r;
         row_load32p(r, vals + (size_t)cslot * W, lane, W);
         bool okv = false;
+        const bool tinyD = D < (1 << 15) && S.rcls[cslot] == 0;  // |v| < 2^15 and D < 2^15: remainders through a float reciprocal
         const float rD = __builtin_amdgcn_rcpf((float)D);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           const int j = 2 * lane + h;
           const int v = r.v[0][h];
-          // piplib_llmod (integrer.c:69-74): the remainder in [0, D); |v| < 2^15 and D < 2^15
-          const unsigned m = umod_tiny((unsigned)(v < 0 ? -v : v), (unsigned)D, rD);
-          const int pos = v < 0 ? (m ? D - (int)m : 0) : (int)m;         // v mod D
+          // piplib_llmod (integrer.c:69-74): the remainder in [0, D)
+          int pos;
+          if (tinyD) {
+            const unsigned m = umod_tiny((unsigned)(v < 0 ? -v : v), (unsigned)D, rD);
+            pos = v < 0 ? (m ? D - (int)m : 0) : (int)m;  // v mod D
+          } else {
+            const int m = v % D;
+            pos = m < 0 ? m + D : m;
+          }
           int x;
           if (j < nvar) {
             x = pos;
@@ -483,29 +550,30 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         pivi = nligne;
         ni++;
         nligne++;
-        why = 2;
-        if (mcw != 0) break;  // (cannot happen: the cut's entries are below D)
       }
     }
+    PROF(0);
     // ---------------- A: pivot row, choisir_piv, work list
     const int pslot = S.ref[pivi];
     const T dpiv = uni64(S.den[pslot]);
-    why = 4;
-    if (dpiv <= -((T)1 << 15) || dpiv >= ((T)1 << 15)) {
-      // the pivot row's denominator is not small: the general kernel does this pivot.  A cut row just appended stays
-      // (it is flagged Minus: the general kernel's chercher finds it).
-      break;
-    }
-    why = 0;
+    // small path for a row: the row and the pivot row in class 0 and the pivot row's denominator below 2^15 (then the
+    // multipliers are below 2^15 as well and every product below 2^30)
+    const bool psmall = S.rcls[pslot] == 0 && dpiv > -((T)1 << 15) && dpiv < ((T)1 << 15);
     npiv++;
     RowRegs32<1> pr;
     row_load32p(pr, vals + (size_t)pslot * W, lane, W);
     const int psig_v = S.sig[pslot];
-    const int pj = choose_column32(S, pr, vals, W, nvar, nligne, pivi, &sc);
+#ifdef PIP_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PROF(1);
+    const int pj = mcw == 0 ? choose_column32<true>(S, pr, vals, W, nvar, nligne, pivi, &sc)
+                            : choose_column32<false>(S, pr, vals, W, nvar, nligne, pivi, &sc);
     if (pj == -1) {  // traiter.c:782-785
       status = PIPAMD_ST_NIL;
       break;
     }
+    PROF(2);
     const int pe = pj & 1, pl = pj >> 1;
     int nwork = 0;
     for (int s0 = 0; s0 < ni; s0 += 64) {
@@ -540,6 +608,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
     nlog++;
     const int ku = S.urow[pivj];  // unit row of the entering column
     const int pred = psig_v & SIG_RED;
+    PROF(3);
     // ---------------- B: eliminate the pivot column
     nupd += nwork - 1;
     {
@@ -553,17 +622,22 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         sq[q2] = S.work[q2 < nwork ? q2 : 0];
         if (q2 < nwork && sq[q2] != pslot) row_load32p(rq[q2], vals + (size_t)sq[q2] * W, lane, W);
       }
-#if PIP_LEAN_RECYCLE_FIRST
-      {
-        // while the first rows are on their way: the pivot slot is recycled for the row replacing ku's unit row
-        // (traiter.c:461-465,503-513) -- it needs no load, the pivot row is in registers
+      // while the first rows are on their way: the pivot slot is recycled for the row replacing ku's unit row
+      // (traiter.c:461-465,503-513) -- it needs no load, the pivot row is in registers
+      if (dpiv > -((T)1 << 31) && dpiv < ((T)1 << 31)) {
         RowRegs32<1> r;
 #pragma unroll
         for (int h = 0; h < 2; h++) r.v[0][h] = (2 * lane + h == pivj) ? (int)dpiv : -pr.v[0][h];
         row_store32p(r, vals + (size_t)pslot * W, lane, W);
         mcw = max(mcw, lean_publish(r, S, cst, pslot, pivj, pred, lane, nvar));
+      } else {  // the denominator is no int: that row is not one either
+        i64 zw[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) zw[h] = (2 * lane + h == pivj) ? dpiv : -(i64)pr.v[0][h];
+        row_store64w(zw, vals + (size_t)pslot * W, lane, W);
+        mcw = max(mcw, lean_publish_wide(zw, S, cst, pslot, pivj, pred, lane, nvar));
       }
-#endif
+      PROF(4);
       for (int w = 0; w < nwork; w++) {
         const int s = sq[0];
         RowRegs32<1> r = rq[0];
@@ -578,19 +652,12 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
         }
         T *row = vals + (size_t)s * W;
         {
-#if PIP_LEAN_RECYCLE_FIRST
           if (s == pslot) continue;
-#else
-          if (s == pslot) {
-            // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
-#pragma unroll
-            for (int h = 0; h < 2; h++) r.v[0][h] = (2 * lane + h == pivj) ? (int)dpiv : -pr.v[0][h];
-            row_store32p(r, row, lane, W);
-            mcw = max(mcw, lean_publish(r, S, cst, s, pivj, pred, lane, nvar));
-            continue;
-          }
+#ifdef PIP_PROFILE
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF - 1) : "memory");
 #endif
-          // multipliers from the row's own pivot-column entry (traiter.c:470-476); everything below 2^15
+          PROF(5);
+          // multipliers from the row's own pivot-column entry (traiter.c:470-476); ints
           int foo = __builtin_amdgcn_readlane(r.v[0][0], pl) * (1 - pe) + __builtin_amdgcn_readlane(r.v[0][1], pl) * pe;
           const T den_s = uni64(S.den[s]);
           int lp = pivot;
@@ -603,28 +670,60 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
             }
             g0 = wmul((T)lp, den_s);
           }
-          int z[1][2];
-          unsigned mx = 0;
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            int v = __mul24(r.v[0][h], lp) - __mul24(pr.v[0][h], foo);
-            if (2 * lane + h == pivj) v = __mul24((int)dpiv, foo);
-            z[0][h] = v;
-            mx |= (unsigned)(v < 0 ? -v : v);
-          }
           T nd;
-          if (!small_reduce<1>(z, mx, g0, lane, nd)) {
-            if (lane == 0) sc.bad = 1;
+          PROF(6);
+          if (psmall && S.rcls[s] == 0) {
+            // small path: every operand below 2^15, every product below 2^30
+            int z[1][2];
+            unsigned mx = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              int v = __mul24(r.v[0][h], lp) - __mul24(pr.v[0][h], foo);
+              if (2 * lane + h == pivj) v = __mul24((int)dpiv, foo);
+              z[0][h] = v;
+              mx |= (unsigned)(v < 0 ? -v : v);
+            }
+            if (!small_reduce<1>(z, mx, g0, lane, nd)) {
+              if (lane == 0) sc.bad = 1;
+            }
+            r.v[0][0] = z[0][0];
+            r.v[0][1] = z[0][1];
+            PROF(7);
+            row_store32p(r, row, lane, W);
+            mcw = max(mcw, lean_publish(r, S, cst, s, pivj, SIG_RED, lane, nvar));
+          } else {
+            // mid path: int operands, products below 2^62 in long longs -- pip_advance_kernel's update_row on the same
+            // values (its wrap-around arithmetic has nothing to wrap here, except dpiv * foo under a denominator
+            // beyond ints, which wraps the same way)
+            i64 zw[2];
+            u64 mx = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              i64 v = (i64)r.v[0][h] * (i64)lp - (i64)pr.v[0][h] * (i64)foo;
+              if (2 * lane + h == pivj) v = wmul(dpiv, (i64)foo);
+              zw[h] = v;
+              mx |= uabs64(v);
+            }
+            if (!row_reduce<i64, 2>(zw, mx, g0, lane, nd)) {
+              if (lane == 0) sc.bad = 1;
+            }
+            if (ballot64(((uabs64(zw[0]) | uabs64(zw[1])) >> 31) != 0) == 0) {
+              r.v[0][0] = (int)zw[0];
+              r.v[0][1] = (int)zw[1];
+              row_store32p(r, row, lane, W);
+              mcw = max(mcw, lean_publish(r, S, cst, s, pivj, SIG_RED, lane, nvar));
+            } else {  // not an int row any more: general format, the lean run ends after this pivot
+              row_store64w(zw, row, lane, W);
+              mcw = max(mcw, lean_publish_wide(zw, S, cst, s, pivj, SIG_RED, lane, nvar));
+            }
           }
-          r.v[0][0] = z[0][0];
-          r.v[0][1] = z[0][1];
-          row_store32p(r, row, lane, W);
-          mcw = max(mcw, lean_publish(r, S, cst, s, pivj, SIG_RED, lane, nvar));
           if (lane == 0) S.den[s] = nd;
+          PROF(8);
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
+    PROF(4);
     if (sc.bad) {
       status = PIPAMD_ST_OVERFLOW;
       break;
@@ -665,6 +764,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
       }
     }
     __builtin_amdgcn_wave_barrier();
+    PROF(9);
   }
 
   // ---- epilogue: the row tables, the header and (if any) the solution, as pip_advance_kernel writes them
@@ -708,7 +808,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
       const int rf = S.ref[i];
       T v = 0, d = 1;
       if (!(rf & UNITBIT)) {
-        v = (T)reinterpret_cast<const int *>(vals + (size_t)rf * W)[nvar];
+        v = (T)cst[rf];  // (the constant terms are kept current in LDS by lean_publish)
         d = S.den[rf];
       }
       sol_num[i] = v;
@@ -717,7 +817,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
   }
   if (status == PIPAMD_ST_RUN || status == PIPAMD_ST_CAPACITY) {
     // the job goes on elsewhere (pip_advance_kernel, pip_rehouse_kernel): its rows in the general format again
-    rows_unpack(vals, ni, lane, W);
+    rows_unpack(vals, ni, lane, W, S.rcls);
   }
   int mc = 0;
   for (int s = lane; s < ni; s += 64)
@@ -744,13 +844,22 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
       atomicMax(q.out_maxni, PIPAMD_Q_CAPFLAG | ni);
     }
   }
+  PROF(11);
+#ifdef PIP_PROFILE
+  PROF_FLUSH(prof);
+#endif
 }
 
 template <int SC, bool FULL>
 hipError_t launch_lean(const AdvanceLaunch &a) {
   const int grid = a.grid > 0 && a.grid < a.njobs ? a.grid : a.njobs;
   const size_t shm = lean_lds_bytes(SC);
+#ifdef PIP_PROFILE
+  hipLaunchKernelGGL((pip_lean_kernel<SC, FULL>), dim3(grid), dim3(64), shm, a.stream, a.jobs, a.arena, a.njobs, a.iter_limit, a.q,
+                     (u64 *)a.prof);
+#else
   hipLaunchKernelGGL((pip_lean_kernel<SC, FULL>), dim3(grid), dim3(64), shm, a.stream, a.jobs, a.arena, a.njobs, a.iter_limit, a.q);
+#endif
   return hipGetLastError();
 }
 // the row-capacity classes of launch_static (pip_kernels.hip)

@@ -22,7 +22,7 @@ while time.time() - t0 < budget:
     kw = dict(nnz=int(rng.integers(2, 7)), cmax=int(rng.choice([1, 2, 5, 30, 200, 5000, 30000])), x0max=int(rng.choice([3, 9, 50])),
               slackmax=int(rng.choice([0, 3, 10])), pneg=float(rng.choice([0.0, 0.25, 0.5])))
     rows = synth.lexmin_batch(seed, batch, nvar, ni, **kw)
-    scale = int(rng.choice([1, 1, 1 << 7, 1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 30, 1 << 33]))
+    scale = int(rng.choice([1, 1, 1 << 7, 1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 20, 1 << 24, 1 << 27, 1 << 30, 1 << 33]))
     if scale > 1:  # some inequalities multiplied through (same polyhedron, larger entries)
         which = rng.random((batch, ni)) < 0.15
         rows = np.where(which[:, :, None], rows * scale, rows)

@@ -634,7 +634,9 @@ def test_rows_fetched_by_the_pivot_kernel(nvar, ni, nq, waves):
     ("headline", 64, 1, dict(), None, True),           # most tableaux finish in the lean kernel; some leave it mid-run
     ("headline-copied-rows", 64, 1, dict(), None, False),  # rows already in the job blocks: packed in place
     ("rational", 64, 0, dict(), None, True),
-    ("class-1-at-entry", 64, 1, dict(scale=40000), None, True),   # entries of 2^15 and more: left before the first pivot
+    ("class-1-at-entry", 64, 1, dict(scale=40000), None, True),   # entries of 2^15 and more from the start: the mid path
+    ("class-2-mid-run", 64, 1, dict(scale=1 << 24), None, True),  # ints at entry, a row beyond 2^31 after a few pivots
+    ("class-2-mid-run-copied", 64, 1, dict(scale=1 << 24), None, False),
     ("beyond-32-bits", 40, 1, dict(scale=1 << 33), None, False),  # rows that cannot be packed (widened again in place)
     ("beyond-32-bits-fetched", 64, 1, dict(scale=1 << 33), None, True),
     ("overflow", 64, 1, dict(cmax=40000, x0max=3), None, True),   # "Integer overflow" (traiter.c:424,442) on every tableau
@@ -643,10 +645,10 @@ def test_rows_fetched_by_the_pivot_kernel(nvar, ni, nq, waves):
     ("spare-rows-spent", 64, 1, dict(), 6, True),      # PIPAMD_ST_CAPACITY inside the lean kernel, then expanser
 ])
 def test_lean_kernel_paths(name, ni, nq, kw, cap, stay):
-    """The lean bulk kernel (csrc/pip_lean.h: 127 unknowns, int rows, entries below 2^15) and every way a tableau
-    leaves it -- finished, pivot budget, a row or a denominator beyond class 0, no spare row, rows it cannot pack --
-    against the same batch without it (pipamd_debug_lean: statuses, pivot and cut counts, solutions identical) and
-    against the oracle."""
+    """The lean bulk kernel (csrc/pip_lean.h: 127 unknowns, int rows; entries below 2^15: 24-bit products, below 2^31:
+    64-bit products on the same int rows) and every way a tableau leaves it -- finished, pivot budget, a row that no longer
+    fits ints (stored in the general format mid-pivot), no spare row, rows it cannot pack -- against the same batch
+    without it (pipamd_debug_lean: statuses, pivot and cut counts, solutions identical) and against the oracle."""
     import torch
     from gpu_common import oracle_batch, solution_text
     import pipbatch as pb
@@ -676,20 +678,25 @@ def test_lean_kernel_paths(name, ni, nq, kw, cap, stay):
     if name != "no-class":
         assert launches[1] > launches[0] or cap, launches  # the lean launch went out (one more launch than without)
         # the lean launch on its own: how its tableaux ended (PipJob of csrc/pip_job.h, 200 bytes: status at byte 72,
-        # pivots at 80, the lean kernel's exit reason at 172 -- 1 pivot budget, 2 a row beyond class 0)
+        # pivots at 80, the largest magnitude class among its rows at 160, the lean kernel's exit reason at 172 -- 1 pivot
+        # budget, 2 a row beyond ints)
         e.debug_single_launch(2)
         b.load()
         b.solve()
         e.debug_single_launch(0)
         j = b.ws[:25 * batch].view(torch.int32).view(batch, 50).cpu().numpy()
-        status, npiv, why = j[:, 18], j[:, 20], j[:, 43]
+        status, npiv, why, mcls = j[:, 18], j[:, 20], j[:, 43], j[:, 40]
         running = status == eng.ST_RUN
         if name == "class-160":   # long tableaux: most spend the launch's pivot budget
             assert (npiv > 0).all() and (running & (why == 1)).any()
         if name in ("headline", "headline-copied-rows", "rational"):
-            assert (~running).sum() > batch // 2 and (running & (why == 2) & (npiv > 0)).any(), (running.sum(), why[running])
-        if name == "class-1-at-entry":   # the scaled tableaux leave before their first pivot, the others run
-            assert (running[::2] & (why[::2] == 2) & (npiv[::2] == 0)).all() and (npiv[1::2] > 0).all()
+            # (rows between 2^15 and 2^31 do not end a lean run any more: only the pivot budget does on this family)
+            assert (~running).sum() > batch // 2 and (why[running] == 1).all(), (running.sum(), why[running])
+        if name == "class-1-at-entry":   # the scaled tableaux run on the mid path from their first pivot
+            assert (npiv > 0).all() and (~running[::2]).sum() > batch // 4 and (why[::2] != 2).sum() > batch // 4, why[::2]
+        if name.startswith("class-2-mid-run"):   # scaled tableaux start as int rows and leave mid-run on a row beyond 2^31
+            left = running[::2] & (why[::2] == 2)
+            assert (npiv > 0).all() and left.sum() > batch // 8 and (mcls[::2][left] >= 2).all(), (left.sum(), why[::2])
         if name.startswith("beyond-32-bits"):   # not taken: header untouched
             assert (running[::2] & (npiv[::2] == 0)).all() and (npiv[1::2] > 0).all()
         if name == "spare-rows-spent":
