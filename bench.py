@@ -1032,7 +1032,10 @@ def main():
                 except VoidLine as ex:
                     others.append({"config": oc["key"], "workload": oc["workload"], "error": "void: " + str(ex), "value": None})
                     continue
-                osteps = 16 * od * ofuse
+                # (the pinned configs[4] batch is seconds of GPU time a pass -- its longest tableau needs 4,513 pivots on
+                # some 900 rows --: two passes per lane and region, and two lone steps)
+                heavy = bool(oc.get("family"))
+                osteps = (2 if heavy else 16) * od * ofuse
                 # The median of three timed regions: a region here is 35 ms to 1.4 s long, and the first region of a
                 # fresh set of lanes came out 2-3x slower than every later one on configs[1] (cause not found).
                 regions = sorted((timed(ol, osteps, od, barrier) for _ in range(3)), key=lambda r: r[0])
@@ -1042,7 +1045,8 @@ def main():
                 oe, ob, _ = ol.lanes[0]
                 okm = kernel_ms_of(ob, ol.batches[0])
                 o1 = Lanes(oc, 1, dev, local, [[0]], args)
-                odt1, osh1 = timed(o1, 16, 2, barrier, 0)
+                n_lone = 2 if heavy else 16
+                odt1, osh1 = timed(o1, n_lone, 1 if heavy else 2, barrier, 0)
                 ot1 = o1.totals(osh1)
                 others.append({
                     "config": oc["key"], "workload": oc["workload"], "dtype": "int128" if oc["ebits"] == 128 else "int64",
@@ -1053,7 +1057,7 @@ def main():
                     "status_histogram": {STATUS_NAMES.get(k, str(k)): v for k, v in sorted(ol.status_histogram().items())},
                     "regions_checked": ol.checked_passes > 0, "oracle_checked_batches": ol.oracle_checked,
                     "screened_count": sum(len(v) for v in ol.screened.values()),
-                    "pipeline1_value": ot1[0] / odt1, "pipeline1_ms_per_step": odt1 / 16 * 1e3,
+                    "pipeline1_value": ot1[0] / odt1, "pipeline1_ms_per_step": odt1 / n_lone * 1e3,
                     "roofline": roofline_of(ob, oe, okm, oc)})
                 ol.close()
                 o1.close()

@@ -71,6 +71,12 @@ typedef unsigned char u8;
 #endif
 #define PIP_OPT_CSMALL 1   // (A/B switch) choisir_piv with 24-bit cross products while every row is in class 0
 #endif
+#ifndef PIP_OPT_INV_REDUCE
+#define PIP_OPT_INV_REDUCE 1  // (A/B switch) row gcd and division by inverse multiplication (reduce_by_inverse) instead of remainders
+#endif
+#ifndef PIP_OPT_LANEPREP
+#define PIP_OPT_LANEPREP 1  // (A/B switch) 128-bit rows: gcds and multipliers of a pivot's rows prepared one row per lane
+#endif
 #ifndef PIP_MINWAVES128
 #define PIP_MINWAVES128 4  // waves per SIMD the 128-bit kernels of <= 256 columns are bounded to (128 VGPRs; 1 = no bound)
 #endif
@@ -260,7 +266,9 @@ __device__ __forceinline__ u128 gcd_mag(u128 a, u128 b) {
   if ((a >> 32) == 0) return (u128)gcd_mag((u64)(unsigned)a, (u64)umod128_32(b, (unsigned)a));
   int sh = ctz128(a | b);
   a >>= ctz128(a);
+  CNT(20, 1);
   do {
+    CNT(21, 1);
     b >>= ctz128(b);
     if (a > b) {
       u128 t = a;
@@ -273,8 +281,10 @@ __device__ __forceinline__ u128 gcd_mag(u128 a, u128 b) {
 }
 __device__ __forceinline__ i128 gcd_i64(i128 a, i128 b) { return (i128)gcd_mag(uabs64(a), uabs64(b)); }
 __device__ __forceinline__ u128 inv_odd64(u128 m) {
-  u128 x = m;  // 3 correct bits, doubled by every Newton step
-  for (int i = 0; i < 6; i++) x *= 2 - m * x;
+  // the inverse modulo 2^64 on 64-bit registers (five Newton steps from 3 correct bits), one 128-bit step on top:
+  // a 128-bit multiplication is ten 32-bit multiply-adds, a 64-bit one three
+  u128 x = (u128)inv_odd64((u64)m);
+  x *= 2 - m * x;
   return x;
 }
 // every division on the pivot path is exact (piplib_int_div_exact of a gcd): shift + odd inverse
@@ -621,6 +631,230 @@ __device__ __forceinline__ int row_publish32(const RowRegs32<NCH> &z, const Shar
   return cls;
 }
 
+// Wave-wide unsigned min / max without LDS traffic: a DPP butterfly inside each row of 16
+// lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row results
+// through the scalar unit.  Call with all 64 lanes active; the result is wave-uniform.
+template <bool MAX>
+__device__ __forceinline__ unsigned wave_minmax_u32(unsigned v) {
+#define PIP_DPP_STEP(ctrl)                                                                         \
+  {                                                                                                \
+    unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, 0xf, 0xf, false);     \
+    v = MAX ? (o > v ? o : v) : (o < v ? o : v);                                                   \
+  }
+  PIP_DPP_STEP(0xB1)   // quad_perm [1,0,3,2]
+  PIP_DPP_STEP(0x4E)   // quad_perm [2,3,0,1]
+  PIP_DPP_STEP(0x141)  // row_half_mirror
+  PIP_DPP_STEP(0x140)  // row_mirror
+#undef PIP_DPP_STEP
+  const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  if (MAX) {
+    const unsigned a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
+  }
+  const unsigned a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+  return a < b ? a : b;
+}
+
+// Row gcd and exact division of a row without remainders.  The refinement of row_reduce_rem (below) reduces every entry
+// modulo the current g, round after round -- a division sequence per entry and round, for 128-bit operands a bit-serial
+// loop of up to 128 steps.  Here one wrap-around multiplication per entry answers "does g divide it" AND yields the
+// quotient: with g = 2^s m (m odd) and inv = m^-1 mod 2^W, an entry a whose low s bits are zero has a >> s = k m  <=>
+// (a >> s) inv mod 2^W = k, and the quotients of non-multiples are the values above (2^W - 1) / m (multiplication by inv
+// is a bijection that maps the multiples of m onto 0 .. (2^W - 1) / m).  Every |a| is below 2^B (B = bits of the OR of the
+// row's magnitudes), so a true quotient is below 2^(B - s - bits(m) + 1) and a false one at least 2^(W - bits(m)): one
+// shift tells them apart.  (With signs: entries lie in (-2^B, 2^B) and the quotient is read as a signed number, so a
+// false quotient k needs |k m| >= 2^W - 2^B while an accepted one has |k m| < 2^(B - s + 1): B <= W - 2 keeps them apart.)  A round that meets a non-multiple folds that entry into g and starts
+// again.  The gcd is associative, so the result is the reference's left fold (traiter.c:479-501).
+// W is the narrowest of 32 / 64 / 128 bits that holds the entries and g (WT<TW>), whatever the row's entry type.
+template <class TW>
+struct WT;
+template <>
+struct WT<int> {
+  typedef unsigned U;
+};
+template <>
+struct WT<i64> {
+  typedef u64 U;
+};
+template <>
+struct WT<i128> {
+  typedef u128 U;
+};
+__device__ __forceinline__ int ctzW(unsigned x) { return __builtin_ctz(x); }
+__device__ __forceinline__ int ctzW(u64 x) { return __builtin_ctzll(x); }
+__device__ __forceinline__ int ctzW(u128 x) { return ctz128(x); }
+__device__ __forceinline__ int bitlenW(unsigned x) { return x ? 32 - __builtin_clz(x) : 0; }
+__device__ __forceinline__ int bitlenW(u64 x) { return bitlen64(x); }
+__device__ __forceinline__ int bitlenW(u128 x) { return bitlen64(x); }
+__device__ __forceinline__ unsigned invW(unsigned m) {
+  unsigned x = (3u * m) ^ 2u;  // 5 correct bits, doubled by every step
+  x *= 2u - m * x;
+  x *= 2u - m * x;
+  x *= 2u - m * x;
+  return x;
+}
+__device__ __forceinline__ u64 invW(u64 m) { return inv_odd64(m); }
+__device__ __forceinline__ u128 invW(u128 m) { return inv_odd64(m); }
+__device__ __forceinline__ unsigned gcdW(unsigned a, unsigned b) { return gcd_u32(a, b); }
+__device__ __forceinline__ u64 gcdW(u64 a, u64 b) { return gcd_mag(a, b); }
+__device__ __forceinline__ u128 gcdW(u128 a, u128 b) { return gcd_mag(a, b); }
+__device__ __forceinline__ unsigned uabsW(int x) { return x < 0 ? 0u - (unsigned)x : (unsigned)x; }
+__device__ __forceinline__ u64 uabsW(i64 x) { return uabs64(x); }
+__device__ __forceinline__ u128 uabsW(i128 x) { return uabs64(x); }
+__device__ __forceinline__ int readlaneW(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ i64 readlaneW(i64 v, int src) { return readlane64(v, src); }
+__device__ __forceinline__ i128 readlaneW(i128 v, int src) { return readlane64(v, src); }
+
+// zz (N entries per lane, every |zz| below 2^B, B at most W - 2) is divided by gcd(g, all |zz|) in place; returns that
+// gcd, with its factor 2^s and the inverse of its odd part (the caller divides the denominator with them).  g >= 1.
+// INPLACE: the quotients take the entries' registers and a failing round undoes its multiplications (times m: the same
+// bijection backwards) -- for 128-bit entries and for callers short of registers.
+template <class TW, int N, bool INPLACE = (sizeof(TW) > 8)>
+__device__ __forceinline__ typename WT<TW>::U reduce_by_inverse(TW (&zz)[N], int B, typename WT<TW>::U g, int &s, typename WT<TW>::U &inv) {
+  typedef typename WT<TW>::U U;
+  for (;;) {
+    s = 0;
+    inv = 1;
+    if (g == 1) return g;
+    s = ctzW(g);
+    const U m = g >> s;
+    if (s) {  // the low s bits of every entry (two's complement: those of z are zero iff those of |z| are)
+      const U lowmask = ((U)1 << s) - 1;
+      TW pick = 0;
+#pragma unroll
+      for (int e = 0; e < N; e++)
+        if (((U)zz[e] & lowmask) != 0) pick = zz[e];
+      const u64 bad = ballot64(pick != 0);
+      if (bad) {
+        g = gcdW(g, uabsW(readlaneW(pick, __ffsll((long long)bad) - 1)));
+        continue;
+      }
+    }
+    if (m == 1) {  // a power of two
+#pragma unroll
+      for (int e = 0; e < N; e++) zz[e] >>= s;
+      return g;
+    }
+    int lim = B - s - bitlenW(m) + 1;
+    lim = lim < 0 ? 0 : lim;
+    CNT(13, 1);
+    inv = invW(m);
+    if constexpr (!INPLACE) {
+      TW qq[N], pick = 0;
+#pragma unroll
+      for (int e = 0; e < N; e++) {
+        const TW q = (TW)((U)(zz[e] >> s) * inv);
+        qq[e] = q;
+        if ((uabsW(q) >> lim) != 0) pick = zz[e];  // (a failing entry is not zero: zero's quotient is zero)
+      }
+      const u64 bad = ballot64(pick != 0);
+      if (!bad) {
+#pragma unroll
+        for (int e = 0; e < N; e++) zz[e] = qq[e];
+        return g;
+      }
+      CNT(14, 1);
+      g = gcdW(g, uabsW(readlaneW(pick, __ffsll((long long)bad) - 1)));
+    } else {
+      bool okl = true;
+#pragma unroll
+      for (int e = 0; e < N; e++) {
+        const TW q = (TW)((U)(zz[e] >> s) * inv);
+        zz[e] = q;
+        okl &= (uabsW(q) >> lim) == 0;
+      }
+      const u64 bad = ballot64(!okl);
+      if (!bad) return g;
+      CNT(14, 1);
+      TW pick = 0;
+#pragma unroll
+      for (int e = 0; e < N; e++) {
+        const TW q = zz[e];
+        const TW a = (TW)(((U)q * m) << s);
+        zz[e] = a;
+        if ((uabsW(q) >> lim) != 0) pick = a;
+      }
+      g = gcdW(g, uabsW(readlaneW(pick, __ffsll((long long)bad) - 1)));
+    }
+  }
+}
+
+// the denominator's share: newden = g0 / g for the g = 2^s m reduce_by_inverse returned (inv = m^-1 modulo its width)
+template <class T, class TW>
+__device__ __forceinline__ T reduce_den(T g0, typename WT<TW>::U g, int s, typename WT<TW>::U inv) {
+  typedef typename ET<T>::U U;
+  if (g == 1) return g0;
+  if constexpr (sizeof(TW) == sizeof(T)) {
+    return (T)((U)(g0 >> s) * (U)inv);
+  } else {
+    if ((T)(TW)g0 == g0) return (T)(TW)((typename WT<TW>::U)((TW)g0 >> s) * inv);  // the quotient of a narrow g0 is narrow
+    return (T)((U)(g0 >> s) * inv_odd64((U)(g >> s)));
+  }
+}
+
+template <class T, int N>
+__device__ __forceinline__ bool row_reduce_rem(T (&z)[N], typename ET<T>::U mx, T g0, int lane, T &newden);
+
+// pivoter()'s row gcd and division (traiter.c:479-501): z (N entries per lane, `mx` = OR of the lane's |z|) is divided by
+// g = gcd(g0, z_0, ..., z_n) in place; newden = g0 / g.  False where the reference would divide by zero.
+// `zfold`: an entry of the row the caller knows beforehand (the one in the pivot column; 0: none) -- it is folded into g
+// first, after which g is the row's gcd more often than not and one round does it; `gpre` != 0: gcd(|g0|, |zfold|) as
+// the caller has it already (the lane-parallel preparation of the 128-bit phase B).
+// TRY32 = false: no 32-bit variant (callers that are short of registers).
+template <class T, int N, bool TRY32 = true>
+__device__ __forceinline__ bool row_reduce(T (&z)[N], typename ET<T>::U mx, T g0, int lane, T &newden, T zfold = 0,
+                                           typename ET<T>::U gpre = 0) {
+  typedef typename ET<T>::U U;
+  newden = g0;
+  if (g0 == 1) return true;
+  const int B = (int)wave_minmax_u32<true>((unsigned)bitlen64(mx));
+  // (g0 == 0 -- the reference would divide by zero unless some entry is not -- and entries of 2^(W-2) and more in magnitude
+  // keep the remainder loop)
+  if (!PIP_OPT_INV_REDUCE || g0 == 0 || B > ET<T>::BITS - 2) return row_reduce_rem<T, N>(z, mx, g0, lane, newden);
+  U g = (U)uni64((T)uabs64(g0));
+  if (gpre != 0)
+    g = gpre;
+  else if (zfold != 0)
+    g = gcd_mag(g, (U)uni64((T)uabs64(zfold)));
+  if (g == 1) return true;
+  const int gb = bitlen64(g);
+  if (TRY32 && B <= 30 && gb <= 32) {
+    int zz[N], s;
+    unsigned inv;
+#pragma unroll
+    for (int e = 0; e < N; e++) zz[e] = (int)z[e];
+    const unsigned gg = reduce_by_inverse<int, N>(zz, B, (unsigned)g, s, inv);
+    if (gg != 1) {
+#pragma unroll
+      for (int e = 0; e < N; e++) z[e] = (T)zz[e];
+    }
+    newden = reduce_den<T, int>(g0, gg, s, inv);
+    return true;
+  }
+  if constexpr (sizeof(T) == 16) {
+    if (B <= 62 && gb <= 64) {
+      i64 zz[N];
+      int s;
+      u64 inv;
+#pragma unroll
+      for (int e = 0; e < N; e++) zz[e] = (i64)z[e];
+      const u64 gg = reduce_by_inverse<i64, N>(zz, B, (u64)g, s, inv);
+      if (gg != 1) {
+#pragma unroll
+        for (int e = 0; e < N; e++) z[e] = (T)zz[e];
+      }
+      newden = reduce_den<T, i64>(g0, gg, s, inv);
+      return true;
+    }
+  }
+  int s;
+  U inv;
+  const U gg = reduce_by_inverse<T, N, (sizeof(T) > 8 || !TRY32)>(z, B, g, s, inv);
+  newden = reduce_den<T, T>(g0, gg, s, inv);
+  return true;
+}
+
 // pivoter()'s inner loop for one row (traiter.c:470-501), one wave per row.
 //   z_j = p_j*lpiv - q_j*foo  (j != pivj),  z_pivj = dpiv*foo
 //   g   = gcd(lpiv*den, z_0, ..., z_{ncol-1});  row /= g; den = lpiv*den/g
@@ -631,7 +865,7 @@ __device__ __forceinline__ int row_publish32(const RowRegs32<NCH> &z, const Shar
 // The second half: z (N entries per lane, `mx` = OR of the lane's |z|) is divided by g = gcd(g0, z_0, ..., z_n) in place;
 // newden = g0 / g.  False where the reference would divide by zero.
 template <class T, int N>
-__device__ __forceinline__ bool row_reduce(T (&z)[N], typename ET<T>::U mx, T g0, int lane, T &newden) {
+__device__ __forceinline__ bool row_reduce_rem(T (&z)[N], typename ET<T>::U mx, T g0, int lane, T &newden) {
   typedef typename ET<T>::U U;
   newden = g0;
   if (g0 == 1) return true;
@@ -687,11 +921,29 @@ __device__ __forceinline__ bool row_reduce(T (&z)[N], typename ET<T>::U mx, T g0
   return true;
 }
 
-template <class T, int NCH>
+// `narrow64` (128-bit entries only): every entry of the row and of the pivot row and both multipliers fit a long long --
+// the products are 64 x 64 -> 128 bits (four 32-bit multiply-adds each instead of ten) and cannot wrap; same bits.
+// LEANREG: the caller is short of registers (the one-wave 64-bit kernels under their 80-register bound) -- the remainder loop.
+template <class T, int NCH, bool LEANREG = false>
 __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, int pivj, T lpiv, T foo, T dpiv, T g0,
-                                           int lane, T &newden) {
+                                           int lane, T &newden, typename ET<T>::U gpre = 0, bool narrow64 = false) {
   typedef typename ET<T>::U U;
   U mx = 0;
+  if constexpr (sizeof(T) == 16) {
+    if (narrow64) {
+      const i64 lp64 = (i64)lpiv, foo64 = (i64)foo;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const int j = colof<T>(c, lane, 0);
+        const i64 p = (i64)r.v[c][0], q = (i64)prow[j];
+        T z = (T)p * (T)lp64 - (T)q * (T)foo64;
+        if (j == pivj) z = wmul(dpiv, foo);
+        r.v[c][0] = z;
+        mx |= uabs64(z);
+      }
+      return row_reduce<T, NCH>(reinterpret_cast<T(&)[NCH]>(r.v), mx, g0, lane, newden, wmul(dpiv, foo), gpre);
+    }
+  }
 #pragma unroll
   for (int c = 0; c < NCH; c++)
 #pragma unroll
@@ -703,7 +955,10 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
       r.v[c][h] = z;
       mx |= uabs64(z);
     }
-  return row_reduce<T, NCH * ET<T>::CPL>(reinterpret_cast<T(&)[NCH * ET<T>::CPL]>(r.v), mx, g0, lane, newden);
+  if constexpr (LEANREG)
+    return row_reduce_rem<T, NCH * ET<T>::CPL>(reinterpret_cast<T(&)[NCH * ET<T>::CPL]>(r.v), mx, g0, lane, newden);
+  else
+    return row_reduce<T, NCH * ET<T>::CPL>(reinterpret_cast<T(&)[NCH * ET<T>::CPL]>(r.v), mx, g0, lane, newden, wmul(dpiv, foo), gpre);
 }
 
 // The same for 128-bit rows whose operands are all below 2^31 (the row and the pivot row in magnitude class 0, the
@@ -712,7 +967,7 @@ __device__ __forceinline__ bool update_row(RowRegs<T, NCH> &r, const T *prow, in
 // bits as well, on row_reduce's 32-bit remainders and quotients -- with the same bits as the 128-bit code.
 template <int NCH>
 __device__ __forceinline__ bool update_row_narrow(RowRegs<i128, NCH> &r, const i128 *prow, int pivj, i64 lpiv, i64 foo, i64 dpiv,
-                                                  i64 g0, int lane, i128 &newden) {
+                                                  i64 g0, int lane, i128 &newden, u64 gpre = 0) {
   i64 z[NCH];
   u64 mx = 0;
 #pragma unroll
@@ -725,7 +980,7 @@ __device__ __forceinline__ bool update_row_narrow(RowRegs<i128, NCH> &r, const i
     mx |= uabs64(v);
   }
   i64 nd;
-  const bool ok = row_reduce<i64, NCH>(z, mx, g0, lane, nd);
+  const bool ok = row_reduce<i64, NCH>(z, mx, g0, lane, nd, dpiv * foo, gpre);
 #pragma unroll
   for (int c = 0; c < NCH; c++) r.v[c][0] = (i128)z[c];
   newden = (i128)nd;
@@ -1182,31 +1437,6 @@ __device__ int choose_column_slow(const Shared<T> &S, const T *vals, int W, int 
     }
   }
   return pivj;
-}
-
-// Wave-wide unsigned min / max without LDS traffic: a DPP butterfly inside each row of 16
-// lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row results
-// through the scalar unit.  Call with all 64 lanes active; the result is wave-uniform.
-template <bool MAX>
-__device__ __forceinline__ unsigned wave_minmax_u32(unsigned v) {
-#define PIP_DPP_STEP(ctrl)                                                                         \
-  {                                                                                                \
-    unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, 0xf, 0xf, false);     \
-    v = MAX ? (o > v ? o : v) : (o < v ? o : v);                                                   \
-  }
-  PIP_DPP_STEP(0xB1)   // quad_perm [1,0,3,2]
-  PIP_DPP_STEP(0x4E)   // quad_perm [2,3,0,1]
-  PIP_DPP_STEP(0x141)  // row_half_mirror
-  PIP_DPP_STEP(0x140)  // row_mirror
-#undef PIP_DPP_STEP
-  const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
-  const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
-  if (MAX) {
-    const unsigned a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
-    return a > b ? a : b;
-  }
-  const unsigned a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
-  return a < b ? a : b;
 }
 
 // ------------------------------------------------------------ tab_sort_rows
@@ -1833,11 +2063,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
 #endif
     constexpr int PF = (NCH * ET<T>::EW) <= 2 ? PIP_PF : ((NCH * ET<T>::EW) <= 4 ? 2 : 1);  // by the registers a row takes
     RowRegs<T, NCH> rr[PF];
+    if constexpr (!(sizeof(T) == 16 && PIP_OPT_LANEPREP)) {  // (the 128-bit row loop prepares its rows first, see below)
 #pragma unroll
-    for (int q = 0; q < PF; q++) {
-      const int w = wave + q * NW;
-      const int sw = q == 0 ? wq0 : (q == 1 ? wq1 : (int)S.work[w < nwork ? w : 0]);
-      if (w < nwork && sw != pslot) row_load<T, NCH>(rr[q], vals + (size_t)sw * W, ncolp, lane);
+      for (int q = 0; q < PF; q++) {
+        const int w = wave + q * NW;
+        const int sw = q == 0 ? wq0 : (q == 1 ? wq1 : (int)S.work[w < nwork ? w : 0]);
+        if (w < nwork && sw != pslot) row_load<T, NCH>(rr[q], vals + (size_t)sw * W, ncolp, lane);
+      }
     }
     // pivot scalars, traiter.c:394-396 (uniform, every thread); the determinant bookkeeping of
     // traiter.c:412-446 only needs them logged
@@ -1853,7 +2085,98 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     const int pc = pivj / (64 * ET<T>::CPL), ph = pivj % ET<T>::CPL, pl = (pivj % (64 * ET<T>::CPL)) / ET<T>::CPL;
     PROF(5);
     // ---------------- B: eliminate the pivot column (all waves) ----------------
-    {
+    if constexpr (sizeof(T) == 16 && PIP_OPT_LANEPREP) {
+      // 128-bit entries: the wave-uniform part of a row's update -- gcd(pivot, foo), the multipliers, and the gcd of the
+      // new denominator lp * den with the one entry of the new row known beforehand, dpiv * foo (row_reduce_wide's first
+      // fold) -- is a couple of 128-bit binary gcds, thousands of instructions a row when every lane computes the same one,
+      // several times the row's own arithmetic.  So a wave first prepares ALL its rows of this pivot, one row per lane
+      // (the row's entry in the pivot column is gathered from HBM, its denominator comes from LDS), and the row loop
+      // picks each row's scalars out of the lanes.
+      nupd += nwork - 1;
+      for (int wb = wave; wb < nwork; wb += NW * 64) {
+        T m_lp = pivot, m_foo = 0;
+        typename ET<T>::U m_g = 0;
+        {
+          const int wk = wb + lane * NW;
+          const int sk = wk < nwork ? (int)S.work[wk] : pslot;
+          if (sk != pslot) {
+            T fk = vals[(size_t)sk * W + pivj];
+            const T dk = S.den[sk];
+            T lpk = pivot, g0k = dk;
+            if (pivot != 1) {
+              const T d = gcd_i64(pivot, fk);
+              if (d != 1) {
+                lpk = exact_quo(pivot, d);
+                fk = exact_quo(fk, d);
+              }
+              g0k = wmul(lpk, dk);
+            }
+            m_lp = lpk;
+            m_foo = fk;
+            const T zf = wmul(dpiv, fk);
+            typename ET<T>::U g = uabs64(g0k);
+            if (g > 1 && zf != 0) g = gcd_mag(g, uabs64(zf));
+            m_g = zf != 0 ? g : 0;  // (0: nothing folded in, row_reduce_wide starts from |g0|)
+          }
+        }
+        for (int k = 0; k < 64; k++) {
+          const int w = wb + k * NW;
+          if (w >= nwork) break;
+          const int s = S.work[w];
+          T *row = vals + (size_t)s * W;
+          RowRegs<T, NCH> r;
+          if (s == pslot) {
+            // the slot is recycled for the row replacing ku's unit row (traiter.c:461-465,503-513)
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+              const int j = colof<T>(c, lane, 0);
+              r.v[c][0] = (j == pivj) ? dpiv : wneg(S.prow[j]);
+            }
+            row_store<T, NCH>(r, row, ncolp, lane);
+            row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, pred, has_parm, lane);
+            continue;
+          }
+          row_load<T, NCH>(r, row, ncolp, lane);
+          const T lp = readlane64(m_lp, k), foo = readlane64(m_foo, k);
+          const typename ET<T>::U gpre = (typename ET<T>::U)readlane64((T)m_g, k);
+          PROF(9);
+          if (foo == 0 && (S.sig[s] & SIG_RED)) {
+            // only reached with PIPAMD_T_NOSKIP: multipliers (1, 0) and gcd 1, the reference rewrites the row with the
+            // bits it read -- so do we, without the arithmetic
+            row_store<T, NCH>(r, row, ncolp, lane);
+            if (lane == 0) S.sig[s] &= ~0xC0;
+            continue;
+          }
+          const T den_s = uni64(S.den[s]);
+          const T g0 = pivot != 1 ? wmul(lp, den_s) : den_s;
+          PROF(10);
+          T nd;
+          bool done_small = false;
+          {
+            // operands all below 2^31 (both rows in magnitude class 0) under a denominator product of at most 63 bits:
+            // the update on 64-bit registers (update_row_narrow)
+            const T lim = (T)1 << 31, glim = (T)1 << 62;
+            if (PIP_OPT_NARROW128 && S.rcls[s] == 0 && prow_cls == 0 && lp < lim && foo < lim && foo > -lim && dpiv < lim &&
+                dpiv > -lim && g0 < glim && g0 > -glim) {
+              if (!update_row_narrow<NCH>(r, S.prow, pivj, (i64)lp, (i64)foo, (i64)dpiv, (i64)g0, lane, nd, (u64)gpre)) {
+                if (lane == 0) sc.bad = 1;
+              }
+              done_small = true;
+            }
+          }
+          // (classes of the 128-bit kernel: 0 below 2^31, 1 below 2^63)
+          const bool n64 = S.rcls[s] <= 1 && prow_cls <= 1 && fits64(lp) && fits64(foo);
+          if (!done_small && !update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd, gpre, n64)) {
+            if (lane == 0) sc.bad = 1;
+          }
+          PROF(11);
+          row_store<T, NCH>(r, row, ncolp, lane);
+          row_publish<T, NCH>(r, S, s, nvar, ncol, bigparm, pivj, SIG_RED, has_parm, lane);
+          if (lane == 0) S.den[s] = nd;
+          PROF(12);
+        }
+      }
+    } else {
       nupd += nwork - 1;
       for (int w0 = wave; w0 < nwork; w0 += NW * PF) {
         if (w0 != wave) {  // the first PF rows are already on their way
@@ -2005,7 +2328,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
                 done_small = true;
               }
             }
-            if (!done_small && !update_row<T, NCH>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
+            if (!done_small && !update_row<T, NCH, (NW == 1 && NCH == 1 && sizeof(T) == 8)>(r, S.prow, pivj, lp, foo, dpiv, g0, lane, nd)) {
               if (lane == 0) sc.bad = 1;
             }
             PROF(11);

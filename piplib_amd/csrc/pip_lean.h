@@ -704,7 +704,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
               zw[h] = v;
               mx |= uabs64(v);
             }
-            if (!row_reduce<i64, 2>(zw, mx, g0, lane, nd)) {
+            if (!row_reduce_rem<i64, 2>(zw, mx, g0, lane, nd)) {  // (the remainder loop: reduce_by_inverse costs this kernel 12 bytes of scratch)
               if (lane == 0) sc.bad = 1;
             }
             if (ballot64(((uabs64(zw[0]) | uabs64(zw[1])) >> 31) != 0) == 0) {
