@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpipamd.so")
-SOURCES = ["pip_adv_d.hip", "pip_adv_c.hip", "pip_adv_b.hip", "pip_adv_a.hip", "pip_adv_e.hip", "pip_kernels.hip", "pip_quast.hip", "pip_host.cpp",
+SOURCES = ["pip_adv_d.hip", "pip_adv_c.hip", "pip_adv_b.hip", "pip_adv_a.hip", "pip_adv_e.hip", "pip_adv_f.hip", "pip_kernels.hip", "pip_quast.hip", "pip_host.cpp",
            "pip_tree.cpp"]
 HEADERS = ["pip_job.h", "pip_host.h", "pip_quast.h", "pip_advance.h", "pip_lean.h", "pip_adv_inst.h", os.path.join("..", "..", "include", "piplib_amd.h")]
 

@@ -21,5 +21,7 @@
   X(i128, 1, 1, false, 0, false) X(i128, 1, 4, false, 0, false) X(i128, 2, 1, false, 0, false) \
   X(i128, 2, 4, false, 0, false) X(i128, 4, 1, false, 0, false) X(i128, 4, 4, false, 0, false) \
   X(i128, 8, 1, false, 0, false) X(i128, 8, 4, false, 0, false)
+// F: 128-bit entries, sixteen waves per tableau (a whole CU): the tail launches over a few long tableaux with hundreds of rows
+#define PIP_ADV_GROUP_F(X) X(i128, 1, 16, false, 0, false) X(i128, 2, 16, false, 0, false) X(i128, 4, 16, false, 0, false)
 #define PIP_ADV_DEFINE(...) template hipError_t launch_advance_t<__VA_ARGS__>(const AdvanceLaunch &);
 #endif

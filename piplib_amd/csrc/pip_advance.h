@@ -1569,6 +1569,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     if (J->status == PIPAMD_ST_CAPACITY && q.out_count && threadIdx.x == 0) {
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
       atomicMax(q.out_maxni, PIPAMD_Q_CAPFLAG | J->ni);
+      atomicAdd(q.out_maxni + 1, 1);  // (the list\'s third control word: tableaux out of rows)
     }
     return;
   }
@@ -2464,6 +2465,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? 
     if (status == PIPAMD_ST_CAPACITY && q.out_count) {  // no spare row left: the host re-houses it (expanser)
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
       atomicMax(q.out_maxni, PIPAMD_Q_CAPFLAG | ni);
+      atomicAdd(q.out_maxni + 1, 1);  // (the list\'s third control word: tableaux out of rows)
     }
   }
   if constexpr (GM) {  // give the HBM image back

@@ -62,6 +62,7 @@ extern "C" void pipamd_engine_destroy(pipamd_engine *e) {
   if (e->d_scratch) hipFree(e->d_scratch);
   for (void *b : e->d_side)
     if (b) hipFree(b);
+  for (int i = 0; i < e->nretired; i++) hipFree(e->retired[i]);
   if (e->d_side_count) hipFree(e->d_side_count);
   free(e->run);
   for (void *b : e->dt_buf)
@@ -175,7 +176,7 @@ extern "C" int pipamd_batch_load(pipamd_engine *e, void *d_ws, const pipamd_batc
 //         little parallelism is left, so the latency of a pivot is what counts.
 // Only then the host looks at the number of tableaux still running (normally 0; tableaux that
 // hit the per-launch pivot limit `iter_limit` go through further tail launches).
-#define Q_CTRL 2 /* control words per launch: out_count, out_maxni */
+#define Q_CTRL 3 /* control words per launch: out_count, out_maxni, the number of listed jobs that are out of rows */
 // Control words (out_count, out_maxni per launch) must be zero when a launch starts.  They come
 // from a pool of Q_POOL solves x Q_FAST launches that one memset zeroes every Q_POOL solves (a
 // solve of a small batch is a handful of runtime calls: this was a fifth of them); the rare
@@ -219,7 +220,7 @@ struct BatchRun {
   // of the engine and go on; the others are passed through.  A stage like a launch: it consumes the list and writes
   // the next one.  When the engine's limits (16-bit row codes; 128-bit entries: the LDS image) allow no larger
   // block, the pass only drops the jobs that are at the limit from the list: they keep PIPAMD_ST_CAPACITY.
-  int rehouse(int n) {
+  int rehouse(int n, int ncap) {
     pipamd_batch_desc d2 = d;
     int newS = curS * 2 > curS + 32 ? curS * 2 : curS + 32;
     if (e->grow_step > 0) newS = curS + e->grow_step;  // testing aid: many small growth rounds
@@ -229,7 +230,11 @@ struct BatchRun {
     if (newS < curS) newS = curS;  // == curS: nothing larger is allowed -- the pass drops the jobs that are at the limit
     PipBatchLayout nl;
     size_t jb2;
-    d2.batch = n;
+    // the side arena holds the jobs that are out of rows (`ncap`, counted by the launch that listed them), not the whole
+    // list: that also carries the jobs merely paused
+    if (ncap < 1) ncap = 1;
+    if (ncap > n) ncap = n;
+    d2.batch = ncap;
     for (;;) {
       d2.cap_cuts = newS - d.ni;
       if (pipamd_batch_layout(&d2, &nl, &jb2) == PIPAMD_OK) break;
@@ -239,27 +244,51 @@ struct BatchRun {
     int rc2 = next_stage();
     if (rc2) return rc2;
     const bool room = grow_round < PIPAMD_MAX_GROW;
-    const size_t need = (size_t)nl.per_job * (size_t)n * sizeof(int64_t) + 16;
-    if (room && e->side_bytes[grow_round] < need) {
-      if (e->d_side[grow_round]) HIPCHK(hipFree(e->d_side[grow_round]));
-      e->d_side[grow_round] = nullptr;
-      e->side_bytes[grow_round] = 0;
-      HIPCHK(hipMalloc(&e->d_side[grow_round], need));
-      e->side_bytes[grow_round] = need;
+    const size_t per_job_bytes = (size_t)nl.per_job * sizeof(int64_t);
+    const size_t need = per_job_bytes * (size_t)ncap + 16;
+    int side_cap = 0;
+    if (room) {
+      if (e->side_bytes[grow_round] < need) {
+        // grown geometrically; the outgrown arena is kept until the engine goes (hipFree in mid-stream would wait for
+        // every other batch in flight on the device); if the device has no room the jobs that do not fit the arena that
+        // is there keep PIPAMD_ST_CAPACITY -- the batch is not failed for them
+        size_t want = 2 * e->side_bytes[grow_round] > need ? 2 * e->side_bytes[grow_round] : need;
+        void *nb = nullptr;
+        if (hipMalloc(&nb, want) != hipSuccess) {
+          (void)hipGetLastError();
+          want = need;
+          if (hipMalloc(&nb, want) != hipSuccess) {
+            (void)hipGetLastError();
+            nb = nullptr;
+          }
+        }
+        if (nb) {
+          if (e->d_side[grow_round]) {
+            if (e->nretired < (int)(sizeof e->retired / sizeof e->retired[0]))
+              e->retired[e->nretired++] = e->d_side[grow_round];
+            else
+              HIPCHK(hipFree(e->d_side[grow_round]));
+          }
+          e->d_side[grow_round] = nb;
+          e->side_bytes[grow_round] = want;
+        }
+      }
+      const size_t fit = e->side_bytes[grow_round] > 16 ? (e->side_bytes[grow_round] - 16) / per_job_bytes : 0;
+      side_cap = fit < (size_t)ncap ? (int)fit : ncap;
     }
     if (!e->d_side_count) HIPCHK(hipMalloc((void **)&e->d_side_count, sizeof(int)));
     HIPCHK(hipMemsetAsync(e->d_side_count, 0, sizeof(int), st));
     // job offsets are in int64 units from `arena`, rows 16-byte aligned
-    const char *side = room ? (const char *)e->d_side[grow_round] : (const char *)arena;
+    const char *side = (room && e->d_side[grow_round]) ? (const char *)e->d_side[grow_round] : (const char *)arena;
     if (((side - (const char *)arena) & 15) != 0) side += 8;
     nl.arena_off = (int64_t)((side - (const char *)arena) / (ptrdiff_t)sizeof(int64_t));
     int *c = ctrl_of(stage);
     void *q5[5] = {list[(stage - 1) & 1], ctrl_of(stage - 1), list[stage & 1], c, c + 1};
-    HIPCHK(pipk_launch_rehouse(jobs, arena, q5, n, nl, e->d_side_count, room ? n : 0, st));
+    HIPCHK(pipk_launch_rehouse(jobs, arena, q5, n, nl, e->d_side_count, side_cap, st));
     stage++;
     if (room) grow_round++;
     curS = newS;
-    e->last_rehoused += n;  // an upper bound: the list also carries the jobs still running
+    e->last_rehoused += ncap;
     return PIPAMD_OK;
   }
 
@@ -300,13 +329,16 @@ struct BatchRun {
     // turn on a device busy with other batches' bulk launches, and nothing in the pivot launches depends on it -- a
     // tableau that overflowed goes on pivoting until the replay says so, its status and pivot count are the same.
     // The bulk launches log at most 2 x 96 pivots per tableau, the log holds PIPAMD_DETLOG.
-    int rc = launch(tail_waves, e->iter_limit, curS, upper, false, !replay_pending);
+    // (128-bit entries: a list shorter than the GPU has CUs gets a CU per tableau -- sixteen waves; what is left after the
+    // first tail launch are the few tableaux of hundreds of pivots and rows, each a latency chain of its own)
+    const bool wide16 = lay.ebits == 128 && lay.W <= 256 && upper <= 256 && !e->waves_per_job && !e->tail_waves;
+    int rc = launch(wide16 ? 16 : tail_waves, e->iter_limit, curS, upper, false, !replay_pending);
     if (rc) return rc;
     if (replay_pending) {
       HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, e->lone_batches, st));
       replay_pending = false;
     }
-    HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), Q_CTRL * sizeof(int), hipMemcpyDeviceToHost, st));
     return PIPAMD_OK;
   }
 
@@ -319,7 +351,7 @@ struct BatchRun {
     jobs = (PipJob *)d_ws;
     arena = (long long *)((char *)d_ws + jb);
     st = (hipStream_t)stream;
-    if (!e->h_run) HIPCHK(hipHostMalloc((void **)&e->h_run, 2 * sizeof(int), hipHostMallocDefault));
+    if (!e->h_run) HIPCHK(hipHostMalloc((void **)&e->h_run, Q_CTRL * sizeof(int), hipHostMallocDefault));
     if (!e->d_q || e->q_cap < lay.batch) {
       if (e->d_q) HIPCHK(hipFree(e->d_q));
       e->d_q = nullptr;
@@ -369,7 +401,7 @@ struct BatchRun {
         if (e->single_launch == 2) {  // measurement aid: the lean launch on its own
           if (replay_pending) HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, e->lone_batches, st));
           replay_pending = false;
-          HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+          HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), Q_CTRL * sizeof(int), hipMemcpyDeviceToHost, st));
           active = true;
           return PIPAMD_OK;
         }
@@ -395,7 +427,7 @@ struct BatchRun {
       if (e->single_launch) {  // measurement aid: the bulk launch on its own (its tableaux stay PIPAMD_ST_RUN)
         if (replay_pending) HIPCHK(pipk_launch_replay_all(jobs, arena, lay.batch, lay.ebits, e->lone_batches, st));
         replay_pending = false;
-        HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), Q_CTRL * sizeof(int), hipMemcpyDeviceToHost, st));
         active = true;
         return PIPAMD_OK;
       }
@@ -430,7 +462,7 @@ struct BatchRun {
     if (e->h_run[0] > 0 && !e->single_launch) {
       upper = e->h_run[0];
       if (e->h_run[1] & PIPAMD_Q_CAPFLAG) {  // some of them have spent their spare rows
-        int rc = rehouse(upper);
+        int rc = rehouse(upper, e->h_run[2]);
         if (rc) return rc;
       }
       int rc = tail();

@@ -21,7 +21,7 @@ struct pipamd_engine {
   int lone_batches;  /* 1: no general one-wave launch between the lean launch and the tail (pipamd_engine_set_lone_batches) */
   int no_lean;       /* 1: bulk launches without the lean kernel (pip_lean.h) */
   int no_lean2;      /* 1: the second one-wave bulk launch is the general kernel even where the lean kernel could resume */
-  int *h_run;        /* pinned: {jobs still running, their largest row count} */
+  int *h_run;        /* pinned: {jobs still running, their largest row count | PIPAMD_Q_CAPFLAG, how many of them are out of rows} */
   int *d_q;          /* launch-list control words (a pool, see pipamd_batch_solve) and the two job lists */
   unsigned solve_seq; /* solves since the control pool was last zeroed */
   hipStream_t pool_stream; /* the stream that zeroing was ordered on */
@@ -46,6 +46,8 @@ struct pipamd_engine {
   void *d_side[PIPAMD_MAX_GROW];
   size_t side_bytes[PIPAMD_MAX_GROW];
   int *d_side_count;
+  void *retired[128]; /* side arenas outgrown while batches were in flight: freed with the engine (hipFree waits for the device) */
+  int nretired;
   int max_rows;      /* row budget per tableau of pipamd_batch_solve's growth (0 = the engine's limit) */
   int grow_step;     /* testing aid: rows added per growth round (0 = double) */
   int last_rehoused; /* tableaux the last pipamd_batch_solve re-housed (all rounds) */

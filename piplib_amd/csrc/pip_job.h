@@ -52,7 +52,8 @@ typedef struct PipJob {
 } PipJob;
 
 /* pipamd_batch_solve's launch lists: a job that ran out of spare rows (PIPAMD_ST_CAPACITY) stays on the list, and
- * the list's `maxni` word carries this bit, until the host has re-housed it in a larger block */
+ * the list's `maxni` word carries this bit, until the host has re-housed it in a larger block; the word behind `maxni`
+ * counts these jobs (the host sizes the larger blocks' arena by it) */
 #define PIPAMD_Q_CAPFLAG (1 << 30)
 
 typedef struct PipBatchLayout {

@@ -12,6 +12,7 @@ PIP_ADV_GROUP_A(PIP_ADV_EXTERN)
 PIP_ADV_GROUP_B(PIP_ADV_EXTERN)
 PIP_ADV_GROUP_C(PIP_ADV_EXTERN)
 PIP_ADV_GROUP_D(PIP_ADV_EXTERN)
+PIP_ADV_GROUP_F(PIP_ADV_EXTERN)
 #undef PIP_ADV_EXTERN
 #define PIP_LEAN_EXTERN(SC, FULL) extern template hipError_t launch_lean<SC, FULL>(const AdvanceLaunch &);
 PIP_LEAN_CLASSES(PIP_LEAN_EXTERN)
@@ -608,6 +609,11 @@ static hipError_t launch_advance_w(bool one, const AdvanceLaunch &a) {
     // eight waves per job: the rows of a late pivot of a long tableau (15-25 of them change) are
     // spread over twice the waves -- for the few tableaux of a tail launch
     if (a.waves == 8) return launch_advance_t<T, NCH, 8, false, 0, false>(a);
+  }
+  if constexpr (sizeof(T) == 16 && NCH <= 4) {
+    // sixteen waves per job, a whole CU: the hundreds of rows a late pivot of a long 128-bit tableau rewrites, spread over
+    // four times the waves -- for a tail launch over a few such tableaux (fewer than the GPU has CUs)
+    if (a.waves == 16) return launch_advance_t<T, NCH, 16, false, 0, false>(a);
   }
   return one ? launch_advance_t<T, NCH, 1, false, 0, false>(a) : launch_advance_t<T, NCH, 4, false, 0, false>(a);
 }

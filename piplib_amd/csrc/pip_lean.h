@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
     if (J->status == PIPAMD_ST_CAPACITY && q.out_count && lane == 0) {
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
       atomicMax(q.out_maxni, PIPAMD_Q_CAPFLAG | J->ni);
+      atomicAdd(q.out_maxni + 1, 1);  // (the list\'s third control word: tableaux out of rows)
     }
     return;
   }
@@ -842,6 +843,7 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
     if (status == PIPAMD_ST_CAPACITY && q.out_count) {
       q.out_list[atomicAdd(q.out_count, 1)] = jb;
       atomicMax(q.out_maxni, PIPAMD_Q_CAPFLAG | ni);
+      atomicAdd(q.out_maxni + 1, 1);  // (the list\'s third control word: tableaux out of rows)
     }
   }
   PROF(11);

@@ -23,6 +23,12 @@ def run(name, r):
     e.set_max_rows(128 + 1280)
     if TW:
         e.set_tail_waves(TW)
+    # engine knobs from the environment: WAVES (waves per tableau, every launch), BULKMIN, ROUND (pivot budget of the
+    # one-wave bulk launches), ROUNDROWS (spare rows of their LDS image)
+    if os.environ.get("WAVES"): e.set_waves_per_job(int(os.environ["WAVES"]))
+    if os.environ.get("BULKMIN"): e.set_bulk_min(int(os.environ["BULKMIN"]))
+    if os.environ.get("ROUND"): e.set_round_pivots(int(os.environ["ROUND"]))
+    if os.environ.get("ROUNDROWS"): e.set_round_rows(int(os.environ["ROUNDROWS"]))
     e.set_timing(True)
     b = eng.Batch(e, r, 255, 0, tflags=eng.T_INT, entier_bits=128)
     for it in range(2):

@@ -11,12 +11,12 @@ args = types.SimpleNamespace(waves=int(sys.argv[3]) if len(sys.argv) > 3 else 0,
 dev = torch.device("cuda", 0)
 def barrier(): torch.cuda.synchronize(dev)
 fuse = int(os.environ.get("CFG_FUSE", "0")) or (max(1, min(16, 10000 // oc["batch"])) if oc["ebits"] == 64 else 1)
-ol = bench.Lanes(oc, od, dev, 0, [2000 + 7919 * i for i in range(od)], args, fuse=fuse)
-regs = sorted((bench.timed(ol, 8 * od * fuse, od, barrier) for _ in range(3)), key=lambda r: r[0])
+ol = bench.Lanes(oc, od, dev, 0, [[0] for _ in range(od)] if oc.get("family") else [[i * fuse + k for k in range(fuse)] for i in range(od)], args, fuse=fuse)
+regs = sorted((bench.timed(ol, (2 if oc.get("family") else 8) * od * fuse, od, barrier) for _ in range(3)), key=lambda r: r[0])
 dt, sh = regs[1]
 t = ol.totals(sh)
-o1 = bench.Lanes(oc, 1, dev, 0, [2000], args)
-n1 = int(os.environ.get("LONE_STEPS", "12"))
+o1 = bench.Lanes(oc, 1, dev, 0, [[0]], args)
+n1 = int(os.environ.get("LONE_STEPS", "2" if oc.get("family") else "12"))
 dt1, sh1 = bench.timed(o1, n1, 2, barrier)
 t1 = o1.totals(sh1)
 print("round %d rows %d: " % (args.round, args.round_rows), end="")
