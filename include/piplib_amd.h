@@ -114,6 +114,14 @@ int pipamd_engine_set_tail_waves(pipamd_engine *e, int waves);
  * launches run beside it; for a lone batch it is a long, nearly empty launch, and the tableaux go straight to the
  * tail launches instead (a lone 10k batch: 4.7 ms instead of 6.3 ms; 14 batches in flight: 10 % fewer pivots/s). */
 int pipamd_engine_set_lone_batches(pipamd_engine *e, int on);
+/* 128-bit batches without parameters of 129 ... 256 columns (at least 128 tableaux): 1 = the first launch of
+ * pipamd_batch_solve is the lean kernel of csrc/pip_lean64.h -- one wave per tableau, rows held as long longs while every
+ * entry fits 63 bits (half the traffic and registers), tableaux with a wider entry handed over to the 128-bit kernel.
+ * Default 0: on BASELINE's configs[4] it is no faster than the four-waves-per-tableau 128-bit kernel. */
+int pipamd_engine_set_lean64(pipamd_engine *e, int on);
+/* A tail launch of a 128-bit batch over at most 256 tableaux gives each a whole CU (sixteen waves): the hundreds of rows a
+ * late pivot of a long tableau rewrites spread over four times the waves (built in; pipamd_engine_set_tail_waves or
+ * _set_waves_per_job switch it off). */
 /* How pipamd_batch_solve waits for the device at its end: 0 (default) polls the stream, which is the
  * quickest for a few host threads; 1 naps 40 us between looks at the stream.  With more batches in flight
  * than the host has CPUs the spinning threads take turns on the cores: 48 batches of 1,250 tableaux on 16 CPUs ran

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpipamd.so")
 SOURCES = ["pip_adv_d.hip", "pip_adv_c.hip", "pip_adv_b.hip", "pip_adv_a.hip", "pip_adv_e.hip", "pip_adv_f.hip", "pip_kernels.hip", "pip_quast.hip", "pip_host.cpp",
            "pip_tree.cpp"]
-HEADERS = ["pip_job.h", "pip_host.h", "pip_quast.h", "pip_advance.h", "pip_lean.h", "pip_adv_inst.h", os.path.join("..", "..", "include", "piplib_amd.h")]
+HEADERS = ["pip_job.h", "pip_host.h", "pip_quast.h", "pip_advance.h", "pip_lean.h", "pip_lean64.h", "pip_adv_inst.h", os.path.join("..", "..", "include", "piplib_amd.h")]
 
 
 def needs_build():

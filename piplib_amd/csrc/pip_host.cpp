@@ -312,7 +312,8 @@ struct BatchRun {
     }
     void *big[2] = {&e->d_scratch, &e->scratch_bytes};
     // a uniform batch without parameters whose rows fill a wave's 128 columns exactly: FULL kernels
-    const int hints = ((lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 && lay.W == 128) ? 1 : 0) | (lean ? 2 : 0) | (replay ? 0 : 4);
+    const int hints = ((lay.nparm == 0 && lay.bigparm < 0 && lay.nvar + 1 == 128 && lay.W == 128) ? 1 : 0) |
+                      (lean ? (lay.ebits == 128 ? 8 : 2) : 0) | (replay ? 0 : 4);
     HIPCHK(pipk_launch_advance_q(jobs, arena, lay.batch, lay.nvar + smax, smax, lay.W, budget, waves, lay.ebits, q5, grid,
                                  big, hints, e->d_prof, st));
     if (!e->no_timing) HIPCHK(hipEventRecord(e->ev[2 * e->nlaunch + 1], st));
@@ -383,7 +384,27 @@ struct BatchRun {
     const int KA = !integer ? 0 : (e->round_rows > 0 ? e->round_rows : 48);
     tail_waves = e->waves_per_job ? e->waves_per_job : (e->tail_waves ? e->tail_waves : 4);
     upper = lay.batch;
-    if (lay.batch >= (e->bulk_min > 0 ? e->bulk_min : 2048) && e->waves_per_job != 4 && e->waves_per_job != 8) {
+    // The 128-bit flavour on rows of 129 ... 256 columns without parameters can start with the lean kernel of pip_lean64.h,
+    // one wave per tableau over the whole batch: it finishes the tableaux whose stored entries stay below 2^63 (two in
+    // three of BASELINE's configs[4]) and leaves the others to the launches below.  Opt-in (pipamd_engine_set_lean64):
+    // measured on that batch it is no faster than pip_advance_kernel's four waves per tableau.
+    bool took64 = false;
+    if (e->lean64 && !e->no_lean && lay.ebits == 128 && lay.nparm == 0 && lay.bigparm < 0 && lay.W > 128 && lay.W <= 256 &&
+        !(lay.tflags & (PIPAMD_T_NOSKIP | PIPAMD_T_DEEPEST)) && lay.batch >= (e->bulk_min > 0 ? e->bulk_min : 128) &&
+        e->waves_per_job != 4 && e->waves_per_job != 8) {
+      int smax = curS < 448 ? curS : 448;  // (448 rows: an image of 30 KB, five tableaux per CU)
+      if (smax >= lay.ni && pipk_lean64_lds_bytes(smax, lay.nvar + smax) <= PIPAMD_LDS_BUDGET) {
+        rc = launch(1, e->iter_limit, smax, lay.batch, true, true);
+        if (rc) return rc;
+        took64 = true;
+        if (e->single_launch) {  // measurement aid: the lean launch on its own (its unfinished tableaux stay PIPAMD_ST_RUN)
+          HIPCHK(hipMemcpyAsync(e->h_run, ctrl_of(stage - 1), Q_CTRL * sizeof(int), hipMemcpyDeviceToHost, st));
+          active = true;
+          return PIPAMD_OK;
+        }
+      }
+    }
+    if (!took64 && lay.batch >= (e->bulk_min > 0 ? e->bulk_min : 2048) && e->waves_per_job != 4 && e->waves_per_job != 8) {
       const int budget = e->iter_limit < K1 ? e->iter_limit : K1;
       int smax = lay.ni + (KA < budget ? KA : budget);
       if (smax > curS) smax = curS;
@@ -576,6 +597,14 @@ extern "C" int pipamd_debug_single_launch(pipamd_engine *e, int on) {
 extern "C" int pipamd_debug_lean(pipamd_engine *e, int on) {
   if (!e) return PIPAMD_E_INVALID;
   e->no_lean = on ? 0 : 1;
+  return PIPAMD_OK;
+}
+
+// The lean kernel of the 128-bit flavour (csrc/pip_lean64.h) as the first launch of pipamd_batch_solve on batches it can
+// take (no parameters, 129 ... 256 columns, at least 128 tableaux); default off.
+extern "C" int pipamd_engine_set_lean64(pipamd_engine *e, int on) {
+  if (!e) return PIPAMD_E_INVALID;
+  e->lean64 = on ? 1 : 0;
   return PIPAMD_OK;
 }
 

@@ -20,6 +20,7 @@ struct pipamd_engine {
   int single_launch; /* debug: stop after one launch */
   int lone_batches;  /* 1: no general one-wave launch between the lean launch and the tail (pipamd_engine_set_lone_batches) */
   int no_lean;       /* 1: bulk launches without the lean kernel (pip_lean.h) */
+  int lean64;        /* 1: 128-bit batches of 129 ... 256 columns start with the lean kernel of pip_lean64.h (pipamd_engine_set_lean64) */
   int no_lean2;      /* 1: the second one-wave bulk launch is the general kernel even where the lean kernel could resume */
   int *h_run;        /* pinned: {jobs still running, their largest row count | PIPAMD_Q_CAPFLAG, how many of them are out of rows} */
   int *d_q;          /* launch-list control words (a pool, see pipamd_batch_solve) and the two job lists */
@@ -65,6 +66,7 @@ int pipk_static_class(int smax);
 int pipk_lean_class(int smax);
 hipError_t pipk_launch_advance(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
                                int waves_per_job, int ebits, unsigned long long *prof, hipStream_t stream);
+size_t pipk_lean64_lds_bytes(int Smax, int Lmax);
 hipError_t pipk_launch_advance_q(PipJob *jobs, long long *arena, int njobs, int Lmax, int Smax, int Wmax, int iter_limit,
                                  int waves_per_job, int ebits, void *const *q5, int grid, void **big, int hints,
                                  unsigned long long *prof,

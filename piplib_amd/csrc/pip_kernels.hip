@@ -5,6 +5,7 @@
 // holds the determinant replay, the batch load / results / counters kernels, expanser for the batch layer, the
 // helpers of the lock-step scheduler and every launcher.
 #include "pip_lean.h"
+#include "pip_lean64.h"
 
 // the instantiations of the pivot kernel's launcher live in pip_adv_*.hip
 #define PIP_ADV_EXTERN(...) extern template hipError_t launch_advance_t<__VA_ARGS__>(const AdvanceLaunch &);
@@ -570,6 +571,7 @@ extern "C" int pipk_lean_class(int smax) {
   const int s = (smax + 3) & ~3;
   return s <= 64 ? 64 : (s <= 96 ? 96 : (s <= 112 ? 112 : (s <= 128 ? 128 : (s <= 160 ? 160 : 0))));
 }
+extern "C" size_t pipk_lean64_lds_bytes(int Smax, int Lmax) { return lean64_lds_bytes((Smax + 3) & ~3, (Lmax + 3) & ~3); }
 // the lean bulk kernel over a launch list; the caller has checked pipk_lean_class(a.Smax) != 0
 static hipError_t launch_lean_class(AdvanceLaunch a) {
   const int sc = pipk_lean_class(a.Smax);
@@ -633,7 +635,9 @@ static hipError_t launch_by_shape(const AdvanceLaunch &a, bool one, int wp, int 
 // the wave's column coverage (the caller knows its batch is uniform): see FULL.  Bit 1 (one wave per job, 64-bit entries, at
 // most 128 columns and pipk_lean_class(Smax) != 0, else refused) = the lean kernel of pip_lean.h: it runs the jobs it
 // can (no parameters, entries below 2^15) and leaves the others PIPAMD_ST_RUN on the output list for a launch without
-// this bit.  Bit 2: no determinant replay behind the launch (see pipk_launch_replay_all).
+// this bit.  Bit 2: no determinant replay behind the launch (see pipk_launch_replay_all).  Bit 3 (one wave per job, 128-bit
+// entries, 129 ... 256 columns, pipk_lean64_lds_bytes(Smax, Lmax) within the LDS budget, else refused) = the lean kernel of
+// pip_lean64.h: it runs the jobs it can (no parameters, entries below 2^63) and leaves the others on the output list.
 extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs, int Lmax, int Smax, int Wmax,
                                             int iter_limit, int waves_per_job, int ebits, void *const *q5, int grid,
                                             void **big, int hints, unsigned long long *prof, hipStream_t stream) {
@@ -698,6 +702,9 @@ extern "C" hipError_t pipk_launch_advance_q(PipJob *jobs, i64 *arena, int njobs,
   if (hints & 2) {
     if (!one || ebits != 64 || wp != 128 || a.gimg || !pipk_lean_class(a.Smax)) return hipErrorInvalidValue;
     le = launch_lean_class(a);
+  } else if (hints & 8) {  // the lean kernel of the 128-bit flavour (pip_lean64.h): 129 ... 256 columns, one wave per job
+    if (!one || ebits != 128 || wp != 256 || pipk_lean64_lds_bytes(a.Smax, a.Lmax) > PIPAMD_LDS_BUDGET) return hipErrorInvalidValue;
+    le = launch_lean64(a);
   } else {
     le = launch_by_shape(a, one, wp, ebits);
   }

@@ -117,6 +117,11 @@ class Engine:
         lib().pipamd_engine_set_lone_batches.argtypes = [C.c_void_p, C.c_int]
         _check(lib().pipamd_engine_set_lone_batches(self._h, int(bool(on))))
 
+    def set_lean64(self, on):
+        """128-bit batches of 129 ... 256 columns start with the lean kernel of csrc/pip_lean64.h (default off)"""
+        lib().pipamd_engine_set_lean64.argtypes = [C.c_void_p, C.c_int]
+        _check(lib().pipamd_engine_set_lean64(self._h, int(bool(on))))
+
     def set_tail_waves(self, n):
         lib().pipamd_engine_set_tail_waves.argtypes = [C.c_void_p, C.c_int]
         _check(lib().pipamd_engine_set_tail_waves(self._h, int(n)))

@@ -250,10 +250,11 @@ def test_bench_lane_seeds_all_finish():
     print("tableaux that needed more than ni + 64 cut rows and were re-housed:", grown)
 
 
-def _gpu128(rows, nvar, nq, cap_cuts):
+def _gpu128(rows, nvar, nq, cap_cuts, lean64=False):
     import torch
     from piplib_amd import engine as eng
     e = eng.Engine(0)
+    e.set_lean64(lean64)
     b = eng.Batch(e, rows, nvar, 0, tflags=eng.T_INT if nq else 0, cap_cuts=cap_cuts, entier_bits=128)
     b.load()
     b.solve()
@@ -386,6 +387,52 @@ def test_full_size_int128_config():
     assert same >= 990 and big >= 500 and limb == 0, (same, big, limb)
     checked, big24 = _check_against_records(g, recs)
     assert checked >= 12 and big24 >= 6, (checked, big24)
+
+
+def test_lean64_kernel_paths():
+    """The lean kernel of the 128-bit flavour (csrc/pip_lean64.h, opt-in: pipamd_engine_set_lean64): one wave per tableau,
+    rows held as long longs while every entry fits 63 bits.  configs[4]'s pinned batch through it -- two in three
+    tableaux finish there, a third leave on a row beyond 2^63 (stored in the general format mid-pivot, the tableau handed
+    to pip_advance_kernel<__int128>), a few on the launch's pivot budget -- must come out as without it (statuses, pivot
+    and cut counts, solutions) and as the reference's GMP build has it; then the same with rows multiplied through so that
+    entries start beyond 2^31 and near 2^62 (the 128-bit products from the first pivot; rows outgrow long longs at once), and a
+    rational solve."""
+    import numpy as np
+    import torch
+    import make_bigint_fixtures as mk  # noqa: F401
+    from piplib_amd import engine as eng
+    _bigint_family("wide128")
+    rows = mk.rows_full("wide128")
+    nvar = mk.FAMILIES["wide128"]["nvar"]
+    g1, g0 = _gpu128(rows, nvar, 1, None, lean64=True), _gpu128(rows, nvar, 1, None)
+    for name in ("status", "pivots", "cuts", "sol_num", "sol_den"):
+        assert (getattr(g1, name) == getattr(g0, name)).all(), name
+    same, big, limb = _check_against_gmp(g1, "wide128")
+    assert same >= 990 and big >= 500 and limb == 0, (same, big, limb)
+    # the lean launch on its own: how its tableaux ended (PipJob: status at byte 72, pivots at 80, exit reason at 172)
+    e = eng.Engine(0)
+    e.set_lean64(True)
+    e.debug_single_launch(1)
+    b = eng.Batch(e, rows, nvar, 0, tflags=eng.T_INT, entier_bits=128)
+    b.load()
+    b.solve()
+    torch.cuda.synchronize()
+    j = b.ws[:25 * rows.shape[0]].view(torch.int32).view(rows.shape[0], 50).cpu().numpy()
+    status, npiv, why = j[:, 18], j[:, 20], j[:, 43]
+    running = status == eng.ST_RUN
+    assert (npiv > 0).all() and (~running).sum() > 500 and (running & (why == 2)).sum() > 100 and (running & (why == 1)).any()
+    # other magnitudes and a rational solve: with and without the kernel
+    sub = rows[:160].copy()
+    for scale, nq in ((1 << 33, 1), (1 << 57, 1), (1, 0)):
+        r2 = sub.copy()
+        if scale > 1:
+            r2[::2, 5, :] *= scale   # every other tableau: one inequality multiplied through (same polyhedron)
+            for b_ in {1 << 33: (18,), 1 << 57: (92,)}[scale]:   # (scaled like that the CPU oracle does not finish these two)
+                r2[b_] = sub[b_]
+        a, c = _gpu128(r2, nvar, nq, None, lean64=True), _gpu128(r2, nvar, nq, None)
+        for name in ("status", "pivots", "cuts", "sol_num", "sol_den"):
+            assert (getattr(a, name) == getattr(c, name)).all(), (scale, nq, name)
+        assert (a.status.cpu().numpy() != eng.ST_RUN).all()
 
 
 def test_many_parametric_problems_multithreaded():

@@ -12,6 +12,7 @@ from piplib_amd import engine as eng
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 TW = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rows = mk.rows_full("wide128")
+REP = int(os.environ.get("REP", "1"))  # the batch REP times over (a larger batch of the same tableaux)
 rec = json.load(open(os.path.join(ROOT, "tests", "golden", "gmp", "wide128.json")))["problems"]
 piv = np.array([r["pivots"] for r in rec])
 order = np.argsort(piv)
@@ -48,7 +49,7 @@ def run(name, r):
 
 
 print("pivots of the %d longest: %s" % (N, sorted(piv[hard].tolist())))
-run("all", rows)
-run("without the %d longest" % N, rows[easy])
+run("all", np.concatenate([rows] * REP))
+run("without the %d longest" % N, np.concatenate([rows[easy]] * REP))
 run("the %d longest alone" % N, rows[hard])
 run("the longest alone", rows[order[-1:]])
