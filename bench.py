@@ -254,7 +254,7 @@ class Lanes:
         # sequence's middle launch for long, so the engines run in their lone-batches mode (pipamd_engine_set_lone_batches).
         # One MI355X, 96 steps of 10k tableaux: 2 lanes 234 -> 281 M pivots/s, 4 lanes 404 -> 393 M, 6 lanes 496 -> 432 M;
         # 20 steps of 1,250-tableau shards, five per sequence on 4 lanes: 265 -> 330 M.
-        self.lone = depth <= 3 or (passes is not None and passes <= depth <= 5)
+        self.lone = depth <= 3 or (passes is not None and passes <= depth <= 5) or getattr(args, "lone", -1) == 1
         # the input rows stay resident and untouched in HBM for the whole run: T_ROWS_STAY lets the first pivot
         # launch read them where they are instead of a copy pass (--copy-rows switches that off)
         stay = 0 if getattr(args, "copy_rows", False) else eng.T_ROWS_STAY
@@ -572,7 +572,7 @@ def roofline_of(b, e, k_ms, cfg, extra=None, split=None):
 def launch_split(b, e, cfg, parts):
     """Roofline per launch of one un-pipelined solve.  The launches do very different work per pivot: the lean bulk
     launch (csrc/pip_lean.h, one wave per tableau, int rows: the headline shape only) takes every tableau as far as
-    its entries stay below 2^15, the general one-wave launch the ones it left, the four-wave tail launches the long
+    its entries stay ints and its pivot budget lasts, a second one-wave launch the ones it left, the four-wave tail launches the long
     tableaux (a late pivot of a long tableau rewrites 15-25 rows, an early one 1-3).  Durations: HIP events around each
     launch; pivots and rows per launch: the batch solved again with the solve stopped after the lean launch and after
     the bulk launches (pipamd_debug_single_launch), the tail's = the whole solve's minus those."""
@@ -603,7 +603,8 @@ def launch_split(b, e, cfg, parts):
     if nb == 2:
         legs.append(("lean bulk (pip_lean_kernel, one wave per tableau, int rows)", ms[0], lean["pivots"], lean["rows_rewritten"],
                      lean["finished"]))
-        legs.append(("general bulk (pip_advance_kernel, one wave per tableau) over what the lean launch left", ms[1],
+        legs.append(("second bulk launch over what the first left (pip_lean_kernel again where the shape has one: it resumes its "
+                     "paused tableaux, 160 pivots more; else pip_advance_kernel, one wave per tableau)", ms[1],
                      bulk["pivots"] - lean["pivots"], bulk["rows_rewritten"] - lean["rows_rewritten"], bulk["finished"] - lean["finished"]))
     elif cfg["ebits"] == 64 and cfg["nvar"] <= 127 and cfg["ni"] + (48 if cfg["integer"] else 0) <= 160:
         # (an engine in lone-batches mode: the lean launch is the whole bulk stage)
@@ -611,7 +612,8 @@ def launch_split(b, e, cfg, parts):
                      bulk["finished"]))
     else:
         legs.append(("bulk (pip_advance_kernel, one wave per tableau)", ms[0], bulk["pivots"], bulk["rows_rewritten"], bulk["finished"]))
-    legs.append(("tail (pip_advance_kernel, four waves per tableau, %d launch%s)" % (n - nb, "" if n - nb == 1 else "es"), sum(ms[nb:]),
+    legs.append(("tail (pip_advance_kernel, four waves per tableau -- sixteen for a short list of 128-bit tableaux --, %d launch%s)"
+                 % (n - nb, "" if n - nb == 1 else "es"), sum(ms[nb:]),
                  whole["pivots"] - bulk["pivots"], whole["rows_rewritten"] - bulk["rows_rewritten"], whole["finished"] - bulk["finished"]))
     out = []
     for kind, t, piv, rows, fin in legs:
@@ -716,7 +718,7 @@ def main():
                     help="1: host threads sleep while the device works, 0: they poll; -1: sleep when there are more lanes than CPUs")
     ap.add_argument("--lone", type=int, default=-1,
                     help="0: a lone batch (--pipeline 1) keeps the launch sequence of the pipelined run (profiles); "
-                         "-1: it runs with pipamd_engine_set_lone_batches")
+                         "-1: it runs with pipamd_engine_set_lone_batches; 1: every lane does, whatever their number (experiments)")
     ap.add_argument("--copy-rows", action="store_true", help="load copies the input rows into the job blocks (no PIPAMD_T_ROWS_STAY)")
     ap.add_argument("--no-dense", action="store_true", help="skip the row-skipping-off measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

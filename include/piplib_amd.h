@@ -301,7 +301,7 @@ int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *problem
                           int *statuses, int64_t *pivots);
 
 /* The same on 128-bit entries (one TreeT<__int128> per host thread; cells as pipamd_traiter128 hands them out).  The
- * lock-step scheduler and the device-resident traiter() below stay 64-bit. */
+ * device-resident traiter() below stays 64-bit; the lock-step scheduler has a 128-bit entry (pipamd_solve_tableaux_lockstep128). */
 int pipamd_solve_tableaux128(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
                              int deepest_cut, int nthreads, pipamd_sol_cell128 **cells, size_t *n_cells, int *rcs,
                              int *statuses, int64_t *pivots);
@@ -314,6 +314,12 @@ int pipamd_solve_tableaux128(pipamd_engine *e, int n, const pipamd_problem *prob
 int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
                                    int deepest_cut, pipamd_sol_cell **cells, size_t *n_cells, int *rcs,
                                    int *statuses, int64_t *pivots);
+/* The lock-step scheduler of the overflow-safe flavour (piplib.h:42-88, funcall.h:37-41: the flavour is a type choice):
+ * device tableaux, contexts, parametric cuts and tape cells are 128-bit, one launch sequence per step serves the whole
+ * batch; no device-resident traiter() in front of it (that kernel is 64-bit); rare paths go to a TreeT<__int128>. */
+int pipamd_solve_tableaux_lockstep128(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
+                                      int deepest_cut, pipamd_sol_cell128 **cells, size_t *n_cells, int *rcs,
+                                      int *statuses, int64_t *pivots);
 /* Small problems (at most 64 columns and 64 inequalities, spare room for cuts and new parameters
  * included) are first given to the device-resident traiter() (csrc/pip_quast.hip): one wave per
  * problem runs the whole call tree -- pivots, compa_test sub-problems (traiter.c:162-243), forks of the

@@ -35,6 +35,7 @@ struct pipamd_engine {
   int no_device_tree; /* 1: pipamd_solve_tableaux_lockstep skips the device-resident traiter() (pip_quast.hip) */
   void *dt_buf[8];     /* device tree: device buffers kept between calls (problems, rows, stacks, tapes, results, ...) */
   size_t dt_cap[8];
+  int dt_small[8];     /* calls in a row that needed less than a quarter of the buffer (it is given back after eight) */
   pthread_mutex_t dt_lock; /* the device-tree buffers below serve one call at a time */
   void *dt_host;       /* device tree: pinned staging buffer for the problems' rows */
   size_t dt_host_cap;
@@ -82,9 +83,9 @@ hipError_t pipk_launch_rehouse(PipJob *jobs, long long *arena, void *const *q5, 
 hipError_t pipk_launch_rehouse_finish(PipJob *jobs, long long *arena, int njobs, int sol_words, hipStream_t stream);
 hipError_t pipk_launch_clone(long long *arena, const long long *list, int n, hipStream_t stream);
 hipError_t pipk_launch_patch(long long *arena, const int *buf, const long long *index, int n, hipStream_t stream);
-hipError_t pipk_launch_fresh(long long *arena, const long long *buf, const long long *index, int n, hipStream_t stream);
+hipError_t pipk_launch_fresh(long long *arena, const long long *buf, const long long *index, int n, int ebits, hipStream_t stream);
 hipError_t pipk_launch_gather(const PipJob *jobs, const long long *arena, int njobs, long long *out,
-                              const long long *off, hipStream_t stream);
+                              const long long *off, int ebits, hipStream_t stream);
 hipError_t pipk_launch_batch_counters(const PipJob *jobs, int njobs, unsigned long long *out, hipStream_t stream);
 }
 #endif

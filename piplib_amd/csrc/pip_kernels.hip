@@ -416,18 +416,21 @@ __global__ void pip_patch_kernel(int *arena32, const int *buf, const i64 *index,
   for (int i = threadIdx.x; i < nw; i += blockDim.x) arena32[dst + i] = p[3 + i];
 }
 // fresh: build new tableaux (tab_alloc + tab_get, tab.c:158-248) from their rows alone.
-// Record r at buf[index[r]] (int64 words): rows_off, nvar, ni, ncol, L, S, W, then ni*ncol values.
+// Record r at buf[index[r]] (int64 words): rows_off, nvar, ni, ncol, L, S, W, 0, then ni*ncol values of the entry type T
+// (the offsets are the job's, in int64 words; a 128-bit value is two words, low first).
+template <class T>
 __global__ void pip_fresh_kernel(i64 *arena, const i64 *buf, const i64 *index, int n) {
+  constexpr int EW = sizeof(T) / 8;
   const int b = blockIdx.x;
   if (b >= n) return;
   const i64 *p = buf + index[b];
   const i64 rows_off = p[0];
   const int nvar = (int)p[1], ni = (int)p[2], ncol = (int)p[3], L = (int)p[4], S = (int)p[5], W = (int)p[6];
-  const i64 *src = p + 7;
-  i64 *g_den = arena + rows_off;
+  const T *src = (const T *)(p + 8);
+  T *g_den = (T *)(arena + rows_off);
   int *g_flag = (int *)(g_den + L);
   int *g_ref = g_flag + L;
-  i64 *vals = arena + rows_off + 2 * (i64)L;
+  T *vals = (T *)(arena + rows_off + (i64)L * EW + L);
   for (int i = threadIdx.x; i < nvar + ni; i += blockDim.x) {
     g_den[i] = 1;
     g_flag[i] = i < nvar ? PIPAMD_F_UNIT : PIPAMD_F_UNKNOWN;
@@ -435,7 +438,7 @@ __global__ void pip_fresh_kernel(i64 *arena, const i64 *buf, const i64 *index, i
   }
   for (int e = threadIdx.x; e < ni * W; e += blockDim.x) {
     const int s = e / W, j = e % W;
-    vals[e] = j < ncol ? src[(size_t)s * ncol + j] : 0;
+    vals[e] = j < ncol ? src[(size_t)s * ncol + j] : (T)0;
   }
   const int pad = W - ncol;
   for (int e = threadIdx.x; e < (S - ni) * pad; e += blockDim.x) {
@@ -444,21 +447,23 @@ __global__ void pip_fresh_kernel(i64 *arena, const i64 *buf, const i64 *index, i
   }
 }
 
-// gather: what the host needs from each job of the last launch, by status, into out + off[b]:
+// gather: what the host needs from each job of the last launch, by status, into out + off[b] (off in int64 words; every
+// item is a value of the entry type T):
 //   NEED_COMPA  : n, then per undecided row (ascending): row, critic, constant, nparm parameter coefs
 //   NEED_PARMCUT: row (aux), denominator, ncol entries
 //   SOLUTION    : the solution block (nvar*(nparm+1) numerators, nvar denominators)
+template <class T>
 __global__ void pip_gather_kernel(const PipJob *jobs, const i64 *arena, int njobs, i64 *out, const i64 *off) {
   const int b = blockIdx.x;
   if (b >= njobs) return;
   const PipJob *J = &jobs[b];
   if (off[b + 1] == off[b]) return;  // the host does not want anything from this job
-  i64 *o = out + off[b];
+  T *o = (T *)(out + off[b]);
   const int nvar = J->nvar, nparm = J->nparm, L = J->L, W = J->W, ncol = nvar + nparm + 1;
-  const i64 *g_den = arena + J->rows_off;
+  const T *g_den = (const T *)(arena + J->rows_off);
   const int *g_flag = (const int *)(g_den + L);
   const int *g_ref = g_flag + L;
-  const i64 *vals = arena + J->vals_off;
+  const T *vals = (const T *)(arena + J->vals_off);
   const int lane = threadIdx.x;  // one wave
   if (J->status == PIPAMD_ST_NEED_COMPA) {
     const int nligne = nvar + J->ni;
@@ -469,8 +474,8 @@ __global__ void pip_gather_kernel(const PipJob *jobs, const i64 *arena, int njob
       const bool und = k < nligne && (g_flag[k] & (PIPAMD_F_CRITIC | PIPAMD_F_UNKNOWN));
       const u64 m = __ballot(und);
       if (und) {
-        const i64 *r = vals + (size_t)g_ref[k] * W;
-        i64 *q = o + 1 + (size_t)(base + __popcll(m & ((1ull << lane) - 1))) * rec;
+        const T *r = vals + (size_t)g_ref[k] * W;
+        T *q = o + 1 + (size_t)(base + __popcll(m & ((1ull << lane) - 1))) * rec;
         int critic = 1;
         for (int j = 0; j < nvar; j++)
           if (r[j] > 0) {
@@ -487,14 +492,14 @@ __global__ void pip_gather_kernel(const PipJob *jobs, const i64 *arena, int njob
     if (lane == 0) o[0] = base;
   } else if (J->status == PIPAMD_ST_NEED_PARMCUT) {
     const int ci = J->aux;
-    const i64 *r = vals + (size_t)g_ref[ci] * W;
+    const T *r = vals + (size_t)g_ref[ci] * W;
     if (lane == 0) {
       o[0] = ci;
       o[1] = g_den[ci];
     }
     for (int j = lane; j < ncol; j += 64) o[2 + j] = r[j];
   } else if (J->status == PIPAMD_ST_SOLUTION) {
-    const i64 *sn = arena + J->sol_off;
+    const T *sn = (const T *)(arena + J->sol_off);
     const int n = nvar * (nparm + 1) + nvar;
     for (int e = lane; e < n; e += 64) o[e] = sn[e];
   }
@@ -510,15 +515,21 @@ extern "C" hipError_t pipk_launch_patch(i64 *arena, const int *buf, const i64 *i
   hipLaunchKernelGGL(pip_patch_kernel, dim3(n), dim3(128), 0, stream, (int *)arena, buf, index, n);
   return hipGetLastError();
 }
-extern "C" hipError_t pipk_launch_fresh(i64 *arena, const i64 *buf, const i64 *index, int n, hipStream_t stream) {
+extern "C" hipError_t pipk_launch_fresh(i64 *arena, const i64 *buf, const i64 *index, int n, int ebits, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pip_fresh_kernel, dim3(n), dim3(128), 0, stream, arena, buf, index, n);
+  if (ebits == 128)
+    hipLaunchKernelGGL(pip_fresh_kernel<i128>, dim3(n), dim3(128), 0, stream, arena, buf, index, n);
+  else
+    hipLaunchKernelGGL(pip_fresh_kernel<i64>, dim3(n), dim3(128), 0, stream, arena, buf, index, n);
   return hipGetLastError();
 }
-extern "C" hipError_t pipk_launch_gather(const PipJob *jobs, const i64 *arena, int njobs, i64 *out, const i64 *off,
+extern "C" hipError_t pipk_launch_gather(const PipJob *jobs, const i64 *arena, int njobs, i64 *out, const i64 *off, int ebits,
                                          hipStream_t stream) {
   if (njobs <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pip_gather_kernel, dim3(njobs), dim3(64), 0, stream, jobs, arena, njobs, out, off);
+  if (ebits == 128)
+    hipLaunchKernelGGL(pip_gather_kernel<i128>, dim3(njobs), dim3(64), 0, stream, jobs, arena, njobs, out, off);
+  else
+    hipLaunchKernelGGL(pip_gather_kernel<i64>, dim3(njobs), dim3(64), 0, stream, jobs, arena, njobs, out, off);
   return hipGetLastError();
 }
 

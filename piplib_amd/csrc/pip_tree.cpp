@@ -1145,16 +1145,25 @@ extern "C" int pipamd_solve_tableaux128(pipamd_engine *e, int n, const pipamd_pr
 // Problems that hit a rare path (capacity growth, deepest cuts, dual) are handed to the Tree.
 namespace {
 
-struct FResult {
+template <class E> struct FResultT {
   int rc = PIPAMD_OK, status = 0;
   long long pivots = 0;
   bool is_void = false;
-  std::vector<Cell> tape;
+  std::vector<CellT<E>> tape;
 };
+typedef FResultT<i64> FResult;
 
-class Forest {
+// E = the entry type of the device tableaux, of the contexts, cut rows and tape cells on the host: long long, or __int128
+// for the overflow-safe flavour (the same scheduler; blocks, patches and gathered records are EW = 1 or 2 int64 words a value).
+template <class E>
+class ForestT {
+  typedef CtxT<E> Ctx;
+  typedef CellT<E> Cell;
+  typedef FResultT<E> FResult;
+  static constexpr int EW = (int)(sizeof(E) / 8), EBITS = 64 * EW;
+
  public:
-  explicit Forest(int device) {
+  explicit ForestT(int device) {
     (void)device;
     const hipError_t err = hipStreamCreateWithFlags(&st_, hipStreamNonBlocking);
     if (err != hipSuccess) {
@@ -1163,7 +1172,7 @@ class Forest {
       throw (int)PIPAMD_E_HIP;
     }
   }
-  ~Forest() {
+  ~ForestT() {
     void *bufs[] = {d_arena_, d_jobs_, d_off_, d_out_, d_patch_, d_pidx_, d_clone_, d_fresh_, d_fidx_, d_big_};
     for (void *b : bufs)
       if (b) hipFree(b);
@@ -1268,7 +1277,7 @@ class Forest {
     size_t mark = 0;  // region top when the frame was pushed (released when it pops)
     // compa_test in flight
     std::vector<int> rows, critic;
-    std::vector<std::vector<i64>> rowvals;  // constant | parameters of each undecided row
+    std::vector<std::vector<E>> rowvals;  // constant | parameters of each undecided row
     int sub_begin = 0, sub_count = 0;
     // split in flight (this frame is the parent waiting for its "then" child)
     int split_row = -1;
@@ -1321,8 +1330,8 @@ class Forest {
   static size_t block_words(int nvar, int S, int W) {
     W = even(W);
     const int L = even(nvar + S);
-    return 2 * (size_t)L + (size_t)S * W + (size_t)even(nvar * (W - nvar) + nvar) + (size_t)even(S * 8 + (3 * L + 7) / 8) +
-           2 * PIPAMD_DETLOG;
+    return (size_t)L * EW + (size_t)L + (size_t)S * W * EW + (size_t)even(nvar * (W - nvar) + nvar) * EW +
+           (size_t)even(S * 8 + (3 * L + 7) / 8) + 2 * PIPAMD_DETLOG * EW;
   }
   template <class T>
   void ensure(T *&buf, size_t &cap, size_t bytes) {
@@ -1340,7 +1349,7 @@ class Forest {
     q.done = true;
     q.rc = code;
   }
-  void tape_push(int i, int kind, i64 a, i64 b) {
+  void tape_push(int i, int kind, E a, E b) {
     P_[i].tape.push_back(Cell{kind, a, b});
     if (P_[i].tape.size() >= 4096) fail(i, PIPAMD_ST_INTERNAL);
   }
@@ -1353,8 +1362,9 @@ class Forest {
     patch_.push_back(n32);
     patch_.insert(patch_.end(), data, data + n32);
   }
-  void patch64(size_t dst64, const i64 *data, size_t n64) { patch32(dst64 * 2, (const int *)data, (int)(n64 * 2)); }
-  void patch_flag(const PipJob &pj, int row, int f) { patch32(((size_t)pj.rows_off + pj.L) * 2 + row, &f, 1); }
+  // n values of the entry type at int64 word dst64
+  void patch_vals(size_t dst64, const E *data, size_t n) { patch32(dst64 * 2, (const int *)data, (int)(n * 2 * EW)); }
+  void patch_flag(const PipJob &pj, int row, int f) { patch32(((size_t)pj.rows_off + (size_t)pj.L * EW) * 2 + row, &f, 1); }
 
   // ---- jobs ---------------------------------------------------------------
   // allocate a job block in problem i's region; throws TOOLARGE (-> Tree path) when it is full
@@ -1365,7 +1375,7 @@ class Forest {
     S = std::max(S, ni + 1);
     W = even(std::max(W, nvar + nparm + 1));
     if (W > PIPAMD_MAXCOL || S > PIPAMD_SMAX || nvar + S > PIPAMD_LMAX ||
-        pipk_advance_lds_bytes((even(nvar + S) + 3) & ~3, (S + 3) & ~3, W, 64) > PIPAMD_LDS_BUDGET)
+        pipk_advance_lds_bytes((even(nvar + S) + 3) & ~3, (S + 3) & ~3, W, EBITS) > PIPAMD_LDS_BUDGET)
       throw (int)PIPAMD_E_TOOLARGE;
     const int L = even(nvar + S);
     const size_t words = block_words(nvar, S, W);
@@ -1373,10 +1383,10 @@ class Forest {
     const i64 off = (i64)(q.region_off + q.top);
     q.top += words;
     pj.rows_off = off;
-    pj.vals_off = off + 2 * (i64)L;
-    pj.sol_off = pj.vals_off + (i64)S * W;
-    pj.state_off = pj.sol_off + even(nvar * (W - nvar) + nvar);
-    pj.log_off = off + (i64)words - 2 * PIPAMD_DETLOG;
+    pj.vals_off = off + (i64)L * EW + (i64)L;
+    pj.sol_off = pj.vals_off + (i64)S * W * EW;
+    pj.state_off = pj.sol_off + (i64)even(nvar * (W - nvar) + nvar) * EW;
+    pj.log_off = off + (i64)words - 2 * PIPAMD_DETLOG * EW;
     pj.nvar = nvar;
     pj.nparm = nparm;
     pj.ni = ni;
@@ -1388,7 +1398,7 @@ class Forest {
     pj.status = PIPAMD_ST_RUN;
     pj.ldet = 1;
     pj.det[0] = 1;
-    pj.ebits = 64;
+    pj.ebits = EBITS;
     jobs_.push_back(pj);
     is_sub_.push_back(0);
     return (int)jobs_.size() - 1;
@@ -1397,19 +1407,27 @@ class Forest {
   void fresh_begin(int job) {
     const PipJob &pj = jobs_[job];
     fidx_.push_back((i64)fresh_.size());
-    const i64 hdr[7] = {pj.rows_off, pj.nvar, pj.ni, pj.nvar + pj.nparm + 1, pj.L, pj.S, pj.W};
-    fresh_.insert(fresh_.end(), hdr, hdr + 7);
+    const i64 hdr[8] = {pj.rows_off, pj.nvar, pj.ni, pj.nvar + pj.nparm + 1, pj.L, pj.S, pj.W, 0};
+    fresh_.insert(fresh_.end(), hdr, hdr + 8);
   }
-  void fresh_block(int job, const std::vector<i64> &rows) {
+  // values of the entry type behind a record's header (EW words each, low word first)
+  void fresh_vals(const E *v, size_t n) {
+    const i64 *w = (const i64 *)v;
+    fresh_.insert(fresh_.end(), w, w + n * EW);
+  }
+  void fresh_block(int job, const std::vector<i64> &rows) {  // (input rows: long longs in either flavour)
     fresh_begin(job);
-    fresh_.insert(fresh_.end(), rows.begin(), rows.end());
+    for (i64 x : rows) {
+      const E v = (E)x;
+      fresh_vals(&v, 1);
+    }
   }
-  int context_job(int i, const Ctx &ctx, int nparm, int nc, const std::vector<i64> *extra) {
+  int context_job(int i, const Ctx &ctx, int nparm, int nc, const std::vector<E> *extra) {
     const int ni = nc + (extra ? 1 : 0), ncol = nparm + 1;
     const int job = new_job(i, nparm, 0, ni, -1, PIPAMD_T_INT, ni + 16, ncol);
     fresh_begin(job);
-    for (int k = 0; k < nc; k++) fresh_.insert(fresh_.end(), &ctx.v[(size_t)k * ctx.width], &ctx.v[(size_t)k * ctx.width] + ncol);
-    if (extra) fresh_.insert(fresh_.end(), extra->begin(), extra->begin() + ncol);
+    for (int k = 0; k < nc; k++) fresh_vals(&ctx.v[(size_t)k * ctx.width], ncol);
+    if (extra) fresh_vals(extra->data(), ncol);
     is_sub_[job] = 1;
     return job;
   }
@@ -1436,7 +1454,7 @@ class Forest {
     f.ctx.reserve(p.nc + 4, p.nparm + 2);
     f.ctx.nc = p.nc;
     for (int r = 0; r < p.nc; r++)
-      for (int k = 0; k <= p.nparm; k++) f.ctx.at(r, k) = c[(size_t)r * (p.nparm + 1) + k];
+      for (int k = 0; k <= p.nparm; k++) f.ctx.at(r, k) = (E)c[(size_t)r * (p.nparm + 1) + k];
     f.nparm = p.nparm;
     f.mark = 0;
     if (p.nc) {  // context emptiness test first (maind.c:196-203)
@@ -1491,7 +1509,7 @@ class Forest {
       ensure(d_fidx_, fidx_cap_, sizeof(i64) * fidx_.size());
       HIPTHROW(hipMemcpyAsync(d_fresh_, fresh_.data(), sizeof(i64) * fresh_.size(), hipMemcpyHostToDevice, st_));
       HIPTHROW(hipMemcpyAsync(d_fidx_, fidx_.data(), sizeof(i64) * fidx_.size(), hipMemcpyHostToDevice, st_));
-      HIPTHROW(pipk_launch_fresh(d_arena_, d_fresh_, d_fidx_, (int)fidx_.size(), st_));
+      HIPTHROW(pipk_launch_fresh(d_arena_, d_fresh_, d_fidx_, (int)fidx_.size(), EBITS, st_));
     }
     if (!pidx_.empty()) {
       ensure(d_patch_, patch_cap_, sizeof(int) * patch_.size());
@@ -1503,7 +1521,7 @@ class Forest {
     HIPTHROW(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(PipJob) * n, hipMemcpyHostToDevice, st_));
     // the staging vectors must stay alive until the copies are done: sync once before reuse
     for (int guard = 0; guard < 4096; guard++) {
-      HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, 64, nullptr, 0, big_, 0,
+      HIPTHROW(pipk_launch_advance_q(d_jobs_, d_arena_, n, Lm, Sm, Wm, 1 << 20, n >= 2048 ? 1 : 4, EBITS, nullptr, 0, big_, 0,
                                      nullptr, st_));
       HIPTHROW(hipMemcpyAsync(tab.data(), d_jobs_, sizeof(PipJob) * n, hipMemcpyDeviceToHost, st_));
       HIPTHROW(hipStreamSynchronize(st_));
@@ -1528,18 +1546,18 @@ class Forest {
         else if (tab[k].status == PIPAMD_ST_SOLUTION)
           need = (size_t)tab[k].nvar * (tab[k].nparm + 2);
       }
-      goff_[k + 1] = goff_[k] + (i64)need;
+      goff_[k + 1] = goff_[k] + (i64)need * EW;
     }
     ensure(d_out_, out_cap_, sizeof(i64) * (size_t)goff_[n] + 8);
     HIPTHROW(hipMemcpyAsync(d_off_, goff_.data(), sizeof(i64) * (n + 1), hipMemcpyHostToDevice, st_));
-    HIPTHROW(pipk_launch_gather(d_jobs_, d_arena_, n, d_out_, d_off_, st_));
+    HIPTHROW(pipk_launch_gather(d_jobs_, d_arena_, n, d_out_, d_off_, EBITS, st_));
     gout_.resize((size_t)goff_[n]);
     if (goff_[n])
       HIPTHROW(hipMemcpyAsync(gout_.data(), d_out_, sizeof(i64) * (size_t)goff_[n], hipMemcpyDeviceToHost, st_));
     HIPTHROW(hipStreamSynchronize(st_));
     for (int k = 0; k < n; k++) jobs_[lj[k]] = tab[k];
   }
-  const i64 *gathered(int job) const { return gout_.data() + goff_[lpos_[job]]; }
+  const E *gathered(int job) const { return (const E *)(gout_.data() + goff_[lpos_[job]]); }
 
   // ---- host side of one problem after a step ----------------------------------------
   void pop_frame(int i) {
@@ -1554,7 +1572,7 @@ class Forest {
     Frame &f = q.stack.back();
     const int nc = f.ctx.nc;
     for (int j = 0; j < f.nparm; j++) f.ctx.at(nc, j) = wneg(f.ctx.at(nc, j));
-    f.ctx.at(nc, f.nparm) = wneg(wadd(f.ctx.at(nc, f.nparm), (i64)1));
+    f.ctx.at(nc, f.nparm) = wneg(wadd(f.ctx.at(nc, f.nparm), (E)1));
     f.ctx.nc = nc + 1;
     patch_flag(jobs_[f.job], f.split_row, PIPAMD_F_MINUS);
     jobs_[f.job].status = PIPAMD_ST_RUN;
@@ -1589,19 +1607,19 @@ class Forest {
     }
     switch (st) {
       case PIPAMD_ST_SOLUTION: {
-        const i64 *g = gathered(f.job);
+        const E *g = gathered(f.job);
         const int nvar = q.nvar, np = f.nparm;
         const size_t nn = (size_t)nvar * (np + 1);
-        tape_push(i, S_LIST, nvar, 0);
+        tape_push(i, S_LIST, (E)nvar, (E)0);
         for (int r = 0; r < nvar; r++) {
-          tape_push(i, S_FORM, np + 1, 0);
+          tape_push(i, S_FORM, (E)(np + 1), (E)0);
           for (int j = 0; j <= np; j++) tape_push(i, S_VAL, g[(size_t)r * (np + 1) + j], g[nn + r]);
         }
         pop_frame(i);
         return;
       }
       case PIPAMD_ST_NIL:
-        tape_push(i, S_NIL, 0, 0);
+        tape_push(i, S_NIL, (E)0, (E)0);
         pop_frame(i);
         return;
       case PIPAMD_ST_NEED_PARMCUT: parm_cut(i); return;
@@ -1616,7 +1634,7 @@ class Forest {
     Prob &q = P_[i];
     Frame &f = q.stack.back();
     if (f.nparm >= PIPAMD_MAXPARM) fail(i, PIPAMD_ST_INTERNAL);
-    const i64 *g = gathered(f.job);
+    const E *g = gathered(f.job);
     const int nrec = (int)g[0], rec = 3 + f.nparm, np = f.nparm;
     f.rows.clear();
     f.critic.clear();
@@ -1624,17 +1642,17 @@ class Forest {
     f.sub_begin = (int)jobs_.size();
     f.sub_count = 0;
     for (int t = 0; t < nrec; t++) {
-      const i64 *r = g + 1 + (size_t)t * rec;
+      const E *r = g + 1 + (size_t)t * rec;
       f.rows.push_back((int)r[0]);
       f.critic.push_back((int)r[1]);
-      std::vector<i64> rv(r + 2, r + 3 + np);  // constant | parameters
+      std::vector<E> rv(r + 2, r + 3 + np);  // constant | parameters
       f.rowvals.push_back(rv);
-      std::vector<i64> ex(np + 1);
+      std::vector<E> ex(np + 1);
       for (int j = 0; j < np; j++) ex[j] = rv[1 + j];
-      ex[np] = r[1] ? rv[0] : wsub(rv[0], (i64)1);
+      ex[np] = r[1] != 0 ? rv[0] : wsub(rv[0], (E)1);
       context_job(i, f.ctx, np, f.ctx.nc, &ex);
       for (int j = 0; j < np; j++) ex[j] = wneg(rv[1 + j]);
-      ex[np] = wsub(wneg(rv[0]), (i64)1);
+      ex[np] = wsub(wneg(rv[0]), (E)1);
       context_job(i, f.ctx, np, f.ctx.nc, &ex);
       f.sub_count += 2;
     }
@@ -1700,7 +1718,7 @@ class Forest {
     Frame &f = q.stack.back();
     if (f.nparm >= PIPAMD_MAXPARM) fail(i, PIPAMD_ST_INTERNAL);
     const int np = f.nparm, pivi = f.rows[t];
-    const std::vector<i64> &rv = f.rowvals[t];
+    const std::vector<E> &rv = f.rowvals[t];
     Frame c;
     c.kind = K_NODE;
     c.phase = PH_RUN;
@@ -1717,20 +1735,20 @@ class Forest {
     memcpy(cj.det, pj.det, sizeof pj.det);
     clones_.push_back(pj.rows_off);
     clones_.push_back(cj.rows_off);
-    clones_.push_back(2 * (i64)pj.L + (i64)pj.S * pj.W);
-    tape_push(i, S_IF, 0, 0);
-    tape_push(i, S_FORM, np + 1, 0);
-    i64 g = 0;
+    clones_.push_back((i64)pj.L * EW + (i64)pj.L + (i64)pj.S * pj.W * EW);
+    tape_push(i, S_IF, (E)0, (E)0);
+    tape_push(i, S_FORM, (E)(np + 1), (E)0);
+    E g = 0;
     for (int j = 0; j < np; j++) g = gcd(g, rv[1 + j]);
     if (!(f.flags & PIPAMD_T_INT)) g = gcd(g, rv[0]);
     const int nc = f.ctx.nc;
     f.ctx.reserve(nc + 1, np + 2);
     for (int j = 0; j < np; j++) {
       f.ctx.at(nc, j) = cquo(rv[1 + j], g);
-      tape_push(i, S_VAL, f.ctx.at(nc, j), 1);
+      tape_push(i, S_VAL, f.ctx.at(nc, j), (E)1);
     }
     f.ctx.at(nc, np) = (f.flags & PIPAMD_T_INT) ? floordiv(rv[0], g) : cquo(rv[0], g);
-    tape_push(i, S_VAL, f.ctx.at(nc, np), 1);
+    tape_push(i, S_VAL, f.ctx.at(nc, np), (E)1);
     // the clone pass runs before the patch pass, so the copy still has the flags from before this
     // compa_test: give it the refreshed ones (expanser copies them, traiter.c:717), then Plus
     for (size_t k = 0; k < f.rows.size(); k++)
@@ -1748,14 +1766,14 @@ class Forest {
     Frame &f = q.stack.back();
     PipJob &pj = jobs_[f.job];
     if (pj.tflags & PIPAMD_T_DEEPEST) throw (int)PIPAMD_E_TOOLARGE;
-    const i64 *g = gathered(f.job);
+    const E *g = gathered(f.job);
     const int nvar = q.nvar, ni = f.ni;
     int nparm = f.nparm;
     const int ncol = nvar + nparm + 1, nligne = nvar + ni;
     if (ncol >= PIPAMD_MAXCOL) fail(i, PIPAMD_ST_MAXCOL);
-    const i64 D = g[1];
-    const i64 *r = g + 2;
-    std::vector<i64> cut(ncol + 1);
+    const E D = g[1];
+    const E *r = g + 2;
+    std::vector<E> cut(ncol + 1);
     bool ok_var = false, ok_parm = false;
     for (int j = 0; j < nvar; j++) {
       cut[j] = fmod_(r[j], D);
@@ -1772,24 +1790,24 @@ class Forest {
     }
     cut[ncol] = D;
     if (!ok_parm) throw (int)PIPAMD_E_TOOLARGE;  // only reached with options the Tree handles
-    Ctx::Quotient k{std::vector<i64>(cut.begin() + nvar + 1, cut.begin() + ncol), cut[nvar], D};
+    typename Ctx::Quotient k{std::vector<E>(cut.begin() + nvar + 1, cut.begin() + ncol), cut[nvar], D};
     int parm = f.ctx.find_quotient(nparm, k);
     if (parm == -1) {  // a new parameter on this problem's tape and context
-      Ctx::announce_quotient([&](int kind, i64 a, i64 b) { tape_push(i, kind, a, b); }, nparm, k);
+      Ctx::announce_quotient([&](int kind, E a, E b) { tape_push(i, kind, a, b); }, nparm, k);
       parm = f.ctx.define_quotient(nparm, k);
       nparm++;
     }
     if (!ok_var) fail(i, PIPAMD_ST_INTERNAL);  // assert(ok_var), integrer.c:499
     const int newcol = nvar + 1 + parm;
     if (ni >= pj.S || nligne >= pj.L || nvar + nparm + 1 > pj.W) throw (int)PIPAMD_E_TOOLARGE;
-    std::vector<i64> row(pj.W, 0);
+    std::vector<E> row(pj.W, 0);
     for (int j = 0; j < ncol; j++) row[j] = cut[j];
     row[newcol] = wadd(row[newcol], cut[ncol]);
-    patch64((size_t)pj.vals_off + (size_t)ni * pj.W, row.data(), row.size());
-    patch64((size_t)pj.rows_off + nligne, &D, 1);
+    patch_vals((size_t)pj.vals_off + (size_t)ni * pj.W * EW, row.data(), row.size());
+    patch_vals((size_t)pj.rows_off + (size_t)nligne * EW, &D, 1);
     patch_flag(pj, nligne, PIPAMD_F_MINUS);
     const int slot = ni;
-    patch32(((size_t)pj.rows_off + pj.L) * 2 + pj.L + nligne, &slot, 1);
+    patch32(((size_t)pj.rows_off + (size_t)pj.L * EW) * 2 + pj.L + nligne, &slot, 1);
     f.ni = ni + 1;
     f.nparm = nparm;
     pj.ni = f.ni;
@@ -1799,6 +1817,7 @@ class Forest {
     pj.status = PIPAMD_ST_RUN;
   }
 };
+typedef ForestT<i64> Forest;
 
 }  // namespace
 
@@ -1807,11 +1826,16 @@ class Forest {
 // Fills res[i] for the problems it finishes; the others keep rc == PIPAMD_E_TOOLARGE ("next path").
 namespace {
 // device buffer `slot` of the engine, at least `bytes` large (kept between calls; grown with headroom, given back
-// when a call needs less than a quarter of it and more than 256 MB would stay pinned for nothing)
+// once eight calls in a row have needed less than a quarter of it while more than 256 MB would stay pinned for nothing:
+// a large chunk followed by a small remainder, or large and small calls taking turns, keep their buffer -- every
+// hipFree waits for the whole device)
 template <class T>
 T *dt_buffer(pipamd_engine *e, int slot, size_t bytes) {
-  const bool oversized = e->dt_cap[slot] > 4 * bytes + ((size_t)256 << 20);
+  bool oversized = e->dt_cap[slot] > 4 * bytes + ((size_t)256 << 20);
+  e->dt_small[slot] = oversized ? e->dt_small[slot] + 1 : 0;
+  oversized = oversized && e->dt_small[slot] >= 8;
   if (bytes > e->dt_cap[slot] || oversized) {
+    e->dt_small[slot] = 0;
     if (e->dt_buf[slot]) hipFree(e->dt_buf[slot]);
     e->dt_buf[slot] = nullptr;
     e->dt_cap[slot] = 0;
@@ -2030,8 +2054,10 @@ static bool device_tree_one(pipamd_engine *e, const pipamd_problem &p, int simpl
   res[0].rc = PIPAMD_E_TOOLARGE;
   int served = 0, back = 0;
   device_tree(e, 1, &p, simplify, deepest_cut, res, &served, &back, qflags);
+  pthread_mutex_lock(&e->dt_lock);
   e->dt_served = served;  // (pipamd_last_device_tree also answers for the one-problem entries)
   e->dt_fallback = back;
+  pthread_mutex_unlock(&e->dt_lock);
   if (res[0].rc != PIPAMD_OK) return false;
   tape.swap(res[0].tape);
   *is_void = res[0].is_void;
@@ -2060,15 +2086,25 @@ static void device_tree_many(pipamd_engine *e, int n, const pipamd_problem *prob
 
 // Many problems: the device tree first (small problems), then the lock-step Forest; the few that need
 // a rare path are finished by the Tree.
-extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify,
-                                              int deepest_cut, pipamd_sol_cell **cells, size_t *n_cells, int *rcs,
-                                              int *statuses, int64_t *pivots) {
+// (the device tree is 64-bit: the 128-bit flavour starts with the Forest)
+static void lockstep_device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
+                                 std::vector<FResultT<i64>> &res) {
+  if (!e->no_device_tree && !getenv("PIPAMD_NO_DEVICE_TREE")) device_tree(e, n, probs, simplify, deepest_cut, res, &e->dt_served, &e->dt_fallback);
+}
+static void lockstep_device_tree(pipamd_engine *, int, const pipamd_problem *, int, int, std::vector<FResultT<i128>> &) {}
+
+template <class E, class CELL>
+static int lockstep_any(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut, CELL **cells,
+                        size_t *n_cells, int *rcs, int *statuses, int64_t *pivots) {
+  typedef FResultT<E> FResult;
+  typedef ForestT<E> Forest;
+  typedef TreeT<E> Tree;
   if (!e || n < 0 || (n && (!probs || !cells || !n_cells || !rcs))) return PIPAMD_E_INVALID;
   if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
   std::vector<FResult> res(n);
   for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;  // until a path has served it
   e->dt_served = e->dt_fallback = 0;
-  if (!e->no_device_tree && !getenv("PIPAMD_NO_DEVICE_TREE")) device_tree(e, n, probs, simplify, deepest_cut, res, &e->dt_served, &e->dt_fallback);
+  lockstep_device_tree(e, n, probs, simplify, deepest_cut, res);
   std::vector<int> rest;
   for (int i = 0; i < n; i++)
     if (res[i].rc == PIPAMD_E_TOOLARGE) rest.push_back(i);
@@ -2129,4 +2165,17 @@ extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pip
   }
   delete fallback;
   return rc_all;
+}
+
+extern "C" int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify,
+                                              int deepest_cut, pipamd_sol_cell **cells, size_t *n_cells, int *rcs,
+                                              int *statuses, int64_t *pivots) {
+  return lockstep_any<i64, pipamd_sol_cell>(e, n, probs, simplify, deepest_cut, cells, n_cells, rcs, statuses, pivots);
+}
+// The same on 128-bit entries (the overflow-safe flavour, include/piplib/piplib.h:42-88): ForestT<__int128> -- device tableaux,
+// contexts, cut rows and tape cells 128-bit --, the rare paths finished by a TreeT<__int128>.
+extern "C" int pipamd_solve_tableaux_lockstep128(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify,
+                                                 int deepest_cut, pipamd_sol_cell128 **cells, size_t *n_cells, int *rcs,
+                                                 int *statuses, int64_t *pivots) {
+  return lockstep_any<i128, pipamd_sol_cell128>(e, n, probs, simplify, deepest_cut, cells, n_cells, rcs, statuses, pivots);
 }

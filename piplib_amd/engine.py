@@ -491,6 +491,22 @@ def solve_tableaux128(engine, problems, simplify=True, deepest_cut=False, nthrea
     return out
 
 
+def solve_tableaux_lockstep128(engine, problems, simplify=True, deepest_cut=False):
+    """Many problems through pipamd_solve_tableaux_lockstep128 (128-bit entries, the lock-step scheduler).
+    Returns a list of (text | None, rc, status, pivots)."""
+    prep = PreparedProblems(problems)
+    L = lib()
+    L.pipamd_solve_tableaux_lockstep128.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(L.pipamd_solve_tableaux_lockstep128(engine._h, prep.n, prep.arr, int(bool(simplify)), int(bool(deepest_cut)),
+                                               prep.cells, prep.ncell, prep.rcs, prep.sts, prep.piv))
+    out = []
+    for i in range(prep.n):
+        t = tape_text(_take_cells128(prep.cells[i], prep.ncell[i])) if prep.rcs[i] == 0 else None
+        out.append((t, prep.rcs[i], prep.sts[i], prep.piv[i]))
+    return out
+
+
 def solve_prepared(engine, prep, simplify=True, deepest_cut=False, nthreads=8, lockstep=False):
     """the bare C call on prepared problems (what a C caller pays); prep.results() turns the cells into text"""
     L = lib()

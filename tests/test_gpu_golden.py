@@ -251,6 +251,36 @@ def test_many_problems_on_the_128bit_tree():
         assert rc == 0 and text == t1 and piv == p1
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [81, 82, 83, 84])
+def test_parametric_128bit_lockstep_vs_reference_gmp_build(seed):
+    """The same families through pipamd_solve_tableaux_lockstep128 -- ForestT<__int128>: one clone / patch / pivot-kernel /
+    gather sequence per step for all problems, device tableaux, contexts, parametric cuts and tape cells 128-bit --
+    against the reference's GMP build (quast text and number of pivoter calls), and problem by problem against the
+    one-problem entry."""
+    from gmpfix import gmp_fixture
+    from piplib_amd import engine as eng
+    probs, flags, recs, sha = gmp_fixture("param%d" % seed)
+    keep = [(p, r) for p, r in zip(probs, recs) if "status" in r and not r["wrap128"] and r["pivots"] <= 20000]
+    e = eng.Engine(0)
+    many = eng.solve_tableaux_lockstep128(e, [p for p, _ in keep])
+    assert len(many) == len(keep) >= 12
+    checked = 0
+    for i, ((p, r), (text, rc, st, piv)) in enumerate(zip(keep, many)):
+        if rc != 0:
+            # "Integer overflow" of the limb determinant (fixed-width flavours only) or a problem the reference aborts on:
+            # the one-problem entry must say the same
+            with pytest.raises(eng.SolverError) as ex:
+                eng.solve_tableau(e, p.nvar, p.nparm, p.ni, p.nc, p.bigparm, p.nq, p.ineq, p.ctx, bits=128)
+            assert rc == -5 and st == ex.value.status, (seed, i, rc, st)
+            continue
+        assert r["status"] != pb.ST_ABORT, (seed, i)
+        want = "void\n" if r["status"] == pb.ST_VOID else r["text"]
+        assert pb.squash(text) == pb.squash(want) and piv == r["pivots"], (seed, i, piv, r["pivots"])
+        checked += 1
+    assert checked >= 12
+
+
 REFPIP_GPU_GMP = os.path.join(os.path.dirname(pb.REFPIP_GPU), "refpip_gpu_gmp")
 
 

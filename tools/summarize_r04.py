@@ -1,4 +1,4 @@
-"""Turns the rocprofv3 output of tools/make_profiles_r03.sh (gpurun_out/p3_*) into profiles/r03_*."""
+"""Turns the rocprofv3 output of tools/make_profiles_r04.sh (gpurun_out/p4_*) into profiles/r04_*."""
 import collections, csv, glob, json, os, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
@@ -11,8 +11,8 @@ def one(pat):
     return f[-1]
 
 
-for src, dst in (("p3_np", "r03_kernel_stats.csv"), ("p3_p", "r03_kernel_stats_pipelined.csv"),
-                 ("p3_dense", "r03_dense_mode_kernel_stats.csv"), ("p3_cfg4", "r03_cfg4_kernel_stats.csv")):
+for src, dst in (("p4_np", "r04_kernel_stats.csv"), ("p4_p", "r04_kernel_stats_pipelined.csv"),
+                 ("p4_dense", "r04_dense_mode_kernel_stats.csv"), ("p4_cfg4", "r04_cfg4_kernel_stats.csv")):
     shutil.copy(one(src + "/*/*kernel_stats.csv"), os.path.join(P, dst))
 
 
@@ -35,8 +35,8 @@ def per_step(path, name, kernel=PIVOT_KERNELS, pick=None):
 
 
 def hbm(tag):
-    f = per_step(one(f"p3_{tag}fetch/*/*counter_collection.csv"), "FETCH_SIZE")
-    w = per_step(one(f"p3_{tag}write/*/*counter_collection.csv"), "WRITE_SIZE")
+    f = per_step(one(f"p4_{tag}fetch/*/*counter_collection.csv"), "FETCH_SIZE")
+    w = per_step(one(f"p4_{tag}write/*/*counter_collection.csv"), "WRITE_SIZE")
     return f, w
 
 
@@ -51,15 +51,15 @@ f, w = hbm("")
 rd, wr = 2 * 1024 * sum(s[0] for s in f) / len(f), 1024 * sum(s[0] for s in w) / len(w)
 out.update({"hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr, "hbm_bytes_per_step": rd + wr, "steps_seen": [len(f), len(w)]})
 # the lean launch alone (the dominant kernel of bench.py's `roofline`)
-fl = per_step(one("p3_fetch/*/*counter_collection.csv"), "FETCH_SIZE", kernel=("pip_lean_kernel",))
-wl = per_step(one("p3_write/*/*counter_collection.csv"), "WRITE_SIZE", kernel=("pip_lean_kernel",))
+fl = per_step(one("p4_fetch/*/*counter_collection.csv"), "FETCH_SIZE", kernel=("pip_lean_kernel",))
+wl = per_step(one("p4_write/*/*counter_collection.csv"), "WRITE_SIZE", kernel=("pip_lean_kernel",))
 if fl and wl:
     rdl, wrl = 2 * 1024 * sum(s[0] for s in fl) / len(fl), 1024 * sum(s[0] for s in wl) / len(wl)
     out["lean_launch"] = {"hbm_read_bytes": rdl, "hbm_write_bytes": wrl, "hbm_bytes": rdl + wrl,
                           "kernel_ms_under_the_counter_pass": sum(s[1] for s in fl) / len(fl)}
 # dense mode: the NOSKIP launches are the long four-wave ones (>= 8 ms)
-fd = per_step(one("p3_dense_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
-wd = per_step(one("p3_dense_write/*/*counter_collection.csv"), "WRITE_SIZE")
+fd = per_step(one("p4_dense_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
+wd = per_step(one("p4_dense_write/*/*counter_collection.csv"), "WRITE_SIZE")
 big = lambda steps: [s for s in steps if s[1] > 8.0]
 if big(fd) and big(wd):
     rdd, wrd = 2 * 1024 * sum(s[0] for s in big(fd)) / len(big(fd)), 1024 * sum(s[0] for s in big(wd)) / len(big(wd))
@@ -74,15 +74,15 @@ try:
                    "kernel_ms_per_step": sum(s[1] for s in fc) / len(fc)}
 except AssertionError:
     pass
-json.dump(out, open(os.path.join(P, "r03_pmc_hbm.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, "r04_pmc_hbm.json"), "w"), indent=1)
 
 # instruction mix of one un-pipelined headline step
 mix = collections.defaultdict(lambda: collections.defaultdict(float))
-for r in csv.DictReader(open(one("p3_mix/*/*counter_collection.csv"))):
+for r in csv.DictReader(open(one("p4_mix/*/*counter_collection.csv"))):
     mix[r["Kernel_Name"].split("(")[0]][r["Counter_Name"][9:]] += float(r["Counter_Value"])
 piv = 772044.0
-piv_lean = 741317.0  # of them in the lean launch (tools/lean_split.py)
-lines = ["# tools/make_profiles_r03.sh step 4: rocprofv3 --pmc SQ_INSTS_* -- python3 tools/pmc_one.py",
+piv_lean = 772044.0  # of them in the two lean launches (the second resumes what the first paused): all of them on this batch
+lines = ["# tools/make_profiles_r04.sh step 4: rocprofv3 --pmc SQ_INSTS_* -- python3 tools/pmc_one.py",
          "# one un-pipelined step of the headline batch (10,000 tableaux, 772,044 pivots): wave-instructions per kernel"]
 tot, tot_lean = collections.defaultdict(float), collections.defaultdict(float)
 for k, c in mix.items():
@@ -93,9 +93,9 @@ for k, c in mix.items():
             tot[n] += v
             if "pip_lean_kernel" in k:
                 tot_lean[n] += v
-lines.append("pip_lean_kernel per pivot of its own (741,317): " + ", ".join(f"{n} {v / piv_lean:.1f}" for n, v in sorted(tot_lean.items())))
+lines.append("pip_lean_kernel (both launches) per pivot of its own (772,044): " + ", ".join(f"{n} {v / piv_lean:.1f}" for n, v in sorted(tot_lean.items())))
 lines.append("all pivot launches per pivot (772,044): " + ", ".join(f"{n} {v / piv:.1f}" for n, v in sorted(tot.items())))
-open(os.path.join(P, "r03_pmc_inst_mix.txt"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(P, "r04_pmc_inst_mix.txt"), "w").write("\n".join(lines) + "\n")
 
 # issue utilisation of the launches (counter passes serialise the kernels: these are lone launches whatever --pipeline)
 issue = {"lean_kernel_wave_instructions_per_pivot": {n: round(v / piv_lean, 1) for n, v in sorted(tot_lean.items())},
@@ -104,14 +104,14 @@ issue = {"lean_kernel_wave_instructions_per_pivot": {n: round(v / piv_lean, 1) f
          "wave_instructions_per_pivot_total": round(sum(tot[n] for n in ("VALU", "SALU", "BRANCH", "LDS", "VMEM_RD", "VMEM_WR", "SMEM")) / piv, 1)}
 for mode in (1, 12):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    for pat in (f"p3_sq_{mode}/*/*counter_collection.csv", f"p3_sq2_{mode}/*/*counter_collection.csv"):
+    for pat in (f"p4_sq_{mode}/*/*counter_collection.csv", f"p4_sq2_{mode}/*/*counter_collection.csv"):
         seen = set()
         for r in csv.DictReader(open(one(pat))):
             if not any(pk in r["Kernel_Name"] for pk in PIVOT_KERNELS):
                 continue
             k = "lean" if "pip_lean_kernel" in r["Kernel_Name"] else ("bulk" if "1, 1, false" in r["Kernel_Name"] else "tail")
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            if (pat, r["Dispatch_Id"]) not in seen and pat.startswith(f"p3_sq_{mode}"):
+            if (pat, r["Dispatch_Id"]) not in seen and pat.startswith(f"p4_sq_{mode}"):
                 seen.add((pat, r["Dispatch_Id"]))
                 agg[k]["_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
                 agg[k]["_launches"] += 1
@@ -129,7 +129,7 @@ for mode in (1, 12):
             "icache_miss_rate": round(c["SQC_ICACHE_MISSES"] / max(1.0, c["SQC_ICACHE_REQ"]), 6)}
 issue["note"] = ("SQ_* cycle counters are quad-cycles (MI355X_MICROARCH.md); utilisation assumes 2.4 GHz.  A counter pass serialises the "
                  "kernels, so pipeline12 shows the same lone launches as pipeline1 (12 batches, each launch on its own).  lean = pip_lean_kernel, bulk = the general one-wave launch over what it left, tail = the four-wave launches.")
-json.dump(issue, open(os.path.join(P, "r03_pmc_issue.json"), "w"), indent=1)
+json.dump(issue, open(os.path.join(P, "r04_pmc_issue.json"), "w"), indent=1)
 
 print(json.dumps({k: v for k, v in out.items() if "bytes" in k or k in ("dense_mode", "cfg4")}, indent=1))
 print(json.dumps(issue, indent=1)[:1500])
