@@ -35,11 +35,12 @@ enum {
 };
 
 extern "C" {
-size_t pipk_quast_lds_bytes(const QCaps *c);
-size_t pipk_quast_frame_words(const QCaps *c);
-hipError_t pipk_launch_quast(const QProb *probs, const long long *input, long long *stack, long long *cells, int *out,
-                             int nprob, const QCaps *cap, hipStream_t stream);
+// ebits: the entry width of the launch, 64 (the reference's long long build) or 128 (the overflow-safe flavour)
+size_t pipk_quast_lds_bytes(const QCaps *c, int ebits);
+size_t pipk_quast_frame_words(const QCaps *c, int ebits);  // entries of one stack frame
+hipError_t pipk_launch_quast(const QProb *probs, const long long *input, void *stack, void *cells, int *out, int nprob,
+                             const QCaps *cap, int ebits, hipStream_t stream);
 hipError_t pipk_launch_quast_pack(const long long *cells, const long long *off, long long *packed, int nprob,
-                                  int cells_cap, hipStream_t stream);
+                                  int cells_cap, int ebits, hipStream_t stream);
 }
 #endif

@@ -23,8 +23,101 @@
 #include "pip_quast.h"
 
 namespace {
-typedef long long i64;
-typedef unsigned long long u64;
+typedef long long w64;            // a raw 64-bit word / an input coefficient (inputs are long longs in either flavour)
+typedef unsigned long long u64;   // ballot masks, bit sets
+typedef __int128 w128;
+typedef unsigned __int128 u128;
+
+// ---- what the kernel needs from its entry type QI (long long: the reference's int64 build; __int128: the overflow-safe
+// flavour, piplib.h:42-88), by overloading.  Everything the compiler would turn into a library call for 128 bits
+// (multiplication overflow, division, conversion to double) is spelled out.
+template <class QI> struct QT;
+template <> struct QT<w64> { typedef u64 U; };
+template <> struct QT<w128> { typedef u128 U; };
+__device__ __forceinline__ w64 qshfl(w64 x, int src) { return __shfl(x, src); }
+__device__ __forceinline__ w128 qshfl(w128 x, int src) {
+  const u64 lo = (u64)__shfl((w64)(u64)(u128)x, src), hi = (u64)__shfl((w64)(u64)((u128)x >> 64), src);
+  return (w128)(((u128)hi << 64) | lo);
+}
+__device__ __forceinline__ w64 qrdlane(w64 x, int l) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)(u64)x, l), hi = __builtin_amdgcn_readlane((unsigned)((u64)x >> 32), l);
+  return (w64)(((u64)hi << 32) | lo);
+}
+__device__ __forceinline__ w128 qrdlane(w128 x, int l) {
+  const u64 lo = (u64)qrdlane((w64)(u64)(u128)x, l), hi = (u64)qrdlane((w64)(u64)((u128)x >> 64), l);
+  return (w128)(((u128)hi << 64) | lo);
+}
+__device__ __forceinline__ int qbits(u64 u) { return u ? 64 - __clzll((long long)u) : 0; }
+__device__ __forceinline__ int qbits(u128 u) { return (u64)(u >> 64) ? 128 - __clzll((long long)(u64)(u >> 64)) : qbits((u64)u); }
+__device__ __forceinline__ int qctz(u64 u) { return __builtin_ctzll(u | (1ull << 63)); }
+__device__ __forceinline__ int qctz(u128 u) { return (u64)u ? __builtin_ctzll((u64)u) : 64 + __builtin_ctzll((u64)(u >> 64) | (1ull << 63)); }
+__device__ __forceinline__ bool qaddo(w64 a, w64 b, w64 *r) { return __builtin_add_overflow(a, b, r); }
+__device__ __forceinline__ bool qsubo(w64 a, w64 b, w64 *r) { return __builtin_sub_overflow(a, b, r); }
+__device__ __forceinline__ bool qmulo(w64 a, w64 b, w64 *r) { return __builtin_mul_overflow(a, b, r); }
+__device__ __forceinline__ bool qaddo(w128 a, w128 b, w128 *r) { return __builtin_add_overflow(a, b, r); }
+__device__ __forceinline__ bool qsubo(w128 a, w128 b, w128 *r) { return __builtin_sub_overflow(a, b, r); }
+// 128 x 128: exact when both fit long longs; else by the bit lengths -- a sum of at most 126 cannot overflow, 128 and more
+// must, and 127 (either) is reported as overflow: the problem is handed back, never answered wrongly
+__device__ __forceinline__ bool qmulo(w128 a, w128 b, w128 *r) {
+  *r = (w128)((u128)a * (u128)b);
+  if ((w128)(w64)a == a && (w128)(w64)b == b) return false;
+  if (a == 0 || b == 0) return false;
+  const u128 ua = a < 0 ? (u128)0 - (u128)a : (u128)a, ub = b < 0 ? (u128)0 - (u128)b : (u128)b;
+  return qbits(ua) + qbits(ub) > 126;
+}
+// 64-bit division is a ~150-instruction sequence: one copy each, out of line (operands rarely need it)
+__device__ __noinline__ u64 umod_wide(u64 a, u64 b) { return a % b; }
+__device__ __noinline__ u64 udiv_wide(u64 a, u64 b) { return a / b; }
+__device__ __forceinline__ u64 qumod(u64 a, u64 b) { return ((a | b) >> 32) ? umod_wide(a, b) : (u64)((unsigned)a % (unsigned)b); }
+__device__ __forceinline__ u64 qudiv(u64 a, u64 b) { return ((a | b) >> 32) ? udiv_wide(a, b) : (u64)((unsigned)a / (unsigned)b); }
+// 128 / 128 -> quotient and remainder, shift and subtract over the difference of the bit lengths (operands that fit 64
+// bits take the 64-bit routines)
+__device__ __noinline__ u128 udivmod_wide(u128 a, u128 b, u128 *rem) {
+  u128 q = 0;
+  if (b != 0 && a >= b) {
+    int sh = qbits(a) - qbits(b);
+    u128 d = b << sh;
+    for (; sh >= 0; sh--) {
+      q <<= 1;
+      if (a >= d) {
+        a -= d;
+        q |= 1;
+      }
+      d >>= 1;
+    }
+  }
+  *rem = a;
+  return q;
+}
+__device__ __forceinline__ u128 qumod(u128 a, u128 b) {
+  if (((a | b) >> 64) == 0) return (u128)qumod((u64)a, (u64)b);
+  u128 r;
+  udivmod_wide(a, b, &r);
+  return r;
+}
+__device__ __forceinline__ u128 qudiv(u128 a, u128 b) {
+  if (((a | b) >> 64) == 0) return (u128)qudiv((u64)a, (u64)b);
+  u128 r;
+  return udivmod_wide(a, b, &r);
+}
+__device__ __forceinline__ double qdouble(w64 x) { return (double)x; }
+__device__ __forceinline__ double qdouble(w128 x) {
+  const u128 m = x < 0 ? (u128)0 - (u128)x : (u128)x;  // via the magnitude: hi*2^64 + lo on a negative value would cancel
+  const double d = (double)(u64)(m >> 64) * 18446744073709551616.0 + (double)(u64)m;
+  return x < 0 ? -d : d;
+}
+// inverse of an odd number modulo 2^64 / 2^128 (Newton: 3 correct bits, doubled by every step)
+__device__ __forceinline__ u64 qinv(u64 od) {
+  u64 inv = od;
+#pragma unroll
+  for (int q = 0; q < 5; q++) inv *= 2 - od * inv;
+  return inv;
+}
+__device__ __forceinline__ u128 qinv(u128 od) {
+  u128 inv = (u128)qinv((u64)od);
+  inv *= 2 - od * inv;
+  return inv;
+}
 
 enum { F_UNIT = 1, F_PLUS = 2, F_MINUS = 4, F_ZERO = 8, F_CRITIC = 16, F_UNKNOWN = 32 };
 enum { C_NIL = 1, C_IF = 2, C_LIST = 3, C_FORM = 4, C_NEW = 5, C_DIV = 6, C_VAL = 7 };
@@ -34,8 +127,15 @@ enum { MAXDET = 4 };  // tab.h:67
 // below get ds_read / ds_write instead of flat accesses (a generic pointer argument costs several times
 // the latency).
 #define LDS __attribute__((address_space(3)))
-typedef LDS i64 li64;
 typedef LDS int lint;
+
+// The kernel's functions as static members of a class template over the entry type: inside it `i64` IS the entry type
+// (and `uE` its unsigned twin), so the code below reads as it did when there was one flavour.
+template <class QI>
+struct QK {
+typedef QI i64;
+typedef typename QT<QI>::U uE;
+typedef LDS i64 li64;
 
 // one tableau in LDS: logical rows (unit row on column `ref`, or real row in slot `ref`)
 struct Tab {
@@ -65,86 +165,79 @@ struct QState {
 };
 
 #define BAD(w) (__any((w).bad) != 0)
-__device__ __forceinline__ void wsync() { __syncthreads(); }  // one wave per workgroup: orders its LDS traffic
-__device__ __forceinline__ i64 bcast(i64 x, int src) { return __shfl(x, src); }
-__device__ __forceinline__ int popc64(u64 m) { return __popcll(m); }
-__device__ __forceinline__ int first64(u64 m) { return __ffsll((long long)m) - 1; }
+static __device__ __forceinline__ void wsync() { __syncthreads(); }  // one wave per workgroup: orders its LDS traffic
+static __device__ __forceinline__ i64 bcast(i64 x, int src) { return qshfl(x, src); }
+static __device__ __forceinline__ int popc64(u64 m) { return __popcll(m); }
+static __device__ __forceinline__ int first64(u64 m) { return __ffsll((long long)m) - 1; }
 
-__device__ __forceinline__ i64 cmul(i64 a, i64 b, int &bad) {
+static __device__ __forceinline__ i64 cmul(i64 a, i64 b, int &bad) {
   i64 r;
-  bad |= __builtin_mul_overflow(a, b, &r);
+  bad |= qmulo(a, b, &r);
   return r;
 }
-__device__ __forceinline__ i64 cadd(i64 a, i64 b, int &bad) {
+static __device__ __forceinline__ i64 cadd(i64 a, i64 b, int &bad) {
   i64 r;
-  bad |= __builtin_add_overflow(a, b, &r);
+  bad |= qaddo(a, b, &r);
   return r;
 }
-__device__ __forceinline__ i64 csub(i64 a, i64 b, int &bad) {
+static __device__ __forceinline__ i64 csub(i64 a, i64 b, int &bad) {
   i64 r;
-  bad |= __builtin_sub_overflow(a, b, &r);
+  bad |= qsubo(a, b, &r);
   return r;
 }
-__device__ __forceinline__ i64 cneg(i64 a, int &bad) { return csub(0, a, bad); }
-__device__ __forceinline__ bool fits32(i64 a) { return a == (i64)(int)a; }
-__device__ __forceinline__ i64 mul32(i64 a, i64 b) { return (i64)(int)a * (i64)(int)b; }
-__device__ __forceinline__ u64 uabs(i64 a) { return a < 0 ? 0ull - (u64)a : (u64)a; }
-// 64-bit division is a ~150-instruction sequence: one copy each, out of line (operands rarely need it)
-__device__ __noinline__ u64 umod_wide(u64 a, u64 b) { return a % b; }
-__device__ __noinline__ u64 udiv_wide(u64 a, u64 b) { return a / b; }
-__device__ __forceinline__ u64 umod(u64 a, u64 b) {
-  return ((a | b) >> 32) ? umod_wide(a, b) : (u64)((unsigned)a % (unsigned)b);
-}
-__device__ __forceinline__ u64 udiv(u64 a, u64 b) {
-  return ((a | b) >> 32) ? udiv_wide(a, b) : (u64)((unsigned)a / (unsigned)b);
-}
+static __device__ __forceinline__ i64 cneg(i64 a, int &bad) { return csub(0, a, bad); }
+static __device__ __forceinline__ bool fits32(i64 a) { return a == (i64)(int)a; }
+static __device__ __forceinline__ i64 mul32(i64 a, i64 b) { return (i64)((w64)(int)a * (w64)(int)b); }
+static __device__ __forceinline__ uE uabs(i64 a) { return a < 0 ? (uE)0 - (uE)a : (uE)a; }
+static __device__ __forceinline__ uE umod(uE a, uE b) { return qumod(a, b); }
+static __device__ __forceinline__ uE udiv(uE a, uE b) { return qudiv(a, b); }
 // integrer.c:43-50 on true integers: gcd(|a|, |b|)
-__device__ __noinline__ u64 gcd_loop(u64 x, u64 y) {
+static __device__ __noinline__ uE gcd_loop(uE x, uE y) {
   while (y) {
-    const u64 t = umod(x, y);
+    const uE t = umod(x, y);
     x = y;
     y = t;
   }
   return x;
 }
-__device__ __forceinline__ i64 gcd64(i64 a, i64 b) {
-  const u64 x = uabs(a), y = uabs(b);
+static __device__ __forceinline__ i64 gcd64(i64 a, i64 b) {
+  const uE x = uabs(a), y = uabs(b);
   if (x == 1 || y == 1) return 1;
   if (y == 0) return (i64)x;
   return (i64)gcd_loop(x, y);
 }
 // C '/' and '%' (truncating) for a non-zero divisor
-__device__ __forceinline__ i64 quo(i64 a, i64 b) {
-  const u64 q = udiv(uabs(a), uabs(b));
+static __device__ __forceinline__ i64 quo(i64 a, i64 b) {
+  const uE q = udiv(uabs(a), uabs(b));
   return ((a < 0) != (b < 0)) ? -(i64)q : (i64)q;
 }
-__device__ __forceinline__ i64 rem(i64 a, i64 b) {
-  const u64 r = umod(uabs(a), uabs(b));
+static __device__ __forceinline__ i64 rem(i64 a, i64 b) {
+  const uE r = umod(uabs(a), uabs(b));
   return a < 0 ? -(i64)r : (i64)r;
 }
 // integrer.c:69-74: remainder in [0, |b|)
-__device__ __forceinline__ i64 pmod(i64 a, i64 b) {
+static __device__ __forceinline__ i64 pmod(i64 a, i64 b) {
   i64 m = rem(a, b);
   if (m < 0) m += (i64)uabs(b);
   return m;
 }
 // piplib.h:147-149
-__device__ __forceinline__ i64 floordiv(i64 a, i64 b, int &bad) { return quo(csub(a, pmod(a, b), bad), b); }
+static __device__ __forceinline__ i64 floordiv(i64 a, i64 b, int &bad) { return quo(csub(a, pmod(a, b), bad), b); }
 // integrer.c:51-59: bit length of |x|, 1 for 0
-__device__ __forceinline__ int blen(i64 x) {
-  const u64 u = uabs(x);
-  return u ? 64 - __clzll((long long)u) : 1;
+static __device__ __forceinline__ int blen(i64 x) {
+  const uE u = uabs(x);
+  return u ? qbits(u) : 1;
 }
-__device__ __forceinline__ int sgn_flag(i64 x) { return x < 0 ? F_MINUS : (x > 0 ? F_PLUS : F_ZERO); }
+static __device__ __forceinline__ int sgn_flag(i64 x) { return x < 0 ? F_MINUS : (x > 0 ? F_PLUS : F_ZERO); }
 
-__device__ __forceinline__ int wave_max_i(int x) {
+static __device__ __forceinline__ int wave_max_i(int x) {
   for (int o = 32; o; o >>= 1) {
     const int y = __shfl_xor(x, o);
     x = x > y ? x : y;
   }
   return x;
 }
-__device__ __forceinline__ float wave_min_f(float x) {
+static __device__ __forceinline__ float wave_min_f(float x) {
   for (int o = 32; o; o >>= 1) {
     const float y = __shfl_xor(x, o);
     x = x < y ? x : y;
@@ -153,14 +246,14 @@ __device__ __forceinline__ float wave_min_f(float x) {
 }
 
 // value of logical row k in column `lane` (traiter.c:246-252 valeur); 0 beyond ncol
-__device__ __forceinline__ i64 row_at(const Tab &t, int k, int lane, int ncol) {
+static __device__ __forceinline__ i64 row_at(const Tab &t, int k, int lane, int ncol) {
   const int fl = t.flag[k], rf = t.ref[k];
   if (fl & F_UNIT) return rf == lane ? t.den[k] : 0;
   return lane < ncol ? t.val[rf * t.W + lane] : 0;
 }
 
 // traiter.c:39-44 chercher: first row among 0..n-1 whose flag meets `mask`, n if none
-__device__ __forceinline__ int first_flagged(const Tab &t, int mask, int n, int lane) {
+static __device__ __forceinline__ int first_flagged(const Tab &t, int mask, int n, int lane) {
   for (int base = 0; base < n; base += 64) {
     const int k = base + lane;
     const u64 m = __ballot(k < n && (t.flag[k] & mask));
@@ -170,7 +263,7 @@ __device__ __forceinline__ int first_flagged(const Tab &t, int mask, int n, int 
 }
 
 // traiter.c:101-159 exam_coef: obvious signs of Unknown rows; stops at the first row proven negative
-__device__ __noinline__ int classify_rows(Tab t, int nvar, int ncol, int bigparm, int nligne, int lane) {
+static __device__ __noinline__ int classify_rows(Tab t, int nvar, int ncol, int bigparm, int nligne, int lane) {
   if (bigparm >= 0) {
     for (int base = 0; base < nligne; base += 64) {
       const int k = base + lane;
@@ -231,14 +324,14 @@ __device__ __noinline__ int classify_rows(Tab t, int nvar, int ncol, int bigparm
 
 // traiter.c:556-623 tab_sort_rows: selection sort of the real rows nvar..nligne-1 by
 // max |trunc(coefficient / denominator)| over the unknowns (float keys, the reference's types)
-__device__ __forceinline__ int trunc_x86(double t) {
+static __device__ __forceinline__ int trunc_x86(double t) {
   return (!(t > -2147483649.0 && t < 2147483648.0)) ? (int)0x80000000 : (int)t;
 }
-__device__ __forceinline__ int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+static __device__ __forceinline__ int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
 // pos != null (Compute_dual): pos[i] = the logical row inequality i (row nvar + i before the sort) ends up in; unit
 // rows among nvar.. count as inequality 0, later rows overwriting earlier ones -- the reference never sets their
 // `ineq` (traiter.c:577-578 vs 617-618), zero-filled as the oracle and the reference's own fixtures have it.
-__device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane, LDS unsigned short *pos) {
+static __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane, LDS unsigned short *pos) {
   const int n = nligne - nvar;  // rows to sort: at most 64 + the unit rows among them
   if (n > 64) return Q_WHY_ROWS | 256;
   // lane l holds logical row nvar + l (flag, slot, denominator, key); the selection sort swaps lanes
@@ -262,9 +355,9 @@ __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane, LDS
         s = s > a ? s : a;
       }
     } else {
-      const double d = (double)dn;
+      const double d = qdouble(dn);
       for (int j = 0; j < nvar; j++) {
-        const int q = trunc_x86((double)r[j] / d);
+        const int q = trunc_x86(qdouble(r[j]) / d);
         const int a = q < 0 ? (int)(0u - (unsigned)q) : q;  // abs() incl. INT_MIN
         s = s > a ? s : a;  // (double)INT_MIN never wins against s >= 0
       }
@@ -296,22 +389,21 @@ __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane, LDS
     }
     if (p == i) continue;
     {  // rows i and p trade places (traiter.c:604-612)
-      const int dl = (int)(u64)dn, dh = (int)((u64)dn >> 32);
       const int f_i = rdlane(fl, i), f_p = rdlane(fl, p), r_i = rdlane(rf, i), r_p = rdlane(rf, p);
       const int k_i = rdlane(kb, i), k_p = rdlane(kb, p), o_i = rdlane(oi, i), o_p = rdlane(oi, p);
-      const int dl_i = rdlane(dl, i), dl_p = rdlane(dl, p), dh_i = rdlane(dh, i), dh_p = rdlane(dh, p);
+      const i64 dn_i = qrdlane(dn, i), dn_p = qrdlane(dn, p);
       if (lane == i) {
         fl = f_p;
         rf = r_p;
         kb = k_p;
         oi = o_p;
-        dn = (i64)(((u64)(unsigned)dh_p << 32) | (unsigned)dl_p);
+        dn = dn_p;
       } else if (lane == p) {
         fl = f_i;
         rf = r_i;
         kb = k_i;
         oi = o_i;
-        dn = (i64)(((u64)(unsigned)dh_i << 32) | (unsigned)dl_i);
+        dn = dn_i;
       }
       const u64 bi = (below >> i) & 1;
       below = (below & ~(1ull << p) & ~(1ull << i)) | (1ull << i) | (bi << p);
@@ -339,7 +431,7 @@ __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane, LDS
 
 // traiter.c:345-548 pivoter (with choisir_piv, traiter.c:297-341, as a tournament over the rows);
 // returns -1 when the pivot row has no positive entry among the unknowns
-__device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int ncol, int nligne, int lane) {
+static __device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int ncol, int nligne, int lane) {
   const int W = t.W;
   int bad = 0;
   const int pslot = t.ref[pivi];
@@ -472,11 +564,11 @@ __device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int ncol, int 
       }
       // gcd of g and the whole row (integrer.c:43-50 folds it the same way, entry by entry), four entries
       // at a time: usually g divides them all, or the gcd drops to 1 at once
-      u64 G = uabs(g);
+      uE G = uabs(g);
       for (int j = 0; j < ncol; j += 4) {
         if (!__ballot(act && G != 1)) break;
         if (act && G != 1) {
-          u64 m[4];
+          uE m[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const i64 z = j + q < ncol ? r[j + q] : 0;
@@ -485,22 +577,20 @@ __device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int ncol, int 
           if (m[0] | m[1] | m[2] | m[3]) {
 #pragma unroll
             for (int q = 0; q < 4; q++)
-              if (m[q] && G != 1) G = (u64)gcd64((i64)G, (i64)umod(m[q], G));
+              if (m[q] && G != 1) G = (uE)gcd64((i64)G, (i64)umod(m[q], G));
           }
         }
       }
       if (__ballot(act && G != 1)) {
         // exact division by G = 2^tz * odd: shift, then multiply by the inverse of the odd part modulo 2^64
-        const int tz = __builtin_ctzll(G | (1ull << 63));
-        const u64 od = G >> tz;
-        u64 inv = od;  // 3 correct bits; each step doubles them
-#pragma unroll
-        for (int q = 0; q < 5; q++) inv *= 2 - od * inv;
+        const int tz = qctz(G);
+        const uE od = G >> tz;
+        const uE inv = qinv(od);
         const bool dv = act && G != 1;
 #pragma unroll 4
         for (int j = 0; j < ncol; j++)
-          if (dv) r[j] = (i64)((u64)(r[j] >> tz) * inv);
-        if (dv) g = (i64)((u64)(g >> tz) * inv);
+          if (dv) r[j] = (i64)((uE)(r[j] >> tz) * inv);
+        if (dv) g = (i64)((uE)(g >> tz) * inv);
       }
       if (act) t.den[k] = g;
     }
@@ -523,7 +613,7 @@ __device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int ncol, int 
 }
 
 // integrer.c:98-150 bezout
-__device__ __forceinline__ i64 bezout(i64 x, i64 y, i64 delta, int &bad) {
+static __device__ __forceinline__ i64 bezout(i64 x, i64 y, i64 delta, int &bad) {
   i64 a = 1, b = 0, c = 0, d = 1, u = y, v = delta;
   for (int guard = 0; guard < 200; guard++) {
     const i64 q = floordiv(u, v, bad), r = pmod(u, v);
@@ -545,7 +635,7 @@ struct Cut {
   i64 c;
   bool ok_var, ok_const, ok_parm;
 };
-__device__ __forceinline__ Cut make_cut(const Tab &t, int i, int nvar, int ncol, int bigparm, int lane) {
+static __device__ __forceinline__ Cut make_cut(const Tab &t, int i, int nvar, int ncol, int bigparm, int lane) {
   Cut q;
   const i64 D = t.den[i];
   const i64 v = lane < ncol ? t.val[t.ref[i] * t.W + lane] : 0;
@@ -562,7 +652,7 @@ __device__ __forceinline__ Cut make_cut(const Tab &t, int i, int nvar, int ncol,
 }
 
 // deepest cut, integrer.c:417-438 (constant cuts only)
-__device__ __forceinline__ i64 deepen(i64 c, i64 D, int nvar, int lane, int &bad) {
+static __device__ __forceinline__ i64 deepen(i64 c, i64 D, int nvar, int lane, int &bad) {
   const i64 cst = bcast(c, nvar);
   i64 tt = -cst;
   const i64 delta = gcd64(tt, D), tau = quo(tt, delta), dd = quo(D, delta);
@@ -580,7 +670,7 @@ __device__ __forceinline__ i64 deepen(i64 c, i64 D, int nvar, int lane, int &bad
 }
 
 // append a cut as logical row nligne in slot ni (flag Minus, denominator D); false: no room
-__device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i64 c, i64 D, int lane) {
+static __device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i64 c, i64 D, int lane) {
   if (nligne >= t.rows_cap || ni >= t.slots_cap) return false;
   if (lane < t.W) t.val[ni * t.W + lane] = c;
   if (lane == 0) {
@@ -596,7 +686,7 @@ __device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i64 c, i6
 // context test): true when the first cell of its tape would not be Nil
 // Result word: bit 0 = a solution exists, bits 1..15 = reason bits (per lane), bits 16.. = pivots.
 // `budget`: pivots the problem may still spend (Q_PIVOT_BUDGET less what it has used): beyond it the problem is handed back.
-__device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int deepest, int budget) {
+static __device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int deepest, int budget) {
   const int ncol = nvar + 1;
   int bad = sort_rows(t, nvar, nvar + ni, lane, nullptr), pivots = 0, found = 0;
   for (int guard = 0; guard < 30000 && !__any(bad); guard++) {  // (the pivot count has 15 bits of the result word)
@@ -642,7 +732,7 @@ __device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int d
 
 // the tableau "context (+ one more row)" of compa_test / the context test (traiter.c:196-233,
 // maind.c:196-203): nparm unit rows, the nc context rows, `extra` as the last row
-__device__ __forceinline__ int build_sub(Tab &s, const li64 *ctx, int CW, int nparm, int nc, bool has_extra, i64 extra,
+static __device__ __forceinline__ int build_sub(Tab &s, const li64 *ctx, int CW, int nparm, int nc, bool has_extra, i64 extra,
                                          int lane) {
   const int ni = nc + (has_extra ? 1 : 0);
   if (nparm + ni > s.rows_cap || ni > s.slots_cap) return -1;
@@ -673,7 +763,7 @@ struct Tape {
   i64 *cell;  // global: 3 words per cell (kind, param1, param2)
   int n, cap;
 };
-__device__ __forceinline__ void tape_put(Tape &tp, int at, int kind, i64 a, i64 b) {
+static __device__ __forceinline__ void tape_put(Tape &tp, int at, int kind, i64 a, i64 b) {
   if (at < tp.cap) {
     tp.cell[3 * (size_t)at] = kind;
     tp.cell[3 * (size_t)at + 1] = a;
@@ -685,7 +775,7 @@ __device__ __forceinline__ void tape_put(Tape &tp, int at, int kind, i64 a, i64 
 // Parameter p is floor(-(c . (1, params)) / D) when the context holds the two rows that defined it
 // (integrer.c:156-227): +(c_params | D at p | c0 + D - 1) and -(c_params | D at p | c0), nothing right of p.
 // cutv = c0 | c_params | D in LDS; a lane per context row; the highest such p, -1 if none.
-__device__ __forceinline__ int find_quotient(const li64 *ctx, int CW, int nc, int nparm, const li64 *cutv, int lane,
+static __device__ __forceinline__ int find_quotient(const li64 *ctx, int CW, int nc, int nparm, const li64 *cutv, int lane,
                                              int &bad) {
   if (cutv[nparm] != 0) return -1;  // the last parameter takes part in the cut: it cannot be the quotient's
   const i64 c0 = cutv[0], D = cutv[1 + nparm];
@@ -716,9 +806,10 @@ __device__ __forceinline__ int find_quotient(const li64 *ctx, int CW, int nc, in
   return -1;
 }
 
-__global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const i64 *input, i64 *stack, i64 *cells,
-                                                        int *out, int nprob, QCaps cap) {
+static __device__ __forceinline__ void run(const QProb *probs, const w64 *input, i64 *stack, i64 *cells, int *out, int nprob,
+                                    const QCaps &cap) {
   extern __shared__ __align__(16) unsigned char smem[];
+  constexpr size_t EB = sizeof(i64);  // bytes of an entry
   const int pi = blockIdx.x;
   if (pi >= nprob) return;
   const QProb P = probs[pi];
@@ -741,35 +832,35 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   LDS unsigned char *const q0 = q;
   Tab M, S;
   M.den = (li64 *)q;
-  q += 8 * (size_t)cap.R;
+  q += EB * (size_t)cap.R;
   M.val = (li64 *)q;
-  q += 8 * (size_t)cap.S * cap.W;
+  q += EB * (size_t)cap.S * cap.W;
   li64 *ctx = (li64 *)q;
-  q += 8 * (size_t)cap.CR * cap.CW;
+  q += EB * (size_t)cap.CR * cap.CW;
   M.flag = (lint *)q;
   q += 4 * (size_t)cap.R;
   M.ref = (lint *)q;
   q += 4 * (size_t)cap.R;
   LDS QState *st = (LDS QState *)q;
   q += sizeof(QState);
-  const size_t main_words = (size_t)(q - q0) / 8;
+  const size_t main_words = (size_t)(q - q0) / EB;  // (entries: R and SR are even, the image is whole 16-byte units)
   M.ldet = &st->ldet;
   M.det = st->det;
   M.W = cap.W;
   M.rows_cap = cap.R;
   M.slots_cap = cap.S;
   S.den = (li64 *)q;
-  q += 8 * (size_t)cap.SR;
+  q += EB * (size_t)cap.SR;
   S.val = (li64 *)q;
-  q += 8 * (size_t)cap.SS * cap.CW;
+  q += EB * (size_t)cap.SS * cap.CW;
   S.det = (li64 *)q;
-  q += 8 * MAXDET;
+  q += EB * MAXDET;
   S.flag = (lint *)q;
   q += 4 * (size_t)cap.SR;
   S.ref = (lint *)q;
   q += 4 * (size_t)cap.SR;
   S.ldet = (lint *)q;
-  q += 8;
+  q += 16;
   S.W = cap.CW;
   S.rows_cap = cap.SR;
   S.slots_cap = cap.SS;
@@ -793,10 +884,10 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   wsync();
   {
     const int ncol = nvar + nparm + 1;
-    const i64 *in = input + P.in_off;
+    const w64 *in = input + P.in_off;
     for (int r = 0; r < ni; r++)
       if (lane < ncol) M.val[r * W + lane] = in[(size_t)r * ncol + lane];
-    const i64 *cin = in + (size_t)ni * ncol;
+    const w64 *cin = in + (size_t)ni * ncol;
     for (int r = 0; r < nc; r++)
       if (lane <= nparm) ctx[r * CW + lane] = cin[(size_t)r * (nparm + 1) + lane];
     for (int base = 0; base < nvar + ni; base += 64) {
@@ -883,7 +974,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
             const bool critic = __ballot(lane < nvar && v > 0) == 0;
             // lane j <= nparm of the new context row: parameters, then the constant
             const i64 vc = bcast(v, nvar);
-            const i64 vp = __shfl(v, (lane + nvar + 1) & 63);  // lane j < nparm: column nvar+1+j
+            const i64 vp = qshfl(v, (lane + nvar + 1) & 63);  // lane j < nparm: column nvar+1+j
             i64 ex = lane < nparm ? vp : (lane == nparm ? (critic ? vc : csub(vc, 1, w.bad)) : 0);
             int sni = build_sub(S, ctx, CW, nparm, nc, true, ex, lane);
             if (sni < 0) {
@@ -930,7 +1021,7 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
             }
             const i64 v = lane < ncol ? M.val[M.ref[pivi] * W + lane] : 0;
             const i64 vc = bcast(v, nvar);
-            const i64 vp = __shfl(v, (lane + nvar + 1) & 63);
+            const i64 vp = qshfl(v, (lane + nvar + 1) & 63);
             i64 g = 0;
             for (int j = 0; j < nparm; j++) g = gcd64(g, bcast(vp, j));
             if (!integer) g = gcd64(g, vc);
@@ -1164,46 +1255,67 @@ __global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const
   }
 }
 
-// cells of every finished problem, packed back to back: off[i] .. off[i+1]
-__global__ void pip_quast_pack_kernel(const i64 *cells, const i64 *off, i64 *packed, int cells_cap) {
+};  // struct QK
+
+template <class QI>
+__global__ __launch_bounds__(64) void pip_quast_kernel(const QProb *probs, const w64 *input, QI *stack, QI *cells, int *out,
+                                                        int nprob, QCaps cap) {
+  QK<QI>::run(probs, input, stack, cells, out, nprob, cap);
+}
+
+// cells of every finished problem, packed back to back: off[i] .. off[i+1] (a cell is `cw` raw words: three entries)
+__global__ void pip_quast_pack_kernel(const w64 *cells, const w64 *off, w64 *packed, int cells_cap, int cw) {
   const int pi = blockIdx.x;
-  const i64 lo = off[pi], n = off[pi + 1] - lo;
-  const i64 *src = cells + (size_t)pi * cells_cap * 3;
-  for (i64 k = threadIdx.x; k < 3 * n; k += blockDim.x) packed[3 * lo + k] = src[k];
+  const w64 lo = off[pi], n = off[pi + 1] - lo;
+  const w64 *src = cells + (size_t)pi * cells_cap * cw;
+  for (w64 k = threadIdx.x; k < cw * n; k += blockDim.x) packed[cw * lo + k] = src[k];
 }
 
 }  // namespace
 
-extern "C" size_t pipk_quast_lds_bytes(const QCaps *c) {
-  size_t b = 8 * (size_t)c->R + 8 * (size_t)c->S * c->W + 8 * (size_t)c->CR * c->CW + 8 * (size_t)c->R + sizeof(QState);
-  b += 8 * (size_t)c->SR + 8 * (size_t)c->SS * c->CW + 8 * MAXDET + 8 * (size_t)c->SR + 8;
-  b += 8 * ((size_t)c->CW + 2);
+// LDS image and stack frame of a launch, by entry width (ebits 64 or 128): EB bytes an entry
+static size_t quast_state_bytes(int ebits) { return ebits == 128 ? sizeof(QK<w128>::QState) : sizeof(QK<w64>::QState); }
+extern "C" size_t pipk_quast_lds_bytes(const QCaps *c, int ebits) {
+  const size_t EB = ebits == 128 ? 16 : 8;
+  size_t b = EB * (size_t)c->R + EB * (size_t)c->S * c->W + EB * (size_t)c->CR * c->CW + 8 * (size_t)c->R + quast_state_bytes(ebits);
+  b += EB * (size_t)c->SR + EB * (size_t)c->SS * c->CW + EB * MAXDET + 8 * (size_t)c->SR + 16;
+  b += EB * ((size_t)c->CW + 2);
   return (b + 15) & ~(size_t)15;
 }
-extern "C" size_t pipk_quast_frame_words(const QCaps *c) {
-  return (8 * (size_t)c->R + 8 * (size_t)c->S * c->W + 8 * (size_t)c->CR * c->CW + 8 * (size_t)c->R + sizeof(QState)) / 8;
+// entries (not bytes) of one frame of the fork stack
+extern "C" size_t pipk_quast_frame_words(const QCaps *c, int ebits) {
+  const size_t EB = ebits == 128 ? 16 : 8;
+  return (EB * (size_t)c->R + EB * (size_t)c->S * c->W + EB * (size_t)c->CR * c->CW + 8 * (size_t)c->R + quast_state_bytes(ebits)) / EB;
 }
 
-static int g_quast_lds[64];  // per device: dynamic LDS the kernel has been allowed
+static int g_quast_lds[2][64];  // per flavour and device: dynamic LDS the kernel has been allowed
 
-extern "C" hipError_t pipk_launch_quast(const QProb *probs, const long long *input, long long *stack, long long *cells,
-                                        int *out, int nprob, const QCaps *cap, hipStream_t stream) {
+// stack, cells: entries of `ebits` bits (frame_words x depth and 3 x cells of them per problem); input: long longs
+extern "C" hipError_t pipk_launch_quast(const QProb *probs, const long long *input, void *stack, void *cells, int *out,
+                                        int nprob, const QCaps *cap, int ebits, hipStream_t stream) {
   if (nprob <= 0) return hipSuccess;
-  const size_t shm = pipk_quast_lds_bytes(cap);
+  const size_t shm = pipk_quast_lds_bytes(cap, ebits);
+  const int fl = ebits == 128 ? 1 : 0;
+  const void *fn = fl ? (const void *)pip_quast_kernel<w128> : (const void *)pip_quast_kernel<w64>;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (dev < 0 || dev >= 64 || (size_t)g_quast_lds[dev] < shm) {  // opt in to more dynamic LDS, once per device and size
-    e = hipFuncSetAttribute((const void *)pip_quast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  if (dev < 0 || dev >= 64 || (size_t)g_quast_lds[fl][dev] < shm) {  // opt in to more dynamic LDS, once per device and size
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64) g_quast_lds[dev] = (int)shm;
+    if (dev >= 0 && dev < 64) g_quast_lds[fl][dev] = (int)shm;
   }
-  hipLaunchKernelGGL(pip_quast_kernel, dim3(nprob), dim3(64), shm, stream, probs, input, stack, cells, out, nprob, *cap);
+  if (fl)
+    hipLaunchKernelGGL(pip_quast_kernel<w128>, dim3(nprob), dim3(64), shm, stream, probs, input, (w128 *)stack, (w128 *)cells, out,
+                       nprob, *cap);
+  else
+    hipLaunchKernelGGL(pip_quast_kernel<w64>, dim3(nprob), dim3(64), shm, stream, probs, input, (w64 *)stack, (w64 *)cells, out, nprob,
+                       *cap);
   return hipGetLastError();
 }
 extern "C" hipError_t pipk_launch_quast_pack(const long long *cells, const long long *off, long long *packed, int nprob,
-                                             int cells_cap, hipStream_t stream) {
+                                             int cells_cap, int ebits, hipStream_t stream) {
   if (nprob <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pip_quast_pack_kernel, dim3(nprob), dim3(128), 0, stream, cells, off, packed, cells_cap);
+  hipLaunchKernelGGL(pip_quast_pack_kernel, dim3(nprob), dim3(128), 0, stream, cells, off, packed, cells_cap, ebits == 128 ? 6 : 3);
   return hipGetLastError();
 }

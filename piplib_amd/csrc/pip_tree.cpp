@@ -879,11 +879,14 @@ void simplify_rows(std::vector<i64> &m, int rows, int width, int cst) { simplify
 
 // One small 64-bit problem through the device-resident traiter() (defined with the device tree at the end
 // of this file): true when it was served there (tape / is_void / pivots filled), false: use the host tree.
+// (E: the entry type -- long long, or __int128 for the overflow-safe flavour: the kernel is a template over it)
+template <class E>
 static bool device_tree_one(pipamd_engine *e, const pipamd_problem &p, int simplify, int deepest_cut, int qflags,
-                            std::vector<Cell> &tape, bool *is_void, int64_t *pivots);
+                            std::vector<CellT<E>> &tape, bool *is_void, int64_t *pivots);
 // The same for many problems: fills the outputs of every problem it serves and marks it in `served`.
+template <class E, class CELL>
 static void device_tree_many(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
-                             std::vector<char> &served, pipamd_sol_cell **cells, size_t *n_cells, int *rcs, int *statuses,
+                             std::vector<char> &served, CELL **cells, size_t *n_cells, int *rcs, int *statuses,
                              int64_t *pivots);
 
 // the tape as the C ABI hands it out: (kind, param1, param2) cells, sol.c:52-59
@@ -979,7 +982,7 @@ extern "C" int pipamd_solve_tableau(pipamd_engine *e, int nvar, int nparm, int n
       std::vector<Cell> tape;
       bool is_void = false;
       int64_t pv = 0;
-      if (device_tree_one(e, p, simplify, deepest_cut, 0, tape, &is_void, &pv)) {
+      if (device_tree_one<i64>(e, p, simplify, deepest_cut, 0, tape, &is_void, &pv)) {
         *cells = nullptr;
         *n_cells = 0;
         if (status) *status = 0;
@@ -1011,12 +1014,12 @@ static int traiter_any(pipamd_engine *e, int nvar, int nparm, int ni, int nc, in
   if (pivots) *pivots = 0;
   int rc = PIPAMD_OK;
   try {
-    if constexpr (sizeof(E) == sizeof(i64)) {  // a small problem (with or without the dual): wholly on the device
+    {  // a small problem (with or without the dual): wholly on the device
       const pipamd_problem p{nvar, nparm, ni, nc, bigparm, (flags & PIPAMD_T_INT) ? 1 : 0, tableau, context};
-      std::vector<Cell> tape;
+      std::vector<CellT<E>> tape;
       bool is_void = false;
       int64_t pv = 0;
-      if (device_tree_one(e, p, 0, deepest_cut, Q_NO_CONTEXT_TEST | ((flags & PIPAMD_T_DUAL) ? Q_DUAL : 0), tape, &is_void, &pv)) {
+      if (device_tree_one<E>(e, p, 0, deepest_cut, Q_NO_CONTEXT_TEST | ((flags & PIPAMD_T_DUAL) ? Q_DUAL : 0), tape, &is_void, &pv)) {
         if (pivots) *pivots = pv;
         return export_tape(tape, cells, n_cells);
       }
@@ -1057,6 +1060,19 @@ extern "C" int pipamd_solve_tableau128(pipamd_engine *e, int nvar, int nparm, in
   if (!e) return PIPAMD_E_INVALID;
   if (hipSetDevice(e->device) != hipSuccess) return PIPAMD_E_HIP;
   try {
+    if (cells && n_cells && valid_shape(nvar, nparm, ni, nc, bigparm, ineq, ctx)) {  // a small problem: wholly on the device
+      const pipamd_problem p{nvar, nparm, ni, nc, bigparm, nq, ineq, ctx};
+      std::vector<CellT<i128>> tape;
+      bool is_void = false;
+      int64_t pv = 0;
+      if (device_tree_one<i128>(e, p, simplify, deepest_cut, 0, tape, &is_void, &pv)) {
+        *cells = nullptr;
+        *n_cells = 0;
+        if (status) *status = 0;
+        if (pivots) *pivots = pv;
+        return is_void ? PIPAMD_OK : export_tape(tape, cells, n_cells);
+      }
+    }
     TreeT<i128> t(e, deepest_cut);
     return solve_one(t, nvar, nparm, ni, nc, bigparm, nq, ineq, ctx, simplify, deepest_cut, cells, n_cells, status, pivots);
   } catch (int code) {
@@ -1120,7 +1136,7 @@ extern "C" int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_probl
   if (!many_args(e, n, probs, nthreads, cells, n_cells, rcs, statuses, pivots)) return PIPAMD_E_INVALID;
   std::vector<char> served(n > 0 ? n : 1, 0);
   if (hipSetDevice(e->device) == hipSuccess)  // small problems: wholly on the device, in one launch
-    device_tree_many(e, n, probs, simplify, deepest_cut, served, cells, n_cells, rcs, statuses, pivots);
+    device_tree_many<i64>(e, n, probs, simplify, deepest_cut, served, cells, n_cells, rcs, statuses, pivots);
   return solve_many<Tree, pipamd_sol_cell>(e, n, probs, simplify, deepest_cut, nthreads, cells, n_cells, rcs, statuses, pivots,
                                            served);
 }
@@ -1131,6 +1147,8 @@ extern "C" int pipamd_solve_tableaux128(pipamd_engine *e, int n, const pipamd_pr
                                         int64_t *pivots) {
   if (!many_args(e, n, probs, nthreads, cells, n_cells, rcs, statuses, pivots)) return PIPAMD_E_INVALID;
   std::vector<char> served(n > 0 ? n : 1, 0);
+  if (hipSetDevice(e->device) == hipSuccess)  // small problems: wholly on the device, in one launch
+    device_tree_many<i128>(e, n, probs, simplify, deepest_cut, served, cells, n_cells, rcs, statuses, pivots);
   return solve_many<TreeT<i128>, pipamd_sol_cell128>(e, n, probs, simplify, deepest_cut, nthreads, cells, n_cells, rcs, statuses,
                                                      pivots, served);
 }
@@ -1867,12 +1885,12 @@ bool quast_caps(const pipamd_problem &p, QCaps &c) {
   const int depth = p.nparm ? 24 : 0;
   c.W = ncol + newp;
   c.S = std::min(64, p.ni + 24);
-  c.R = p.nvar + c.S;
+  c.R = (p.nvar + c.S + 1) & ~1;  // (even: the LDS image and the stack frames are whole 16-byte units in either flavour)
   c.CW = p.nparm + newp + 1;
   c.CR = p.nc + 2 * newp + depth + 2;
   c.SS = std::min(64, c.CR + 1 + 16);
   if (c.CR + 1 > c.SS) return false;
-  c.SR = c.CW - 1 + c.SS;
+  c.SR = (c.CW - 1 + c.SS + 1) & ~1;
   c.depth = depth;
   c.cells = 4096;  // SOL_SIZE, type.h:33
   return true;
@@ -1889,8 +1907,10 @@ void quast_caps_max(QCaps &a, const QCaps &b) {
   a.cells = std::max(a.cells, b.cells);
 }
 
+template <class E>
 void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipamd_problem *probs, const QCaps &cap, int qflags,
-                       std::vector<FResult> &res, int *served, int *handed_back) {
+                       std::vector<FResultT<E>> &res, int *served, int *handed_back) {
+  constexpr int EW = (int)(sizeof(E) / 8), EBITS = 64 * EW;
   const int n = (int)idx.size();
   const bool stats = getenv("PIPAMD_FOREST_STATS") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1917,28 +1937,28 @@ void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipa
     if (na) memcpy(in + qp[k].in_off, p.ineq, na * sizeof(i64));
     if (ncx) memcpy(in + qp[k].in_off + na, p.ctx, ncx * sizeof(i64));
   }
-  const size_t frame = pipk_quast_frame_words(&cap);
+  const size_t frame = pipk_quast_frame_words(&cap, EBITS);  // entries
   QProb *d_prob = dt_buffer<QProb>(e, 0, sizeof(QProb) * n);
   i64 *d_in = dt_buffer<i64>(e, 1, sizeof(i64) * words);
-  i64 *d_stack = dt_buffer<i64>(e, 2, sizeof(i64) * frame * (size_t)cap.depth * n);
-  i64 *d_cells = dt_buffer<i64>(e, 3, sizeof(i64) * 3 * (size_t)cap.cells * n);
+  i64 *d_stack = dt_buffer<i64>(e, 2, sizeof(E) * frame * (size_t)cap.depth * n);
+  i64 *d_cells = dt_buffer<i64>(e, 3, sizeof(E) * 3 * (size_t)cap.cells * n);
   int *d_out = dt_buffer<int>(e, 4, sizeof(int) * Q_OUT * n);
   const double t1 = now();
   HIPTHROW(hipMemcpy(d_prob, qp.data(), sizeof(QProb) * n, hipMemcpyHostToDevice));
   HIPTHROW(hipMemcpyAsync(d_in, in, sizeof(i64) * words, hipMemcpyHostToDevice, 0));
-  HIPTHROW(pipk_launch_quast(d_prob, d_in, d_stack, d_cells, d_out, n, &cap, 0));
+  HIPTHROW(pipk_launch_quast(d_prob, d_in, d_stack, d_cells, d_out, n, &cap, EBITS, 0));
   std::vector<int> out(Q_OUT * (size_t)n);
   HIPTHROW(hipMemcpy(out.data(), d_out, sizeof(int) * Q_OUT * n, hipMemcpyDeviceToHost));
   const double t2 = now();
   std::vector<i64> off(n + 1, 0);
   for (int k = 0; k < n; k++) off[k + 1] = off[k] + (out[Q_OUT * k] == Q_DONE ? out[Q_OUT * k + 1] : 0);
-  std::vector<i64> packed(3 * (size_t)off[n]);
+  std::vector<E> packed(3 * (size_t)off[n]);
   if (off[n]) {
     i64 *d_off = dt_buffer<i64>(e, 5, sizeof(i64) * (n + 1));
-    i64 *d_packed = dt_buffer<i64>(e, 6, sizeof(i64) * 3 * (size_t)off[n]);
+    i64 *d_packed = dt_buffer<i64>(e, 6, sizeof(E) * 3 * (size_t)off[n]);
     HIPTHROW(hipMemcpy(d_off, off.data(), sizeof(i64) * (n + 1), hipMemcpyHostToDevice));
-    HIPTHROW(pipk_launch_quast_pack(d_cells, d_off, d_packed, n, cap.cells, 0));
-    HIPTHROW(hipMemcpy(packed.data(), d_packed, sizeof(i64) * packed.size(), hipMemcpyDeviceToHost));
+    HIPTHROW(pipk_launch_quast_pack(d_cells, d_off, d_packed, n, cap.cells, EBITS, 0));
+    HIPTHROW(hipMemcpy(packed.data(), d_packed, sizeof(E) * packed.size(), hipMemcpyDeviceToHost));
   }
   const double t3 = now();
   if (stats) {
@@ -1958,9 +1978,9 @@ void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipa
   }
   if (stats)
     fprintf(stderr, "[device tree] %d problems, LDS %zu B, frame %zu words x %d; pack+alloc %.2f ms, copy+kernel %.2f ms, tape %.2f ms (%lld cells)\n",
-            n, pipk_quast_lds_bytes(&cap), frame, cap.depth, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (long long)off[n]);
+            n, pipk_quast_lds_bytes(&cap, EBITS), frame, cap.depth, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (long long)off[n]);
   for (int k = 0; k < n; k++) {
-    FResult &r = res[idx[k]];
+    FResultT<E> &r = res[idx[k]];
     const int st = out[Q_OUT * k];
     if (st == Q_FALLBACK) {
       ++*handed_back;
@@ -1974,14 +1994,19 @@ void device_tree_chunk(pipamd_engine *e, const std::vector<int> &idx, const pipa
     r.tape.clear();
     if (st == Q_DONE) {
       r.tape.resize((size_t)(off[k + 1] - off[k]));
-      const i64 *c = packed.data() + 3 * (size_t)off[k];
-      for (size_t t = 0; t < r.tape.size(); t++) r.tape[t] = Cell{(int)c[3 * t], c[3 * t + 1], c[3 * t + 2]};
+      const E *c = packed.data() + 3 * (size_t)off[k];
+      for (size_t t = 0; t < r.tape.size(); t++) r.tape[t] = CellT<E>{(int)c[3 * t], c[3 * t + 1], c[3 * t + 2]};
     }
   }
 }
 
-void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut, std::vector<FResult> &res,
+template <class E>
+void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut, std::vector<FResultT<E>> &res,
                  int *served, int *handed_back, int qflags = 0) {
+  constexpr int EBITS = 64 * (int)(sizeof(E) / 8);
+  // LDS a problem's image may take: 64 KB in 64 bits (two problems and more per CU); the 128-bit flavour, whose image is
+  // twice the size, may have a CU's worth
+  const size_t lds_limit = EBITS == 128 ? (size_t)128 * 1024 : (size_t)64 * 1024;
   struct Hold {  // the engine's device-tree buffers serve one call at a time
     pthread_mutex_t *m;
     explicit Hold(pthread_mutex_t *mm) : m(mm) { pthread_mutex_lock(m); }
@@ -1998,7 +2023,7 @@ void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simpl
     cap.deepest = deepest_cut ? 1 : 0;
     cap.simplify = simplify ? 1 : 0;  // the kernel simplifies the rows as it loads them
     try {
-      device_tree_chunk(e, idx, probs, cap, qflags, res, served, handed_back);
+      device_tree_chunk<E>(e, idx, probs, cap, qflags, res, served, handed_back);
     } catch (int) {  // allocation or launch failure: the chunk's problems go to the next path
       (void)hipGetLastError();
     }
@@ -2014,8 +2039,8 @@ void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simpl
     QCaps c;
     memset(&c, 0, sizeof c);
     if (!quast_caps(probs[i], c)) continue;
-    const size_t lds = pipk_quast_lds_bytes(&c);
-    if (lds > 64 * 1024) continue;
+    const size_t lds = pipk_quast_lds_bytes(&c, EBITS);
+    if (lds > lds_limit) continue;
     order.emplace_back((int)(lds / 8192), i);
   }
   std::stable_sort(order.begin(), order.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
@@ -2031,11 +2056,11 @@ void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simpl
     }
     QCaps m = cap;
     quast_caps_max(m, c);
-    if (pipk_quast_lds_bytes(&m) > 64 * 1024) {  // (the maxima of several shapes of one class together)
+    if (pipk_quast_lds_bytes(&m, EBITS) > lds_limit) {  // (the maxima of several shapes of one class together)
       flush();
       m = c;
     }
-    const size_t per = sizeof(i64) * (pipk_quast_frame_words(&m) * (size_t)m.depth + 3 * (size_t)m.cells);
+    const size_t per = sizeof(E) * (pipk_quast_frame_words(&m, EBITS) * (size_t)m.depth + 3 * (size_t)m.cells);
     if (!idx.empty() && per * (idx.size() + 1) > budget) {
       flush();
       m = c;
@@ -2047,13 +2072,14 @@ void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simpl
 }
 }  // namespace
 
+template <class E>
 static bool device_tree_one(pipamd_engine *e, const pipamd_problem &p, int simplify, int deepest_cut, int qflags,
-                            std::vector<Cell> &tape, bool *is_void, int64_t *pivots) {
+                            std::vector<CellT<E>> &tape, bool *is_void, int64_t *pivots) {
   if (e->no_device_tree || getenv("PIPAMD_NO_DEVICE_TREE")) return false;
-  std::vector<FResult> res(1);
+  std::vector<FResultT<E>> res(1);
   res[0].rc = PIPAMD_E_TOOLARGE;
   int served = 0, back = 0;
-  device_tree(e, 1, &p, simplify, deepest_cut, res, &served, &back, qflags);
+  device_tree<E>(e, 1, &p, simplify, deepest_cut, res, &served, &back, qflags);
   pthread_mutex_lock(&e->dt_lock);
   e->dt_served = served;  // (pipamd_last_device_tree also answers for the one-problem entries)
   e->dt_fallback = back;
@@ -2065,14 +2091,15 @@ static bool device_tree_one(pipamd_engine *e, const pipamd_problem &p, int simpl
   return true;
 }
 
+template <class E, class CELL>
 static void device_tree_many(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
-                             std::vector<char> &served, pipamd_sol_cell **cells, size_t *n_cells, int *rcs, int *statuses,
+                             std::vector<char> &served, CELL **cells, size_t *n_cells, int *rcs, int *statuses,
                              int64_t *pivots) {
   e->dt_served = e->dt_fallback = 0;
   if (e->no_device_tree || getenv("PIPAMD_NO_DEVICE_TREE") || n <= 0) return;
-  std::vector<FResult> res(n);
+  std::vector<FResultT<E>> res(n);
   for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;
-  device_tree(e, n, probs, simplify, deepest_cut, res, &e->dt_served, &e->dt_fallback);
+  device_tree<E>(e, n, probs, simplify, deepest_cut, res, &e->dt_served, &e->dt_fallback);
   for (int i = 0; i < n; i++) {
     if (res[i].rc != PIPAMD_OK) continue;
     served[i] = 1;
@@ -2086,12 +2113,12 @@ static void device_tree_many(pipamd_engine *e, int n, const pipamd_problem *prob
 
 // Many problems: the device tree first (small problems), then the lock-step Forest; the few that need
 // a rare path are finished by the Tree.
-// (the device tree is 64-bit: the 128-bit flavour starts with the Forest)
+template <class E>
 static void lockstep_device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut,
-                                 std::vector<FResultT<i64>> &res) {
-  if (!e->no_device_tree && !getenv("PIPAMD_NO_DEVICE_TREE")) device_tree(e, n, probs, simplify, deepest_cut, res, &e->dt_served, &e->dt_fallback);
+                                 std::vector<FResultT<E>> &res) {
+  if (!e->no_device_tree && !getenv("PIPAMD_NO_DEVICE_TREE"))
+    device_tree<E>(e, n, probs, simplify, deepest_cut, res, &e->dt_served, &e->dt_fallback);
 }
-static void lockstep_device_tree(pipamd_engine *, int, const pipamd_problem *, int, int, std::vector<FResultT<i128>> &) {}
 
 template <class E, class CELL>
 static int lockstep_any(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut, CELL **cells,
@@ -2104,7 +2131,7 @@ static int lockstep_any(pipamd_engine *e, int n, const pipamd_problem *probs, in
   std::vector<FResult> res(n);
   for (auto &r : res) r.rc = PIPAMD_E_TOOLARGE;  // until a path has served it
   e->dt_served = e->dt_fallback = 0;
-  lockstep_device_tree(e, n, probs, simplify, deepest_cut, res);
+  lockstep_device_tree<E>(e, n, probs, simplify, deepest_cut, res);
   std::vector<int> rest;
   for (int i = 0; i < n; i++)
     if (res[i].rc == PIPAMD_E_TOOLARGE) rest.push_back(i);

@@ -21,12 +21,12 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 G = os.path.join(pb.ROOT, "tests", "golden")
 
 
-def _screen(probs, limit=3000, flags=0):
-    """(problem, oracle result) for the problems the CPU oracle finishes quickly"""
+def _screen(probs, limit=3000, flags=0, exe=None):
+    """(problem, oracle result) for the problems the CPU oracle (exe: the 64-bit one, or pb.ORACLEPIP128) finishes quickly"""
     keep = []
     for p in probs:
         try:
-            r = pb.run_batch(pb.ORACLEPIP, [p], flags, timeout=3).results[0]
+            r = pb.run_batch(exe or pb.ORACLEPIP, [p], flags, timeout=3).results[0]
         except subprocess.TimeoutExpired:
             continue
         if r.pivots <= limit:
@@ -71,6 +71,35 @@ def test_random_problems_vs_oracle(seed, shape, nq, count, served, cmax):
     keep = _screen(synth.random_problems(seed, count, *shape, nq, cmax=cmax))
     assert len(keep) >= 0.4 * count  # (the 10x14 family has many problems the reference itself does not finish)
     _check(keep, served)
+
+
+@pytest.mark.parametrize("seed,shape,nq,count,served,cmax", [
+    (144, (16, 3, 20, 3), 1, 60, 0.9, 4), (147, (10, 4, 14, 1), 1, 60, 0.9, 4), (142, (4, 3, 6, 3), 1, 120, 0.9, 4),
+    (149, (30, 2, 45, 2), 0, 40, 0.9, 1), (157, (28, 1, 44, 1), 1, 30, 0.9, 1)])
+def test_random_problems_128bit_device_tree_vs_oracle128(seed, shape, nq, count, served, cmax):
+    """The device-resident traiter() of the overflow-safe flavour (the kernel is a template over the entry type: 128-bit
+    tableaux, contexts, cuts and tape cells in LDS, every product and sum checked against 128 bits): the families on
+    which the 64-bit kernel hands a quarter to three quarters of the problems back for overflow, through
+    pipamd_solve_tableaux_lockstep128, against the 128-bit CPU oracle -- tape text and pivot count of every problem, the
+    share served on the device asserted -- and again with the device tree off (ForestT<__int128> / TreeT<__int128>)."""
+    from piplib_amd import engine as eng, synth
+    keep = _screen(synth.random_problems(seed, count, *shape, nq, cmax=cmax), exe=pb.ORACLEPIP128)
+    assert len(keep) >= 0.4 * count
+    e = eng.Engine(0)
+    probs = [p for p, _ in keep]
+    got = eng.solve_tableaux_lockstep128(e, probs)
+    srv, back = e.last_device_tree()
+    assert srv + back <= len(probs) and srv >= served * len(probs), (srv, back, len(probs))
+    for (p, r), (text, rc, st, piv) in zip(keep, got):
+        if r.status == pb.ST_ABORT:
+            assert rc == -5, (rc, st)
+            continue
+        assert rc == 0, (rc, st)
+        assert pb.squash(text) == pb.squash("void\n" if r.status == pb.ST_VOID else r.text)
+        assert piv == r.pivots
+    e.set_device_tree(False)
+    assert eng.solve_tableaux_lockstep128(e, probs) == got
+    assert e.last_device_tree() == (0, 0)
 
 
 def test_big_parameter_problems_vs_oracle():

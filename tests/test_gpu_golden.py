@@ -265,6 +265,13 @@ def test_parametric_128bit_lockstep_vs_reference_gmp_build(seed):
     e = eng.Engine(0)
     many = eng.solve_tableaux_lockstep128(e, [p for p, _ in keep])
     assert len(many) == len(keep) >= 12
+    # the device-resident traiter() of the 128-bit flavour serves them (one wave per problem, no host round trip) ...
+    served, back = e.last_device_tree()
+    assert served >= 0.95 * len(keep), (served, back, len(keep))
+    # ... and without it the lock-step scheduler gives the same, entry by entry
+    e.set_device_tree(False)
+    assert eng.solve_tableaux_lockstep128(e, [p for p, _ in keep]) == many and e.last_device_tree() == (0, 0)
+    e.set_device_tree(True)
     checked = 0
     for i, ((p, r), (text, rc, st, piv)) in enumerate(zip(keep, many)):
         if rc != 0:
