@@ -1552,7 +1552,7 @@ struct PipQueue {
 // parameter-sign bookkeeping of the row summaries and the stride multiplications disappear.
 template <class T, int NCH, int NW, bool GM, int SC, bool FULL>
 __global__ __launch_bounds__(64 * NW, (NW == 1 && NCH == 1 && sizeof(T) == 8) ? PIP_MINWAVES
-                                      : ((sizeof(T) == 16 && NCH <= 4) ? PIP_MINWAVES128 : 1)) void pip_advance_kernel(
+                                      : ((sizeof(T) == 16 && NCH <= 4) ? (NW == 16 ? 4 : PIP_MINWAVES128) : 1)) void pip_advance_kernel(
     PipJob *jobs, i64 *arena, int njobs, int Lmax_, int Smax_, int Wmax, int iter_limit, PipQueue q, unsigned char *gimg,
     size_t gimg_bytes, int gslots, u64 *prof) {
   const int Smax = SC > 0 ? SC : Smax_;

@@ -34,6 +34,9 @@
 #ifndef PIP_LEAN_PF
 #define PIP_LEAN_PF 2  // rows of a pivot's work list in flight
 #endif
+#ifndef PIP_LEAN_MID_INV
+#define PIP_LEAN_MID_INV 0  // (A/B switch) the mid path's row gcd and division by inverse multiplication (12 bytes of scratch per lane)
+#endif
 #ifndef PIP_LEAN_WAVES
 #define PIP_LEAN_WAVES 8  // waves per SIMD the kernel is bounded to (64 VGPRs)
 #endif
@@ -705,7 +708,11 @@ __global__ __launch_bounds__(64, PIP_LEAN_WAVES) void pip_lean_kernel(PipJob *jo
               zw[h] = v;
               mx |= uabs64(v);
             }
+#if PIP_LEAN_MID_INV
+            if (!row_reduce<i64, 2, false>(zw, mx, g0, lane, nd, wmul(dpiv, (i64)foo))) {
+#else
             if (!row_reduce_rem<i64, 2>(zw, mx, g0, lane, nd)) {  // (the remainder loop: reduce_by_inverse costs this kernel 12 bytes of scratch)
+#endif
               if (lane == 0) sc.bad = 1;
             }
             if (ballot64(((uabs64(zw[0]) | uabs64(zw[1])) >> 31) != 0) == 0) {
