@@ -9,6 +9,8 @@ import numpy as np
 from piplib_amd import engine as eng, synth
 import pipbatch as pb
 
+BITS = int(os.environ.get("BITS", "64"))  # 128: the overflow-safe flavour (128-bit oracle, *_lockstep128 / *_tableaux128, the 128-bit device tree)
+ORACLE = pb.ORACLEPIP128 if BITS == 128 else pb.ORACLEPIP
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 e = eng.Engine(0)
@@ -27,7 +29,7 @@ while time.time() - t0 < budget:
     probs, want = [], []
     for p in synth.random_problems(seed, 8 if os.environ.get("FUZZ_BIG") else 24, nvar, nparm, ni, nc, nq, cmax=cmax, bmax=bmax):
         try:  # some random parametric problems make the reference itself cut forever
-            r = pb.run_batch(pb.ORACLEPIP, [p], pb.F_DEEPEST if deepest else 0, timeout=2).results[0]
+            r = pb.run_batch(ORACLE, [p], pb.F_DEEPEST if deepest else 0, timeout=2).results[0]
         except subprocess.TimeoutExpired:
             continue
         if r.pivots <= 2000:
@@ -38,7 +40,7 @@ while time.time() - t0 < budget:
         bp = nvar + 1 + int(rng.integers(0, nparm))
         probs = [pb.Problem(p.nvar, p.nparm, p.ni, p.nc, bp, p.nq, p.ineq, p.ctx) for p in probs]
         try:
-            want = [pb.run_batch(pb.ORACLEPIP, [p], pb.F_DEEPEST if deepest else 0, timeout=4).results[0] for p in probs]
+            want = [pb.run_batch(ORACLE, [p], pb.F_DEEPEST if deepest else 0, timeout=4).results[0] for p in probs]
         except subprocess.TimeoutExpired:
             continue
         tag += f" bigparm={bp}"
@@ -46,7 +48,11 @@ while time.time() - t0 < budget:
         e.set_device_tree(dt)
         if os.environ.get("FUZZ_VERBOSE"):
             print(f"[{time.time()-t0:.1f} s] {mode} device tree {dt}: {len(probs)} problems, oracle pivots {[r.pivots for r in want]}", tag, flush=True)
-        got = eng.solve_tableaux(e, probs, simplify=True, deepest_cut=deepest, lockstep=(mode == "lockstep"), nthreads=4)
+        if BITS == 128:
+            got = (eng.solve_tableaux_lockstep128(e, probs, simplify=True, deepest_cut=deepest) if mode == "lockstep" else
+                   eng.solve_tableaux128(e, probs, simplify=True, deepest_cut=deepest, nthreads=4))
+        else:
+            got = eng.solve_tableaux(e, probs, simplify=True, deepest_cut=deepest, lockstep=(mode == "lockstep"), nthreads=4)
         if dt and mode == "lockstep":
             sv, bk = e.last_device_tree()
             nserved += sv; nback += bk
