@@ -51,11 +51,11 @@ while time.time() - t0 < budget:
         sys.exit(1)
     st, pv, _, num, den = outs[1]
     for k, r in enumerate(o):
+        if st[k] == eng.ST_CAPACITY:
+            continue  # the row budget of this run (the oracle has none: it may go on to a solution or to "Integer overflow")
         if r.status == pb.ST_ABORT:
             want = {2: eng.ST_OVERFLOW, 4: eng.ST_MAXCOL}.get(r.abort_code, eng.ST_OVERFLOW)
             ok = st[k] == want
-        elif st[k] == eng.ST_CAPACITY:
-            continue  # the row budget of this run
         else:
             ok = st[k] in (eng.ST_SOLUTION, eng.ST_NIL) and pv[k] == r.pivots and \
                 ("()" if st[k] == eng.ST_NIL else pb.squash(solution_text(num[k], den[k]))) == pb.squash(r.text)
