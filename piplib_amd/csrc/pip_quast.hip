@@ -475,7 +475,8 @@ static __device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int nco
   const i64 pivot = bcast(p, pivj), dpiv = t.den[pivi];
   // the determinant in limbs, traiter.c:412-446 (uniform values; lane 0 publishes them).  A pivot of 1
   // over a denominator of 1 multiplies a limb that still has room by 1: nothing to do.
-  if (pivot != 1 || dpiv != 1 || blen(t.det[0]) + 1 >= 64) {
+  constexpr int EBW = 8 * (int)sizeof(i64);  // bits of an Entier (traiter.c:430: lllog2(limb) + lllog2(pivot) < 8 * sizeof(Entier))
+  if (pivot != 1 || dpiv != 1 || blen(t.det[0]) + 1 >= EBW) {
     i64 d = gcd64(pivot, dpiv);
     const i64 ppivot = d == 1 ? pivot : quo(pivot, d);
     i64 dppiv = d == 1 ? dpiv : quo(dpiv, d);
@@ -496,7 +497,7 @@ static __device__ __noinline__ int pivot_step(Tab t, int pivi, int nvar, int nco
     bool placed = false;
 #pragma unroll
     for (int i = 0; i < MAXDET; i++)
-      if (!placed && i < ldet && blen(dt[i]) + blen(ppivot) < 64) {
+      if (!placed && i < ldet && blen(dt[i]) + blen(ppivot) < EBW) {
         dt[i] *= ppivot;
         placed = true;
       }
