@@ -320,15 +320,16 @@ int pipamd_solve_tableaux_lockstep(pipamd_engine *e, int n, const pipamd_problem
 int pipamd_solve_tableaux_lockstep128(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
                                       int deepest_cut, pipamd_sol_cell128 **cells, size_t *n_cells, int *rcs,
                                       int *statuses, int64_t *pivots);
-/* Small problems (at most 64 columns and 64 inequalities, spare room for cuts and new parameters
- * included) are first given to the device-resident traiter() (csrc/pip_quast.hip): one wave per
+/* Small problems (at most 64 columns, spare room for new parameters included, and 104 inequalities -- 128 real rows with
+ * the cuts; round 4: in both entry widths) are first given to the device-resident traiter() (csrc/pip_quast.hip): one wave per
  * problem runs the whole call tree -- pivots, compa_test sub-problems (traiter.c:162-243), forks of the
  * quast (traiter.c:695-759), cuts with new parameters (integrer.c:156-291) -- and writes the tape, with
  * no host round trip.  A problem in which a 64-bit operation would overflow, or that outgrows its
  * reserved rows, is handed back and served by the lock-step scheduler / the per-problem tree, which
  * reproduce the reference's wrap-around and "Integer overflow" behaviour.  pipamd_traiter,
- * pipamd_solve_tableau and pipamd_solve_tableaux try it first too (64-bit entries; since interface version 300 also with
- * PIPAMD_T_DUAL).  On by default (the environment
+ * pipamd_solve_tableau and pipamd_solve_tableaux try it first too (since interface version 300 also with
+ * PIPAMD_T_DUAL), and so do their 128-bit counterparts with the kernel's 128-bit instantiation (there every product and
+ * sum is checked against 128 bits).  On by default (the environment
  * variable PIPAMD_NO_DEVICE_TREE switches it off for a process);
  * pipamd_last_device_tree reports how many problems of the last lock-step call each side served. */
 int pipamd_engine_set_device_tree(pipamd_engine *e, int on);

@@ -14,7 +14,7 @@ enum { Q_NO_CONTEXT_TEST = 1,
        Q_DUAL = 2 };  // Compute_dual (traiter.c:273-294): the list of dual values behind every (rational) solution
 // capacities of one launch (every problem of the launch gets the same LDS image and HBM regions)
 struct QCaps {
-  int R, S, W;    // main tableau: logical rows, real-row slots, columns (W <= 64, S <= 64)
+  int R, S, W;    // main tableau: logical rows, real-row slots, columns (W <= 64, S <= 128)
   int CR, CW;     // context: rows, columns (parameters | constant)
   int SR, SS;     // compa_test sub-problems: logical rows, real-row slots (their width is CW)
   int depth;      // frames of the fork stack

@@ -1,5 +1,5 @@
 // piplib_amd/csrc/pip_quast.hip -- traiter() with its quast decision tree on the device, for SMALL
-// parametric problems (at most 64 columns and 64 real rows).
+// parametric problems (at most 64 columns and 128 real rows), in both entry widths.
 //
 // One wave64 per problem runs the whole call tree of traiter() (traiter.c:628-791) without a host
 // round trip: the dual simplex with lexicographic pivoting (pivoter, traiter.c:345-548), exam_coef
@@ -237,6 +237,13 @@ static __device__ __forceinline__ int wave_max_i(int x) {
   }
   return x;
 }
+static __device__ __forceinline__ int wave_min_i(int x) {
+  for (int o = 32; o; o >>= 1) {
+    const int y = __shfl_xor(x, o);
+    x = x < y ? x : y;
+  }
+  return x;
+}
 static __device__ __forceinline__ float wave_min_f(float x) {
   for (int o = 32; o; o >>= 1) {
     const float y = __shfl_xor(x, o);
@@ -328,12 +335,97 @@ static __device__ __forceinline__ int trunc_x86(double t) {
   return (!(t > -2147483649.0 && t < 2147483648.0)) ? (int)0x80000000 : (int)t;
 }
 static __device__ __forceinline__ int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+// tab_sort_rows for 65 ... 128 rows to sort (round 4): the same selection sort -- the first row at or after i with the
+// smallest key strictly below the maximum is swapped into place i, traiter.c:591-614 -- with two rows per lane and the rows'
+// data left in LDS: keys in `skey` (128 ints), the swaps done there by lane 0.  No Compute_dual at this size.
+static __device__ __noinline__ int sort_rows_tall(Tab t, int nvar, int nligne, int lane, LDS int *skey) {
+  const int n = nligne - nvar;
+  if (n > 128) return Q_WHY_ROWS | 256;
+  u64 realm[2], below[2];
+  int sv[2];
+  bool rl[2];
+  int smx = 0;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int r0 = lane + 64 * h, k = nvar + r0;
+    int s = 0;
+    bool real = false;
+    if (r0 < n) {
+      const int fl = t.flag[k], rf = t.ref[k];
+      const i64 dn = t.den[k];
+      real = !(fl & F_UNIT);
+      if (real) {
+        const li64 *r = t.val + rf * t.W;
+        if (dn == 1) {
+          for (int j = 0; j < nvar; j++) {
+            const i64 v = r[j];
+            const int q = v == (i64)(int)v ? (int)v : (int)0x80000000;
+            const int a = q < 0 ? (int)(0u - (unsigned)q) : q;
+            s = s > a ? s : a;
+          }
+        } else {
+          const double d = qdouble(dn);
+          for (int j = 0; j < nvar; j++) {
+            const int q = trunc_x86(qdouble(r[j]) / d);
+            const int a = q < 0 ? (int)(0u - (unsigned)q) : q;
+            s = s > a ? s : a;
+          }
+        }
+      }
+    }
+    sv[h] = s;
+    rl[h] = real;
+    realm[h] = __ballot(real);
+    const int m = wave_max_i(real ? s : 0);
+    smx = m > smx ? m : smx;
+    if (r0 < n) skey[r0] = __float_as_int((float)(double)s);  // non-negative floats order like their bit patterns
+  }
+  const double smax = (double)smx;
+#pragma unroll
+  for (int h = 0; h < 2; h++) below[h] = __ballot(rl[h] && (double)(float)(double)sv[h] < smax);
+  wsync();
+  if (!(below[0] | below[1])) return 0;  // no key is below the maximum: no row moves
+  for (int i = 0; i < n; i++) {
+    const int hi = i >> 6, bi = i & 63;
+    if (!((realm[hi] >> bi) & 1)) continue;
+    const u64 c0 = hi == 0 ? below[0] & ~((1ull << bi) - 1) : 0ull;
+    const u64 c1 = hi == 0 ? below[1] : below[1] & ~((1ull << bi) - 1);
+    if (!(c0 | c1)) break;
+    const int k0 = ((c0 >> lane) & 1) ? skey[lane] : 0x7fffffff, k1 = ((c1 >> lane) & 1) ? skey[64 + lane] : 0x7fffffff;
+    const int best = wave_min_i(k0 < k1 ? k0 : k1);
+    const u64 m0 = __ballot(k0 == best && ((c0 >> lane) & 1)), m1 = __ballot(k1 == best && ((c1 >> lane) & 1));
+    const int p = m0 ? first64(m0) : 64 + first64(m1);
+    if (p == i) continue;
+    if (lane == 0) {  // rows i and p trade places (traiter.c:604-612)
+      const int ki = nvar + i, kp = nvar + p;
+      const int f = t.flag[ki], r = t.ref[ki], q = skey[i];
+      const i64 d = t.den[ki];
+      t.flag[ki] = t.flag[kp];
+      t.ref[ki] = t.ref[kp];
+      t.den[ki] = t.den[kp];
+      skey[i] = skey[p];
+      t.flag[kp] = f;
+      t.ref[kp] = r;
+      t.den[kp] = d;
+      skey[p] = q;
+    }
+    {
+      const u64 bit_i = (below[hi] >> bi) & 1;
+      const int hp = p >> 6, bp = p & 63;
+      below[hp] = (below[hp] & ~(1ull << bp)) | (bit_i << bp);
+      below[hi] |= 1ull << bi;
+    }
+    wsync();
+  }
+  return 0;
+}
+
 // pos != null (Compute_dual): pos[i] = the logical row inequality i (row nvar + i before the sort) ends up in; unit
 // rows among nvar.. count as inequality 0, later rows overwriting earlier ones -- the reference never sets their
 // `ineq` (traiter.c:577-578 vs 617-618), zero-filled as the oracle and the reference's own fixtures have it.
-static __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane, LDS unsigned short *pos) {
-  const int n = nligne - nvar;  // rows to sort: at most 64 + the unit rows among them
-  if (n > 64) return Q_WHY_ROWS | 256;
+static __device__ __noinline__ int sort_rows(Tab t, int nvar, int nligne, int lane, LDS unsigned short *pos, LDS int *skey) {
+  const int n = nligne - nvar;  // rows to sort: at most 64 (a lane each) -- or up to 128, two per lane (sort_rows_tall)
+  if (n > 64) return (pos || !skey) ? (Q_WHY_ROWS | 256) : sort_rows_tall(t, nvar, nligne, lane, skey);
   // lane l holds logical row nvar + l (flag, slot, denominator, key); the selection sort swaps lanes
   const int k = nvar + lane;
   int fl = 0, rf = 0, s = 0;
@@ -689,7 +781,7 @@ static __device__ __forceinline__ bool append_row(Tab &t, int nligne, int ni, i6
 // `budget`: pivots the problem may still spend (Q_PIVOT_BUDGET less what it has used): beyond it the problem is handed back.
 static __device__ __noinline__ int solve_plain(Tab t, int nvar, int ni, int lane, int deepest, int budget) {
   const int ncol = nvar + 1;
-  int bad = sort_rows(t, nvar, nvar + ni, lane, nullptr), pivots = 0, found = 0;
+  int bad = sort_rows(t, nvar, nvar + ni, lane, nullptr, nullptr), pivots = 0, found = 0;
   for (int guard = 0; guard < 30000 && !__any(bad); guard++) {  // (the pivot count has 15 bits of the result word)
     const int nligne = nvar + ni;
     int pivi = first_flagged(t, F_MINUS, nligne, lane);
@@ -866,6 +958,8 @@ static __device__ __forceinline__ void run(const QProb *probs, const w64 *input,
   S.rows_cap = cap.SR;
   S.slots_cap = cap.SS;
   li64 *cutv = (li64 *)q;  // [CW + 2]
+  q += EB * ((size_t)cap.CW + 2);
+  LDS int *skey = (LDS int *)q;  // [128] sort keys of a tall tableau (sort_rows_tall)
 
   i64 *my_stack = stack + (size_t)pi * cap.depth * main_words;
   Tape tape;
@@ -956,7 +1050,7 @@ static __device__ __forceinline__ void run(const QProb *probs, const w64 *input,
       if (BAD(w)) break;
       if (next == DECIDE) {
         if (enter) {
-          w.bad |= sort_rows(M, nvar, nvar + ni, lane, dual ? st->pos : nullptr);
+          w.bad |= sort_rows(M, nvar, nvar + ni, lane, dual ? st->pos : nullptr, skey);
           if (dual && lane == 0) st->ni0 = ni;
           wsync();
           enter = false;
@@ -1280,7 +1374,7 @@ extern "C" size_t pipk_quast_lds_bytes(const QCaps *c, int ebits) {
   const size_t EB = ebits == 128 ? 16 : 8;
   size_t b = EB * (size_t)c->R + EB * (size_t)c->S * c->W + EB * (size_t)c->CR * c->CW + 8 * (size_t)c->R + quast_state_bytes(ebits);
   b += EB * (size_t)c->SR + EB * (size_t)c->SS * c->CW + EB * MAXDET + 8 * (size_t)c->SR + 16;
-  b += EB * ((size_t)c->CW + 2);
+  b += EB * ((size_t)c->CW + 2) + 4 * 128;
   return (b + 15) & ~(size_t)15;
 }
 // entries (not bytes) of one frame of the fork stack

@@ -1877,14 +1877,16 @@ bool quast_caps(const pipamd_problem &p, QCaps &c) {
   const int ncol = p.nvar + p.nparm + 1;
   if (p.nvar < 0 || p.nparm < 0 || p.ni < 0 || p.nc < 0 || (p.ni && !p.ineq) || (p.nc && !p.ctx)) return false;
   if (p.bigparm >= ncol || (p.bigparm >= 0 && p.bigparm <= p.nvar)) return false;
-  if (ncol > 64 || p.ni > 56 || p.ni + p.nvar == 0) return false;
+  // at most 64 columns (a lane per column) and 104 inequalities: up to 128 real rows with the cuts (tab_sort_rows has a
+  // lane per row up to 64 rows and two rows per lane beyond -- not with Compute_dual, whose `pos` table has 64 entries)
+  if (ncol > 64 || p.ni > 104 || p.ni + p.nvar == 0) return false;
   // Room for 10 quotients of parametric cuts, 24 cut rows and 24 nested forks.  (Smaller reserves -- 4 / 8 / 8:
   // 11 KB of LDS instead of 26 KB, twice the problems per CU -- made the launch of 10k problems 27 % shorter,
   // but every problem that then runs out of room costs the host schedulers milliseconds.)
   const int newp = p.nparm ? std::min(10, 64 - ncol) : 0;
   const int depth = p.nparm ? 24 : 0;
   c.W = ncol + newp;
-  c.S = std::min(64, p.ni + 24);
+  c.S = p.ni <= 56 ? std::min(64, p.ni + 24) : std::min(128, p.ni + 24);
   c.R = (p.nvar + c.S + 1) & ~1;  // (even: the LDS image and the stack frames are whole 16-byte units in either flavour)
   c.CW = p.nparm + newp + 1;
   c.CR = p.nc + 2 * newp + depth + 2;
@@ -2004,9 +2006,9 @@ template <class E>
 void device_tree(pipamd_engine *e, int n, const pipamd_problem *probs, int simplify, int deepest_cut, std::vector<FResultT<E>> &res,
                  int *served, int *handed_back, int qflags = 0) {
   constexpr int EBITS = 64 * (int)(sizeof(E) / 8);
-  // LDS a problem's image may take: 64 KB in 64 bits (two problems and more per CU); the 128-bit flavour, whose image is
-  // twice the size, may have a CU's worth
-  const size_t lds_limit = EBITS == 128 ? (size_t)128 * 1024 : (size_t)64 * 1024;
+  // LDS a problem's image may take: 96 KB in 64 bits (the tall shapes of up to 128 real rows; the usual ones are a quarter
+  // of that); the 128-bit flavour, whose image is twice the size, may have a CU's worth
+  const size_t lds_limit = EBITS == 128 ? (size_t)150 * 1024 : (size_t)96 * 1024;
   struct Hold {  // the engine's device-tree buffers serve one call at a time
     pthread_mutex_t *m;
     explicit Hold(pthread_mutex_t *mm) : m(mm) { pthread_mutex_lock(m); }

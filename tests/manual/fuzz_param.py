@@ -19,6 +19,8 @@ while time.time() - t0 < budget:
     nvar = int(rng.integers(2, 12)); nparm = int(rng.integers(0, 5)); ni = int(rng.integers(2, 14))
     if os.environ.get("FUZZ_BIG"):  # larger tableaux: more than 64 logical rows, up to 50 columns
         nvar = int(rng.integers(8, 40)); nparm = int(rng.integers(0, 7)); ni = int(rng.integers(6, 50))
+    if os.environ.get("FUZZ_TALL"):  # 57 ... 104 inequalities: the device tree's two-rows-per-lane sort (sort_rows_tall)
+        nvar = int(rng.integers(3, 24)); nparm = int(rng.integers(0, 5)); ni = int(rng.integers(57, 105))
     nc = int(rng.integers(0, 4)) if nparm else 0
     nq = int(rng.integers(0, 2)); deepest = bool(nq and rng.random() < 0.25)
     seed = int(rng.integers(1, 1 << 30))
@@ -27,7 +29,7 @@ while time.time() - t0 < budget:
         cmax = int(rng.choice([1, 1, 2]))
     tag = f"nvar={nvar} nparm={nparm} ni={ni} nc={nc} nq={nq} deepest={deepest} seed={seed} cmax={cmax} bmax={bmax}"
     probs, want = [], []
-    for p in synth.random_problems(seed, 8 if os.environ.get("FUZZ_BIG") else 24, nvar, nparm, ni, nc, nq, cmax=cmax, bmax=bmax):
+    for p in synth.random_problems(seed, 8 if (os.environ.get("FUZZ_BIG") or os.environ.get("FUZZ_TALL")) else 24, nvar, nparm, ni, nc, nq, cmax=cmax, bmax=bmax):
         try:  # some random parametric problems make the reference itself cut forever
             r = pb.run_batch(ORACLE, [p], pb.F_DEEPEST if deepest else 0, timeout=2).results[0]
         except subprocess.TimeoutExpired:

@@ -187,10 +187,21 @@ def test_overflowing_problems_are_handed_back():
     assert back >= 5, (served, back)   # the family really overflows
 
 
-def test_tall_problems_are_handed_back_or_served():
-    """more inequalities than the device tree reserves rows for: the shape test sends them to the forest"""
+@pytest.mark.parametrize("seed,shape,nq,count,served", [
+    (156, (6, 1, 70, 1), 1, 12, 0.9), (158, (10, 2, 90, 2), 1, 16, 0.8), (159, (8, 0, 100, 0), 1, 16, 0.9), (160, (12, 3, 64, 2), 0, 16, 0.9)])
+def test_tall_problems_on_the_device(seed, shape, nq, count, served):
+    """57 ... 104 inequalities (round 4: up to 128 real rows; tab_sort_rows with two rows per lane, sort_rows_tall): served
+    on the device, tape and pivot count as the oracle has them; with the device tree off the same answers"""
+    from piplib_amd import synth
+    keep = _screen(synth.random_problems(seed, count, *shape, nq))
+    assert len(keep) >= count // 2
+    _check(keep, served)
+
+
+def test_taller_problems_are_handed_back():
+    """more than 104 inequalities: the shape test sends them to the forest"""
     from piplib_amd import engine as eng, synth
-    keep = _screen(synth.random_problems(156, 12, 6, 1, 70, 1, 1))
+    keep = _screen(synth.random_problems(161, 8, 6, 1, 110, 1, 1))
     e = eng.Engine(0)
     got = eng.solve_tableaux(e, [p for p, _ in keep], lockstep=True)
     assert e.last_device_tree() == (0, 0)
