@@ -708,6 +708,8 @@ __device__ __forceinline__ i128 readlaneW(i128 v, int src) { return readlane64(v
 
 // zz (N entries per lane, every |zz| below 2^B, B at most W - 2) is divided by gcd(g, all |zz|) in place; returns that
 // gcd, with its factor 2^s and the inverse of its odd part (the caller divides the denominator with them).  g >= 1.
+// Returns 0 -- zz as it came -- if a round made no progress (it cannot; a wave must never spin on it): the caller falls
+// back to the remainder loop.
 // INPLACE: the quotients take the entries' registers and a failing round undoes its multiplications (times m: the same
 // bijection backwards) -- for 128-bit entries and for callers short of registers.
 template <class TW, int N, bool INPLACE = (sizeof(TW) > 8)>
@@ -727,7 +729,9 @@ __device__ __forceinline__ typename WT<TW>::U reduce_by_inverse(TW (&zz)[N], int
         if (((U)zz[e] & lowmask) != 0) pick = zz[e];
       const u64 bad = ballot64(pick != 0);
       if (bad) {
-        g = gcdW(g, uabsW(readlaneW(pick, __ffsll((long long)bad) - 1)));
+        const U g2 = gcdW(g, uabsW(readlaneW(pick, __ffsll((long long)bad) - 1)));
+        if (g2 == g) return 0;  // (cannot be: an entry with low bits set is no multiple of 2^s) -- never loop on it
+        g = g2;
         continue;
       }
     }
@@ -755,7 +759,9 @@ __device__ __forceinline__ typename WT<TW>::U reduce_by_inverse(TW (&zz)[N], int
         return g;
       }
       CNT(14, 1);
-      g = gcdW(g, uabsW(readlaneW(pick, __ffsll((long long)bad) - 1)));
+      const U g2 = gcdW(g, uabsW(readlaneW(pick, __ffsll((long long)bad) - 1)));
+      if (g2 == g) return 0;  // (cannot be, see the proof above: a rejected entry is no multiple of g) -- never loop on it
+      g = g2;
     } else {
       bool okl = true;
 #pragma unroll
@@ -775,7 +781,9 @@ __device__ __forceinline__ typename WT<TW>::U reduce_by_inverse(TW (&zz)[N], int
         zz[e] = a;
         if ((uabsW(q) >> lim) != 0) pick = a;
       }
-      g = gcdW(g, uabsW(readlaneW(pick, __ffsll((long long)bad) - 1)));
+      const U g2 = gcdW(g, uabsW(readlaneW(pick, __ffsll((long long)bad) - 1)));
+      if (g2 == g) return 0;
+      g = g2;
     }
   }
 }
@@ -825,6 +833,7 @@ __device__ __forceinline__ bool row_reduce(T (&z)[N], typename ET<T>::U mx, T g0
 #pragma unroll
     for (int e = 0; e < N; e++) zz[e] = (int)z[e];
     const unsigned gg = reduce_by_inverse<int, N>(zz, B, (unsigned)g, s, inv);
+    if (gg == 0) return row_reduce_rem<T, N>(z, mx, g0, lane, newden);
     if (gg != 1) {
 #pragma unroll
       for (int e = 0; e < N; e++) z[e] = (T)zz[e];
@@ -840,6 +849,7 @@ __device__ __forceinline__ bool row_reduce(T (&z)[N], typename ET<T>::U mx, T g0
 #pragma unroll
       for (int e = 0; e < N; e++) zz[e] = (i64)z[e];
       const u64 gg = reduce_by_inverse<i64, N>(zz, B, (u64)g, s, inv);
+      if (gg == 0) return row_reduce_rem<T, N>(z, mx, g0, lane, newden);
       if (gg != 1) {
 #pragma unroll
         for (int e = 0; e < N; e++) z[e] = (T)zz[e];
@@ -851,6 +861,7 @@ __device__ __forceinline__ bool row_reduce(T (&z)[N], typename ET<T>::U mx, T g0
   int s;
   U inv;
   const U gg = reduce_by_inverse<T, N, (sizeof(T) > 8 || !TRY32)>(z, B, g, s, inv);
+  if (gg == 0) return row_reduce_rem<T, N>(z, mx, g0, lane, newden);
   newden = reduce_den<T, T>(g0, gg, s, inv);
   return true;
 }
