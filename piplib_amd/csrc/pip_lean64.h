@@ -4,11 +4,12 @@
 // The overflow-safe flavour (piplib.h:42-88: the whole library built with a wider Entier) exists for the tableaux on
 // which 64-bit arithmetic overflows -- but what outgrows 64 bits there are the determinant limbs and the products of a
 // row update, seldom the rows themselves: of the 1,000 tableaux of BASELINE's configs[4] (the batch pinned by
-// tests/golden/gmp/wide128.json) the reference's GMP build forms a value beyond 2^63 on 587, yet on nine in ten every
-// STORED entry stays below 2^63 from the first pivot to the last.  pip_advance_kernel<__int128> nevertheless keeps every
-// row as 128-bit entries: 16 registers a row of 256 columns, 128 VGPRs, 400 bytes of scratch per lane, four waves a
-// tableau of which three wait while one runs choisir_piv.  This kernel is the same loop for the regime those tableaux
-// live in and nothing else: one wave per tableau, no parameters, 129 ... 256 columns, plain cuts, rows skipped -- and
+// tests/golden/gmp/wide128.json) the reference's GMP build forms a value beyond 2^63 on 587, yet on two in three every
+// STORED entry stays below 2^63 from the first pivot to the last (measured with this kernel: 657 of the 1,000 finish in
+// it, 325 leave on a row beyond 2^63).  pip_advance_kernel<__int128> keeps every row as 128-bit entries: 16 registers a
+// row of 256 columns, 128 VGPRs, 400 bytes of scratch per lane, four waves a tableau of which three wait while one runs
+// choisir_piv.  This kernel is the same loop for the regime those tableaux live in and nothing else (OPT-IN,
+// pipamd_engine_set_lean64: measured on that batch it is no faster than the four-wave 128-bit kernel): one wave per tableau, no parameters, 129 ... 256 columns, plain cuts, rows skipped -- and
 // EVERY entry of EVERY row below 2^63 in magnitude, i.e. a long long.  Under that invariant
 //   * rows live in HBM as long longs (8 W bytes, the first half of the row's slot of W 128-bit entries), lane l holds
 //     columns l, 64 + l, 128 + l, 192 + l (the geometry of pip_advance_kernel<__int128, 4>, so that the saved summaries
