@@ -3,10 +3,10 @@
  *
  *   gcc -O2 examples/batch_stream.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Lpiplib_amd -lpipamd \
  *       -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../piplib_amd' -o examples/batch_stream
- *   examples/batch_stream rows.bin <batches> <tableaux> <nvar> <ni> <lanes> <steps>
+ *   examples/batch_stream rows.bin <batches> <tableaux> <nvar> <ni> <lanes> <steps> [<nq>]
  *
  * rows.bin: <batches> x <tableaux> x <ni> x (<nvar>+1) int64, row-major (PIP column order unknowns | constant), no
- * parameters; integer solve.  The batches are made resident in HBM, every batch is solved once for its pivot count,
+ * parameters; integer solve (<nq> = 0: rational solve, the reference's Nq).  The batches are made resident in HBM, every batch is solved once for its pivot count,
  * then <steps> steps are timed: step k = pipamd_batch_load + pipamd_batch_solve_async + pipamd_batch_results of batch
  * k mod <batches> on whichever of the <lanes> lanes (engine + workspace + stream) is free; the thread goes round
  * pipamd_batch_poll.  Prints one line: tableaux, pivots, milliseconds, pivots/s, and the status histogram of the last
@@ -59,9 +59,9 @@ int main(int argc, char **argv) {
     return 64;
   }
   const int nb = atoi(argv[2]), B = atoi(argv[3]), nvar = atoi(argv[4]), ni = atoi(argv[5]), K = atoi(argv[6]),
-            steps = atoi(argv[7]);
+            steps = atoi(argv[7]), nq = argc > 8 ? atoi(argv[8]) : 1;
   const size_t per = (size_t)B * ni * (nvar + 1);
-  pipamd_batch_desc d = {B, nvar, 0, ni, -1, PIPAMD_T_INT | PIPAMD_T_ROWS_STAY, ni + 64, 0, 64};
+  pipamd_batch_desc d = {B, nvar, 0, ni, -1, (nq ? PIPAMD_T_INT : 0) | PIPAMD_T_ROWS_STAY, nq ? ni + 64 : 0, 0, 64};
   int64_t *h = malloc(per * nb * sizeof(int64_t)), **rows = malloc(nb * sizeof *rows);
   uint64_t *piv_of = calloc(nb, sizeof *piv_of), *d_cnt, cnt[4];
   lane_t *L = calloc(K, sizeof *L);
