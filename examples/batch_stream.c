@@ -3,7 +3,7 @@
  *
  *   gcc -O2 examples/batch_stream.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Lpiplib_amd -lpipamd \
  *       -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../piplib_amd' -o examples/batch_stream
- *   examples/batch_stream rows.bin <batches> <tableaux> <nvar> <ni> <lanes> <steps> [<nq>]
+ *   examples/batch_stream rows.bin <batches> <tableaux> <nvar> <ni> <lanes> <steps>  [<nq> [<lone>]]
  *
  * rows.bin: <batches> x <tableaux> x <ni> x (<nvar>+1) int64, row-major (PIP column order unknowns | constant), no
  * parameters; integer solve (<nq> = 0: rational solve, the reference's Nq).  The batches are made resident in HBM, every batch is solved once for its pivot count,
@@ -55,11 +55,12 @@ static double now_ms(void) {
 
 int main(int argc, char **argv) {
   if (argc < 8) {
-    fprintf(stderr, "usage: %s rows.bin batches tableaux nvar ni lanes steps\n", argv[0]);
+    fprintf(stderr, "usage: %s rows.bin batches tableaux nvar ni lanes steps [nq [lone]]\n", argv[0]);
     return 64;
   }
   const int nb = atoi(argv[2]), B = atoi(argv[3]), nvar = atoi(argv[4]), ni = atoi(argv[5]), K = atoi(argv[6]),
-            steps = atoi(argv[7]), nq = argc > 8 ? atoi(argv[8]) : 1;
+            steps = atoi(argv[7]), nq = argc > 8 ? atoi(argv[8]) : 1,
+            lone = argc > 9 ? atoi(argv[9]) : 0; /* 1: pipamd_engine_set_lone_batches (no second one-wave launch) */
   const size_t per = (size_t)B * ni * (nvar + 1);
   pipamd_batch_desc d = {B, nvar, 0, ni, -1, (nq ? PIPAMD_T_INT : 0) | PIPAMD_T_ROWS_STAY, nq ? ni + 64 : 0, 0, 64};
   int64_t *h = malloc(per * nb * sizeof(int64_t)), **rows = malloc(nb * sizeof *rows);
@@ -81,6 +82,7 @@ int main(int argc, char **argv) {
     CHECK(pipamd_engine_create(&L[i].e, 0));
     CHECK(pipamd_engine_set_timing(L[i].e, 0));
     CHECK(pipamd_engine_set_bulk_min(L[i].e, 256));
+    if (lone) CHECK(pipamd_engine_set_lone_batches(L[i].e, 1));
     CHECK(pipamd_engine_set_max_rows(L[i].e, ni + 1024)); /* a tableau on which the cuts do not converge ends CAPACITY */
     HIP(hipStreamCreateWithFlags(&L[i].st, hipStreamNonBlocking));
     HIP(hipMalloc(&L[i].ws, pipamd_batch_workspace_bytes(&d)));
