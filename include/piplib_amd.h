@@ -266,7 +266,8 @@ int pipamd_traiter(pipamd_engine *e, int nvar, int nparm, int ni, int nc, int bi
  * with a wider Entier (include/piplib/piplib.h:42-88): device tableaux, context, parametric cuts
  * and tape all carry __int128 here; the input rows are int64, the cells' parameters come back as
  * (low, high) int64 pairs.  Tableaux must fit a workgroup's LDS (about 1,600 rows of <= 128
- * columns); the lock-step scheduler stays 64-bit. */
+ * columns).  Small problems run their whole decision tree on the device in this flavour too (the 128-bit instantiation
+ * of csrc/pip_quast.hip), many problems go through pipamd_solve_tableaux128 / pipamd_solve_tableaux_lockstep128. */
 typedef struct pipamd_sol_cell128 {
   int32_t kind, reserved;
   int64_t param1_lo, param1_hi, param2_lo, param2_hi;
@@ -300,8 +301,8 @@ int pipamd_solve_tableaux(pipamd_engine *e, int n, const pipamd_problem *problem
                           int deepest_cut, int nthreads, pipamd_sol_cell **cells, size_t *n_cells, int *rcs,
                           int *statuses, int64_t *pivots);
 
-/* The same on 128-bit entries (one TreeT<__int128> per host thread; cells as pipamd_traiter128 hands them out).  The
- * device-resident traiter() below stays 64-bit; the lock-step scheduler has a 128-bit entry (pipamd_solve_tableaux_lockstep128). */
+/* The same on 128-bit entries (small problems on the device first, then one TreeT<__int128> per host thread; cells as
+ * pipamd_traiter128 hands them out); the lock-step scheduler has a 128-bit entry too (pipamd_solve_tableaux_lockstep128). */
 int pipamd_solve_tableaux128(pipamd_engine *e, int n, const pipamd_problem *problems, int simplify,
                              int deepest_cut, int nthreads, pipamd_sol_cell128 **cells, size_t *n_cells, int *rcs,
                              int *statuses, int64_t *pivots);
