@@ -39,8 +39,9 @@ extern "C" {
  * pipamd_quast_*) is gone: pip_solve stays the reference's piplib.c over bindings/piplib_traiter_hook.c.
  * 300: round 3 -- pipamd_batch_solve_async / _wait / _poll, pipamd_batch_load_part, unbounded row growth in the
  * batch layer (no PIPAMD_ST_CAPACITY short of the engine's 16,000-row limit), pipamd_solve_tableaux128,
- * pipamd_engine_set_max_rows. */
-#define PIPAMD_VERSION 300
+ * pipamd_engine_set_max_rows.  400: round 4 -- pipamd_solve_tableaux_lockstep128, pipamd_engine_set_lean64; the 128-bit
+ * entries try the device-resident traiter() first (pipamd_last_device_tree answers for them too); nothing removed. */
+#define PIPAMD_VERSION 400
 
 /* ---- error codes (return values) ---- */
 #define PIPAMD_OK 0

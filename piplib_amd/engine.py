@@ -21,7 +21,7 @@ class BatchDesc(C.Structure):
                 ("batch", "nvar", "nparm", "ni", "bigparm", "tflags", "cap_cuts", "cap_newparm", "entier_bits")]
 
 
-ABI_VERSION = 300  # include/piplib_amd.h PIPAMD_VERSION
+ABI_VERSION = 400  # include/piplib_amd.h PIPAMD_VERSION
 _lib = None
 
 
